@@ -1,0 +1,146 @@
+/*
+ * libottispartan — C ABI of the MI355X-native Spartan NIZK proving path for Otti.
+ *
+ * Drop-in boundary.  The reference reaches this path in two ways:
+ *   - as a process: `spzk verify --nizk X.zkif X.inp.zkif X.wit.zkif`        [REF /root/reference/run.py:52-59, run.py:96-100]
+ *   - in-process, as libspartan calls from rust-circ `--action spartan`       [REF /root/reference/run.py:147]
+ * The library-level interface those callers bind is upstream libspartan's `src/lib.rs` [RECALL — the Spartan/ submodule is an
+ * empty directory in the reference mount, /root/reference/.gitmodules:4-6]; every entry point below names the item it replaces.
+ *
+ * Conventions: plain pointers and sizes; int32 status (0 = ok, negatives mirror upstream's error enums); inputs are borrowed for
+ * the duration of the call; outputs are owned by the library until the matching *_free; no exceptions cross the ABI; handles are
+ * not thread-safe, distinct handles are.  All scalars are 32-byte canonical little-endian encodings of GF(l),
+ * l = 2^252 + 27742317777372353535851937790883648493, unless a comment says "Montgomery" (the in-HBM layout: value*2^256 mod l).
+ */
+#ifndef OTTI_SPARTAN_H
+#define OTTI_SPARTAN_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* upstream R1CSError / ProofVerifyError [RECALL src/errors.rs] */
+enum {
+    OTTI_OK = 0,
+    OTTI_ERR_NON_POW2_CONS = -1,
+    OTTI_ERR_NON_POW2_VARS = -2,
+    OTTI_ERR_INVALID_NUM_INPUTS = -3,
+    OTTI_ERR_INVALID_NUM_VARS = -4,
+    OTTI_ERR_INVALID_SCALAR = -5,
+    OTTI_ERR_INVALID_INDEX = -6,
+    OTTI_ERR_VERIFY_INTERNAL = -10,       /* ProofVerifyError::InternalError */
+    OTTI_ERR_VERIFY_DECOMPRESS = -11,     /* ProofVerifyError::DecompressionError */
+    OTTI_ERR_MALFORMED_PROOF = -12,       /* bincode deserialisation failure */
+    OTTI_ERR_NO_DEVICE = -20,             /* no gfx950 device / HIP failure: the proving path has no CPU fallback */
+    OTTI_ERR_BAD_ARG = -21,
+    OTTI_ERR_IO = -22,                    /* zkInterface file unreadable / malformed */
+    OTTI_ERR_INTERNAL = -23
+};
+
+/* one non-zero of A, B or C: upstream `(usize, usize, [u8; 32])` tuples passed to Instance::new */
+typedef struct { uint64_t row; uint64_t col; uint8_t val[32]; } otti_entry;
+
+typedef struct otti_instance otti_instance;   /* upstream `Instance` */
+typedef struct otti_gens otti_gens;           /* upstream `NIZKGens` */
+
+/* flags for otti_nizk_prove */
+#define OTTI_FLAG_GPU 0x1u                    /* required: the only proving backend */
+
+/* Instance::new(num_cons, num_vars, num_inputs, &A, &B, &C) -> Result<Instance, R1CSError>.
+   Pads cons/vars to powers of two, shifts columns >= num_vars by the padding, rejects bad indices / non-canonical scalars. */
+int32_t otti_instance_new(uint64_t num_cons, uint64_t num_vars, uint64_t num_inputs,
+                          const otti_entry *A, size_t nA, const otti_entry *B, size_t nB, const otti_entry *C, size_t nC,
+                          otti_instance **out);
+void    otti_instance_free(otti_instance *inst);
+/* padded sizes as seen by the prover (Instance.inst.get_num_cons / get_num_vars / get_num_inputs) */
+int32_t otti_instance_dims(const otti_instance *inst, uint64_t *num_cons, uint64_t *num_vars, uint64_t *num_inputs);
+/* Instance::is_sat(&vars, &inputs) -> Result<bool, R1CSError>  (host check, used by spzk before proving) */
+int32_t otti_instance_is_sat(const otti_instance *inst, const uint8_t *vars32, size_t nvars, const uint8_t *inputs32, size_t ninputs,
+                             int32_t *sat);
+
+/* NIZKGens::new(num_cons, num_vars, num_inputs) */
+int32_t otti_gens_new(uint64_t num_cons, uint64_t num_vars, uint64_t num_inputs, otti_gens **out);
+void    otti_gens_free(otti_gens *gens);
+/* compressed generator stream P[0 .. count) (tests pin it against SURVEY App. B) */
+int32_t otti_gens_points(const otti_gens *gens, uint8_t *out32, size_t count);
+
+/* NIZK::prove(&inst, vars, &inputs, &gens, &mut Transcript::new(tlabel)) -> NIZK, bincode-serialised.
+   VarsAssignment::new / InputsAssignment::new validation (InvalidScalar) happens here.
+   seed32: 32 bytes seeding the prover's RandomTape (upstream uses OsRng; NULL => OS entropy).
+   stage_ms: optional 8 doubles — polycommit, multiply_vec, sc_phase_one, eval_table_sparse, sc_phase_two, polyeval, total, 0. */
+int32_t otti_nizk_prove(otti_instance *inst, const uint8_t *vars32, size_t nvars, const uint8_t *inputs32, size_t ninputs,
+                        otti_gens *gens, const uint8_t *tlabel, size_t tlabel_len, const uint8_t *seed32, uint32_t flags,
+                        uint8_t **proof, size_t *proof_len, double *stage_ms);
+/* The same proof with the witness already resident in HBM (z = vars || 1 || inputs || 0.. in Montgomery form): upload once,
+   prove many times.  This is the boundary bench.py times: no PCIe traffic inside otti_nizk_prove_resident except the
+   per-round field elements and the compressed points of the proof itself. */
+typedef struct otti_witness otti_witness;
+int32_t otti_witness_upload(otti_instance *inst, const uint8_t *vars32, size_t nvars, const uint8_t *inputs32, size_t ninputs, otti_witness **out);
+void    otti_witness_free(otti_witness *w);
+int32_t otti_nizk_prove_resident(otti_instance *inst, otti_witness *wit, otti_gens *gens, const uint8_t *tlabel, size_t tlabel_len,
+                                 const uint8_t *seed32, uint8_t **proof, size_t *proof_len, double *stage_ms);
+/* NIZK::verify(&self, &inst, &inputs, &mut Transcript::new(tlabel), &gens) -> Result<(), ProofVerifyError> */
+int32_t otti_nizk_verify(const otti_instance *inst, const uint8_t *inputs32, size_t ninputs, const otti_gens *gens,
+                         const uint8_t *tlabel, size_t tlabel_len, const uint8_t *proof, size_t proof_len);
+void    otti_buf_free(void *p);
+/* copies the calling thread's last error message (NUL-terminated, truncated to cap) */
+size_t  otti_last_error(char *buf, size_t cap);
+
+/* upload instance / build the generator window table ahead of the first prove (both are otherwise lazy) */
+int32_t otti_prepare_device(otti_instance *inst, otti_gens *gens);
+/* number of visible gfx950 devices (0 when none; never initialises a context) */
+int32_t otti_device_count(void);
+
+/* ---- zkInterface ingest (replaces spartan-zkinterface's reader; schema zkinterface 1.x) ---- */
+typedef struct {
+    uint64_t num_cons, num_vars, num_inputs;
+    otti_entry *A, *B, *C; size_t nA, nB, nC;
+    uint8_t *vars32; size_t nvars;         /* witness assignment, canonical LE */
+    uint8_t *inputs32; size_t ninputs;     /* instance (public input) assignment */
+} otti_r1cs;
+int32_t otti_zkif_load(const char *circuit_path, const char *inputs_path, const char *witness_path, otti_r1cs **out);
+/* writes the three-file split the reference compiler produces [REF run.py:47-49] from an R1CS in z-order [vars | 1 | inputs] */
+int32_t otti_zkif_write(const otti_r1cs *r, const char *circuit_path, const char *inputs_path, const char *witness_path);
+void    otti_r1cs_free(otti_r1cs *r);
+/* synthetic satisfiable R1CS: num_cons = num_vars = n, one non-zero per row per matrix */
+int32_t otti_synth_r1cs(uint64_t n, uint64_t num_inputs, uint64_t seed, otti_r1cs **out);
+
+/* ---- kernel-level entry points (tests / bench).  h_* = host pointers; elements are 32-byte Montgomery-form Fr.
+        Each call stages inputs to HBM, runs the named kernel(s) on the library's stream, and copies results back;
+        kernel_ms (optional) receives the HIP-event time of the kernel launches alone. ---- */
+/* Fr/Fp/point self-test kernels: out[i] = a[i] * b[i] etc.  op: 0 mul, 1 add, 2 sub */
+int32_t otti_k_fr_op(int32_t op, const uint8_t *h_a, const uint8_t *h_b, uint8_t *h_out, size_t n, float *kernel_ms);
+/* canonical LE <-> Montgomery on the device */
+int32_t otti_k_fr_from_canonical(const uint8_t *h_in, uint8_t *h_out, size_t n);
+int32_t otti_k_fr_to_canonical(const uint8_t *h_in, uint8_t *h_out, size_t n);
+/* R1CSInstance::multiply_vec: z has 2*num_vars entries; outputs num_cons entries each */
+int32_t otti_k_multiply_vec(otti_instance *inst, const uint8_t *h_z, uint8_t *h_Az, uint8_t *h_Bz, uint8_t *h_Cz, float *kernel_ms);
+/* compute_eval_table_sparse x3 fused with r_A*A + r_B*B + r_C*C: eq_rx has num_cons entries, out 2*num_vars */
+int32_t otti_k_eval_table_sparse(otti_instance *inst, const uint8_t *h_eq_rx, const uint8_t *h_rABC /* 3 */, uint8_t *h_out, float *kernel_ms);
+/* EqPolynomial::evals */
+int32_t otti_k_eq_evals(const uint8_t *h_r, size_t ell, uint8_t *h_out, float *kernel_ms);
+/* DensePolynomial::bound_poly_var_top / _bot (in place on a staged copy; out has len/2 entries) */
+int32_t otti_k_fold_top(const uint8_t *h_Z, size_t len, const uint8_t *h_r, uint8_t *h_out, float *kernel_ms);
+int32_t otti_k_fold_bot(const uint8_t *h_Z, size_t len, const uint8_t *h_r, uint8_t *h_out, float *kernel_ms);
+/* one round of prove_cubic_with_additive_term's table work: (e0,e2,e3) of A*(B*C-D) over tables of length len */
+int32_t otti_k_sc_cubic_round(const uint8_t *h_A, const uint8_t *h_B, const uint8_t *h_C, const uint8_t *h_D, size_t len, uint8_t *h_e3, float *kernel_ms);
+/* fused fold(r) + next round's sums: tables of length len are folded to len/2 (written to h_out4, 4*len/2) and (e0,e2,e3) returned */
+int32_t otti_k_sc_cubic_fold_round(const uint8_t *h_A, const uint8_t *h_B, const uint8_t *h_C, const uint8_t *h_D, size_t len,
+                                   const uint8_t *h_r, uint8_t *h_out4, uint8_t *h_e3, float *kernel_ms);
+/* one round of prove_quad: (e0,e2) of A*B */
+int32_t otti_k_sc_quad_round(const uint8_t *h_A, const uint8_t *h_B, size_t len, uint8_t *h_e2, float *kernel_ms);
+int32_t otti_k_sc_quad_fold_round(const uint8_t *h_A, const uint8_t *h_B, size_t len, const uint8_t *h_r, uint8_t *h_out2, uint8_t *h_e2, float *kernel_ms);
+/* DensePolynomial::commit_inner: L rows of R scalars -> L compressed points C_i = sum_j Z[iR+j] P[j] + blinds[i] P[R+1] */
+int32_t otti_k_msm_rows(otti_gens *gens, const uint8_t *h_Z, size_t L, size_t R, const uint8_t *h_blinds, uint8_t *h_out32, float *kernel_ms);
+
+/* ---- multi-GPU plumbing: sum-check partial sums travel as 8 x u32 limbs widened to u64 lanes so that a plain integer
+        sum all-reduce (RCCL ncclSum/ncclUint64, or gloo in CPU tests) followed by one normalisation gives the Fr sum ---- */
+void    otti_lanes_pack(const uint8_t *fr_mont32, size_t n, uint64_t *lanes /* 8n */);
+void    otti_lanes_unpack(const uint64_t *lanes, size_t n, uint8_t *fr_mont32);   /* reduces each 8-lane group mod l */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

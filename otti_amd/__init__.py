@@ -1,0 +1,13 @@
+"""otti_amd — MI355X-native Spartan NIZK proving path for Otti.
+
+Python mirror of the libspartan interface the reference's callers use [RECALL upstream `src/lib.rs`:
+Instance, VarsAssignment, InputsAssignment, NIZKGens, NIZK::{prove, verify}; the Spartan/ submodule is an empty
+directory in /root/reference], bound over the C ABI of ``libottispartan.so`` (include/otti_spartan.h) with ctypes.
+There is no CPU proving path: without the HIP library and a gfx950 device ``NIZK.prove`` raises.
+"""
+from .api import (  # noqa: F401
+    ENTRY_DTYPE, SpartanError, R1CSError, ProofVerifyError, NoDeviceError,
+    Instance, VarsAssignment, InputsAssignment, NIZKGens, NIZK, Witness,
+    synth_r1cs, zkif_load, zkif_write, device_count, lib, lib_path,
+    fr_from_ints, fr_to_ints, kernels, lanes_pack, lanes_unpack, L_ORDER,
+)

@@ -1,0 +1,457 @@
+"""ctypes binding of libottispartan.so — same names, argument meaning and error behaviour as upstream libspartan's
+`src/lib.rs` for the NIZK path [RECALL], which is what `spzk verify --nizk` [REF /root/reference/run.py:58,100] and
+rust-circ `--action spartan` [REF /root/reference/run.py:147] call."""
+import ctypes
+import os
+import numpy as np
+
+L_ORDER = 2 ** 252 + 27742317777372353535851937790883648493
+_R = (1 << 256) % L_ORDER
+_RINV = pow(_R, -1, L_ORDER)
+
+ENTRY_DTYPE = np.dtype([("row", "<u8"), ("col", "<u8"), ("val", "u1", (32,))])   # otti_entry
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+lib_path = os.path.join(_HERE, "libottispartan.so")
+
+
+class SpartanError(Exception):
+    def __init__(self, code, msg=""):
+        super().__init__(f"{type(self).__name__}({code}): {msg}")
+        self.code = code
+
+
+class R1CSError(SpartanError):
+    """upstream R1CSError: InvalidNumberOfInputs(-3) InvalidNumberOfVars(-4) InvalidScalar(-5) InvalidIndex(-6)"""
+
+
+class ProofVerifyError(SpartanError):
+    """upstream ProofVerifyError: InternalError(-10) DecompressionError(-11); -12 = malformed proof bytes"""
+
+
+class NoDeviceError(SpartanError):
+    """no gfx950 device or HIP failure — the proving path has no CPU fallback"""
+
+
+def _load():
+    if not os.path.exists(lib_path):
+        raise ImportError(
+            f"{lib_path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(make -C otti_amd/csrc). otti_amd has no pure-Python or CPU fallback.")
+    return ctypes.CDLL(lib_path)
+
+
+lib = _load()
+_sz, _u64, _i32, _vp = ctypes.c_size_t, ctypes.c_uint64, ctypes.c_int32, ctypes.c_void_p
+_u8p = ctypes.POINTER(ctypes.c_uint8)
+
+
+class _R1CS(ctypes.Structure):
+    _fields_ = [("num_cons", _u64), ("num_vars", _u64), ("num_inputs", _u64),
+                ("A", _vp), ("B", _vp), ("C", _vp), ("nA", _sz), ("nB", _sz), ("nC", _sz),
+                ("vars32", _vp), ("nvars", _sz), ("inputs32", _vp), ("ninputs", _sz)]
+
+
+def _sig(name, res, *args):
+    f = getattr(lib, name)
+    f.restype = res
+    f.argtypes = list(args)
+    return f
+
+
+_sig("otti_last_error", _sz, ctypes.c_char_p, _sz)
+_sig("otti_buf_free", None, _vp)
+_sig("otti_device_count", _i32)
+_sig("otti_instance_new", _i32, _u64, _u64, _u64, _vp, _sz, _vp, _sz, _vp, _sz, ctypes.POINTER(_vp))
+_sig("otti_instance_free", None, _vp)
+_sig("otti_instance_dims", _i32, _vp, ctypes.POINTER(_u64), ctypes.POINTER(_u64), ctypes.POINTER(_u64))
+_sig("otti_instance_is_sat", _i32, _vp, _vp, _sz, _vp, _sz, ctypes.POINTER(_i32))
+_sig("otti_gens_new", _i32, _u64, _u64, _u64, ctypes.POINTER(_vp))
+_sig("otti_gens_free", None, _vp)
+_sig("otti_gens_points", _i32, _vp, _vp, _sz)
+_sig("otti_nizk_prove", _i32, _vp, _vp, _sz, _vp, _sz, _vp, ctypes.c_char_p, _sz, _vp, ctypes.c_uint32,
+     ctypes.POINTER(_vp), ctypes.POINTER(_sz), ctypes.POINTER(ctypes.c_double))
+_sig("otti_witness_upload", _i32, _vp, _vp, _sz, _vp, _sz, ctypes.POINTER(_vp))
+_sig("otti_witness_free", None, _vp)
+_sig("otti_nizk_prove_resident", _i32, _vp, _vp, _vp, ctypes.c_char_p, _sz, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_sz),
+     ctypes.POINTER(ctypes.c_double))
+_sig("otti_nizk_verify", _i32, _vp, _vp, _sz, _vp, ctypes.c_char_p, _sz, _vp, _sz)
+_sig("otti_prepare_device", _i32, _vp, _vp)
+_sig("otti_zkif_load", _i32, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.POINTER(_R1CS)))
+_sig("otti_zkif_write", _i32, ctypes.POINTER(_R1CS), ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p)
+_sig("otti_r1cs_free", None, ctypes.POINTER(_R1CS))
+_sig("otti_synth_r1cs", _i32, _u64, _u64, _u64, ctypes.POINTER(ctypes.POINTER(_R1CS)))
+_sig("otti_lanes_pack", None, _vp, _sz, _vp)
+_sig("otti_lanes_unpack", None, _vp, _sz, _vp)
+_fp = ctypes.POINTER(ctypes.c_float)
+_sig("otti_k_fr_op", _i32, _i32, _vp, _vp, _vp, _sz, _fp)
+_sig("otti_k_fr_from_canonical", _i32, _vp, _vp, _sz)
+_sig("otti_k_fr_to_canonical", _i32, _vp, _vp, _sz)
+_sig("otti_k_multiply_vec", _i32, _vp, _vp, _vp, _vp, _vp, _fp)
+_sig("otti_k_eval_table_sparse", _i32, _vp, _vp, _vp, _vp, _fp)
+_sig("otti_k_eq_evals", _i32, _vp, _sz, _vp, _fp)
+_sig("otti_k_fold_top", _i32, _vp, _sz, _vp, _vp, _fp)
+_sig("otti_k_fold_bot", _i32, _vp, _sz, _vp, _vp, _fp)
+_sig("otti_k_sc_cubic_round", _i32, _vp, _vp, _vp, _vp, _sz, _vp, _fp)
+_sig("otti_k_sc_cubic_fold_round", _i32, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _fp)
+_sig("otti_k_sc_quad_round", _i32, _vp, _vp, _sz, _vp, _fp)
+_sig("otti_k_sc_quad_fold_round", _i32, _vp, _vp, _sz, _vp, _vp, _vp, _fp)
+_sig("otti_k_msm_rows", _i32, _vp, _vp, _sz, _sz, _vp, _vp, _fp)
+
+
+def _last_error():
+    buf = ctypes.create_string_buffer(512)
+    lib.otti_last_error(buf, 512)
+    return buf.value.decode(errors="replace")
+
+
+def _check(rc):
+    if rc == 0:
+        return
+    msg = _last_error()
+    if rc in (-10, -11, -12):
+        raise ProofVerifyError(rc, msg)
+    if rc == -20:
+        raise NoDeviceError(rc, msg)
+    if -6 <= rc <= -1:
+        raise R1CSError(rc, msg)
+    raise SpartanError(rc, msg)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_vp) if a is not None and a.size else None
+
+
+def _scalars(a, what):
+    """(n,32) uint8 array of canonical little-endian scalars"""
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    if a.ndim == 1:
+        a = a.reshape(-1, 32)
+    if a.ndim != 2 or a.shape[1] != 32:
+        raise ValueError(f"{what}: expected an (n, 32) uint8 array")
+    return a
+
+
+def device_count():
+    return int(lib.otti_device_count())
+
+
+# ---------------------------------------------------------------------------------------------- libspartan mirror
+class Instance:
+    """Instance::new(num_cons, num_vars, num_inputs, &A, &B, &C) -> Result<Instance, R1CSError>"""
+
+    def __init__(self, handle, entries):
+        self._h = handle
+        self._keep = entries
+
+    @classmethod
+    def new(cls, num_cons, num_vars, num_inputs, A, B, C):
+        ents = [np.ascontiguousarray(m, dtype=ENTRY_DTYPE) for m in (A, B, C)]
+        h = _vp()
+        _check(lib.otti_instance_new(num_cons, num_vars, num_inputs, _ptr(ents[0]), ents[0].size, _ptr(ents[1]), ents[1].size,
+                                     _ptr(ents[2]), ents[2].size, ctypes.byref(h)))
+        return cls(h, ents)
+
+    @property
+    def dims(self):
+        a, b, c = _u64(), _u64(), _u64()
+        _check(lib.otti_instance_dims(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        return a.value, b.value, c.value
+
+    def is_sat(self, vars_, inputs):
+        v, i = _scalars(vars_.assignment, "vars"), _scalars(inputs.assignment, "inputs")
+        sat = _i32()
+        _check(lib.otti_instance_is_sat(self._h, _ptr(v), v.shape[0], _ptr(i), i.shape[0], ctypes.byref(sat)))
+        return bool(sat.value)
+
+    def prepare_device(self, gens=None):
+        _check(lib.otti_prepare_device(self._h, gens._h if gens is not None else None))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib.otti_instance_free(self._h)
+            self._h = None
+
+
+def _validate_scalars(a):
+    # Scalar::from_bytes: canonical iff < l  (upstream returns Err(R1CSError::InvalidScalar))
+    if a.shape[0] == 0:
+        return
+    words = a.view("<u8").reshape(-1, 4)
+    lw = [(L_ORDER >> (64 * k)) & (2 ** 64 - 1) for k in range(4)]
+    bad = np.zeros(a.shape[0], dtype=bool)
+    undecided = np.ones(a.shape[0], dtype=bool)
+    for k in (3, 2, 1, 0):
+        gt = undecided & (words[:, k] > np.uint64(lw[k]))
+        lt = undecided & (words[:, k] < np.uint64(lw[k]))
+        bad |= gt
+        undecided &= ~(gt | lt)
+    bad |= undecided   # equal to l
+    if bad.any():
+        raise R1CSError(-5, "InvalidScalar")
+
+
+class VarsAssignment:
+    """VarsAssignment::new(&[[u8; 32]]) -> Result<_, R1CSError::InvalidScalar>"""
+
+    def __init__(self, assignment):
+        self.assignment = assignment
+
+    @classmethod
+    def new(cls, assignment):
+        a = _scalars(assignment, "assignment")
+        _validate_scalars(a)
+        return cls(a)
+
+
+class InputsAssignment(VarsAssignment):
+    """InputsAssignment::new(&[[u8; 32]])"""
+
+
+class NIZKGens:
+    """NIZKGens::new(num_cons, num_vars, num_inputs)"""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @classmethod
+    def new(cls, num_cons, num_vars, num_inputs):
+        h = _vp()
+        _check(lib.otti_gens_new(num_cons, num_vars, num_inputs, ctypes.byref(h)))
+        return cls(h)
+
+    def points(self, count):
+        out = np.zeros((count, 32), dtype=np.uint8)
+        _check(lib.otti_gens_points(self._h, _ptr(out), count))
+        return out
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib.otti_gens_free(self._h)
+            self._h = None
+
+
+class Witness:
+    """Assignment resident in HBM (z = vars || 1 || inputs || 0..): upload once, prove many times."""
+
+    def __init__(self, inst, vars_, inputs):
+        v, i = _scalars(vars_.assignment, "vars"), _scalars(inputs.assignment, "inputs")
+        h = _vp()
+        _check(lib.otti_witness_upload(inst._h, _ptr(v), v.shape[0], _ptr(i), i.shape[0], ctypes.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib.otti_witness_free(self._h)
+            self._h = None
+
+
+STAGES = ("polycommit", "multiply_vec", "sc_phase_one", "eval_table_sparse", "sc_phase_two", "polyeval", "total")
+
+
+class NIZK:
+    """NIZK::prove(&inst, vars, &inputs, &gens, &mut Transcript::new(label)) / NIZK::verify(...)"""
+
+    def __init__(self, proof_bytes, stage_ms=None):
+        self.bytes = proof_bytes
+        self.stage_ms = stage_ms
+
+    @staticmethod
+    def _take(ptr, n):
+        data = ctypes.string_at(ptr, n.value)
+        lib.otti_buf_free(ptr)
+        return data
+
+    @classmethod
+    def prove(cls, inst, vars_, inputs, gens, transcript_label=b"nizk_example", seed=None):
+        label = bytes(transcript_label)
+        if isinstance(vars_, Witness):
+            w = vars_
+            p, n, ms = _vp(), _sz(), (ctypes.c_double * 8)()
+            _check(lib.otti_nizk_prove_resident(inst._h, w._h, gens._h, label, len(label), _seed(seed), ctypes.byref(p), ctypes.byref(n), ms))
+            return cls(cls._take(p, n), dict(zip(STAGES, ms)))
+        v, i = _scalars(vars_.assignment, "vars"), _scalars(inputs.assignment, "inputs")
+        p, n, ms = _vp(), _sz(), (ctypes.c_double * 8)()
+        _check(lib.otti_nizk_prove(inst._h, _ptr(v), v.shape[0], _ptr(i), i.shape[0], gens._h, label, len(label), _seed(seed), 1,
+                                   ctypes.byref(p), ctypes.byref(n), ms))
+        return cls(cls._take(p, n), dict(zip(STAGES, ms)))
+
+    def verify(self, inst, inputs, gens, transcript_label=b"nizk_example"):
+        """Ok(()) -> None; Err(ProofVerifyError) -> raises"""
+        label = bytes(transcript_label)
+        i = _scalars(inputs.assignment, "inputs")
+        buf = np.frombuffer(self.bytes, dtype=np.uint8)
+        _check(lib.otti_nizk_verify(inst._h, _ptr(i), i.shape[0], gens._h, label, len(label), _ptr(buf), buf.size))
+
+
+def _seed(seed):
+    if seed is None:
+        return None
+    seed = bytes(seed)
+    if len(seed) != 32:
+        raise ValueError("seed must be 32 bytes")
+    return ctypes.cast(ctypes.create_string_buffer(seed, 32), _vp)
+
+
+# ---------------------------------------------------------------------------------------------- ingest / synthetic
+def _r1cs_to_py(rp):
+    r = rp.contents
+
+    def ents(p, n):
+        if not n:
+            return np.zeros(0, dtype=ENTRY_DTYPE)
+        return np.ctypeslib.as_array(ctypes.cast(p, _u8p), shape=(n * ENTRY_DTYPE.itemsize,)).view(ENTRY_DTYPE).copy()
+
+    def bytes32(p, n):
+        if not n:
+            return np.zeros((0, 32), dtype=np.uint8)
+        return np.ctypeslib.as_array(ctypes.cast(p, _u8p), shape=(n * 32,)).reshape(n, 32).copy()
+
+    out = dict(num_cons=r.num_cons, num_vars=r.num_vars, num_inputs=r.num_inputs, A=ents(r.A, r.nA), B=ents(r.B, r.nB), C=ents(r.C, r.nC),
+               vars=bytes32(r.vars32, r.nvars), inputs=bytes32(r.inputs32, r.ninputs))
+    lib.otti_r1cs_free(rp)
+    return out
+
+
+def synth_r1cs(n, num_inputs=10, seed=1):
+    """Synthetic satisfiable R1CS of SURVEY.md 8(d): num_cons = num_vars = n, one non-zero per row per matrix."""
+    rp = ctypes.POINTER(_R1CS)()
+    _check(lib.otti_synth_r1cs(n, num_inputs, seed, ctypes.byref(rp)))
+    return _r1cs_to_py(rp)
+
+
+def zkif_load(circuit, inputs=None, witness=None):
+    rp = ctypes.POINTER(_R1CS)()
+    enc = lambda s: None if s is None else os.fsencode(s)
+    _check(lib.otti_zkif_load(enc(circuit), enc(inputs), enc(witness), ctypes.byref(rp)))
+    return _r1cs_to_py(rp)
+
+
+def zkif_write(r, circuit, inputs, witness):
+    A, B, C = (np.ascontiguousarray(r[k], dtype=ENTRY_DTYPE) for k in "ABC")
+    v, i = _scalars(r["vars"], "vars"), _scalars(r["inputs"], "inputs")
+    s = _R1CS(r["num_cons"], r["num_vars"], r["num_inputs"], _ptr(A), _ptr(B), _ptr(C), A.size, B.size, C.size, _ptr(v), v.shape[0], _ptr(i), i.shape[0])
+    _check(lib.otti_zkif_write(ctypes.byref(s), os.fsencode(circuit), os.fsencode(inputs), os.fsencode(witness)))
+
+
+# ---------------------------------------------------------------------------------------------- field element helpers (tests/bench)
+def fr_from_ints(xs):
+    """python ints -> (n,32) uint8 Montgomery-form elements (the in-HBM layout)"""
+    out = np.zeros((len(xs), 32), dtype=np.uint8)
+    for k, x in enumerate(xs):
+        out[k] = np.frombuffer(((x % L_ORDER) * _R % L_ORDER).to_bytes(32, "little"), dtype=np.uint8)
+    return out
+
+
+def fr_to_ints(a):
+    a = _scalars(a, "fr")
+    return [int.from_bytes(a[k].tobytes(), "little") * _RINV % L_ORDER for k in range(a.shape[0])]
+
+
+def lanes_pack(fr_mont):
+    a = _scalars(fr_mont, "fr")
+    out = np.zeros(a.shape[0] * 8, dtype=np.uint64)
+    lib.otti_lanes_pack(_ptr(a), a.shape[0], _ptr(out))
+    return out
+
+
+def lanes_unpack(lanes):
+    lanes = np.ascontiguousarray(lanes, dtype=np.uint64)
+    n = lanes.size // 8
+    out = np.zeros((n, 32), dtype=np.uint8)
+    lib.otti_lanes_unpack(_ptr(lanes), n, _ptr(out))
+    return out
+
+
+class kernels:
+    """Kernel-level entry points (otti_k_*): host (n,32) uint8 Montgomery arrays in, arrays out, plus kernel milliseconds."""
+
+    @staticmethod
+    def _ms():
+        return ctypes.c_float(0)
+
+    @staticmethod
+    def fr_op(op, a, b):
+        a, b = _scalars(a, "a"), _scalars(b, "b")
+        out, ms = np.zeros_like(a), ctypes.c_float(0)
+        _check(lib.otti_k_fr_op({"mul": 0, "add": 1, "sub": 2}[op], _ptr(a), _ptr(b), _ptr(out), a.shape[0], ctypes.byref(ms)))
+        return out, ms.value
+
+    @staticmethod
+    def from_canonical(a):
+        a = _scalars(a, "a"); out = np.zeros_like(a)
+        _check(lib.otti_k_fr_from_canonical(_ptr(a), _ptr(out), a.shape[0])); return out
+
+    @staticmethod
+    def to_canonical(a):
+        a = _scalars(a, "a"); out = np.zeros_like(a)
+        _check(lib.otti_k_fr_to_canonical(_ptr(a), _ptr(out), a.shape[0])); return out
+
+    @staticmethod
+    def multiply_vec(inst, z):
+        z = _scalars(z, "z"); nc, nv, _ = inst.dims
+        assert z.shape[0] == 2 * nv
+        o = [np.zeros((nc, 32), dtype=np.uint8) for _ in range(3)]; ms = ctypes.c_float(0)
+        _check(lib.otti_k_multiply_vec(inst._h, _ptr(z), _ptr(o[0]), _ptr(o[1]), _ptr(o[2]), ctypes.byref(ms)))
+        return o[0], o[1], o[2], ms.value
+
+    @staticmethod
+    def eval_table_sparse(inst, eq_rx, rABC):
+        eq_rx, rABC = _scalars(eq_rx, "eq_rx"), _scalars(rABC, "rABC"); nc, nv, _ = inst.dims
+        assert eq_rx.shape[0] == nc and rABC.shape[0] == 3
+        out = np.zeros((2 * nv, 32), dtype=np.uint8); ms = ctypes.c_float(0)
+        _check(lib.otti_k_eval_table_sparse(inst._h, _ptr(eq_rx), _ptr(rABC), _ptr(out), ctypes.byref(ms)))
+        return out, ms.value
+
+    @staticmethod
+    def eq_evals(r):
+        r = _scalars(r, "r"); ell = r.shape[0]
+        out = np.zeros((1 << ell, 32), dtype=np.uint8); ms = ctypes.c_float(0)
+        _check(lib.otti_k_eq_evals(_ptr(r), ell, _ptr(out), ctypes.byref(ms)))
+        return out, ms.value
+
+    @staticmethod
+    def fold_top(Z, r):
+        Z, r = _scalars(Z, "Z"), _scalars(r, "r"); out = np.zeros((Z.shape[0] // 2, 32), dtype=np.uint8); ms = ctypes.c_float(0)
+        _check(lib.otti_k_fold_top(_ptr(Z), Z.shape[0], _ptr(r), _ptr(out), ctypes.byref(ms)))
+        return out, ms.value
+
+    @staticmethod
+    def fold_bot(Z, r):
+        Z, r = _scalars(Z, "Z"), _scalars(r, "r"); out = np.zeros((Z.shape[0] // 2, 32), dtype=np.uint8); ms = ctypes.c_float(0)
+        _check(lib.otti_k_fold_bot(_ptr(Z), Z.shape[0], _ptr(r), _ptr(out), ctypes.byref(ms)))
+        return out, ms.value
+
+    @staticmethod
+    def sc_cubic_round(A, B, C, D):
+        A, B, C, D = (_scalars(x, "t") for x in (A, B, C, D)); e = np.zeros((3, 32), dtype=np.uint8); ms = ctypes.c_float(0)
+        _check(lib.otti_k_sc_cubic_round(_ptr(A), _ptr(B), _ptr(C), _ptr(D), A.shape[0], _ptr(e), ctypes.byref(ms)))
+        return e, ms.value
+
+    @staticmethod
+    def sc_cubic_fold_round(A, B, C, D, r):
+        A, B, C, D, r = (_scalars(x, "t") for x in (A, B, C, D, r)); n = A.shape[0]
+        out = np.zeros((4, n // 2, 32), dtype=np.uint8); e = np.zeros((3, 32), dtype=np.uint8); ms = ctypes.c_float(0)
+        _check(lib.otti_k_sc_cubic_fold_round(_ptr(A), _ptr(B), _ptr(C), _ptr(D), n, _ptr(r), _ptr(out), _ptr(e), ctypes.byref(ms)))
+        return out, e, ms.value
+
+    @staticmethod
+    def sc_quad_round(A, B):
+        A, B = _scalars(A, "A"), _scalars(B, "B"); e = np.zeros((2, 32), dtype=np.uint8); ms = ctypes.c_float(0)
+        _check(lib.otti_k_sc_quad_round(_ptr(A), _ptr(B), A.shape[0], _ptr(e), ctypes.byref(ms)))
+        return e, ms.value
+
+    @staticmethod
+    def sc_quad_fold_round(A, B, r):
+        A, B, r = (_scalars(x, "t") for x in (A, B, r)); n = A.shape[0]
+        out = np.zeros((2, n // 2, 32), dtype=np.uint8); e = np.zeros((2, 32), dtype=np.uint8); ms = ctypes.c_float(0)
+        _check(lib.otti_k_sc_quad_fold_round(_ptr(A), _ptr(B), n, _ptr(r), _ptr(out), _ptr(e), ctypes.byref(ms)))
+        return out, e, ms.value
+
+    @staticmethod
+    def msm_rows(gens, Z, L, R, blinds):
+        Z, blinds = _scalars(Z, "Z"), _scalars(blinds, "blinds")
+        assert Z.shape[0] == L * R and blinds.shape[0] == L
+        out = np.zeros((L, 32), dtype=np.uint8); ms = ctypes.c_float(0)
+        _check(lib.otti_k_msm_rows(gens._h, _ptr(Z), L, R, _ptr(blinds), _ptr(out), ctypes.byref(ms)))
+        return out, ms.value

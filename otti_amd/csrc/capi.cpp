@@ -1,0 +1,293 @@
+// extern "C" surface of libottispartan (include/otti_spartan.h).  No exception crosses this boundary.
+#include "device.h"
+#include <array>
+#include <mutex>
+
+using namespace otti;
+
+struct otti_instance { std::unique_ptr<Instance> I; };
+struct otti_gens { std::unique_ptr<Gens> g; };
+struct otti_witness { std::unique_ptr<DeviceWitness> w; };
+
+otti_r1cs *otti_r1cs_from(size_t nc, size_t nv, size_t ni, const std::vector<otti_entry> &A, const std::vector<otti_entry> &B,
+                          const std::vector<otti_entry> &C, const std::vector<uint8_t> &vars, const std::vector<uint8_t> &inputs);
+otti_r1cs *zkif_load_impl(const char *circuit_path, const char *inputs_path, const char *witness_path);
+void zkif_write_impl(const otti_r1cs *r, const char *circuit_path, const char *inputs_path, const char *witness_path);
+
+static thread_local std::string g_last_error;
+template <class F> static int32_t guarded(F &&f) {
+    try { g_last_error.clear(); return f(); }
+    catch (const Error &e) { g_last_error = e.what(); return e.code; }
+    catch (const std::bad_alloc &) { g_last_error = "out of memory"; return OTTI_ERR_INTERNAL; }
+    catch (const std::exception &e) { g_last_error = e.what(); return OTTI_ERR_INTERNAL; }
+    catch (...) { g_last_error = "unknown error"; return OTTI_ERR_INTERNAL; }
+}
+static std::vector<Fr> scalars_from_bytes(const uint8_t *b, size_t n) {
+    std::vector<Fr> v(n);
+    for (size_t i = 0; i < n; i++) if (!fr_from_bytes(v[i], b + 32 * i)) throw Error(OTTI_ERR_INVALID_SCALAR, "non-canonical scalar in assignment");
+    return v;
+}
+// VarsAssignment::new + pad, InputsAssignment::new
+static void load_assignment(const Instance &I, const uint8_t *vars32, size_t nvars, const uint8_t *inputs32, size_t ninputs, std::vector<Fr> &vars, std::vector<Fr> &inputs) {
+    if (nvars > I.num_vars) throw Error(OTTI_ERR_INVALID_NUM_VARS, "more variables than the instance has");
+    if (ninputs != I.num_inputs) throw Error(OTTI_ERR_INVALID_NUM_INPUTS, "wrong number of inputs");
+    vars = scalars_from_bytes(vars32, nvars); vars.resize(I.num_vars, fr_zero());
+    inputs = scalars_from_bytes(inputs32, ninputs);
+}
+
+extern "C" {
+
+size_t otti_last_error(char *buf, size_t cap) {
+    if (buf && cap) { size_t n = std::min(cap - 1, g_last_error.size()); memcpy(buf, g_last_error.data(), n); buf[n] = 0; }
+    return g_last_error.size();
+}
+void otti_buf_free(void *p) { free(p); }
+
+int32_t otti_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+
+int32_t otti_instance_new(uint64_t nc, uint64_t nv, uint64_t ni, const otti_entry *A, size_t nA, const otti_entry *B, size_t nB,
+                          const otti_entry *C, size_t nC, otti_instance **out) {
+    return guarded([&] {
+        if (!out) throw Error(OTTI_ERR_BAD_ARG, "null out pointer");
+        auto h = std::make_unique<otti_instance>();
+        h->I = instance_new(nc, nv, ni, A, nA, B, nB, C, nC);
+        *out = h.release(); return OTTI_OK;
+    });
+}
+void otti_instance_free(otti_instance *p) { delete p; }
+int32_t otti_instance_dims(const otti_instance *inst, uint64_t *nc, uint64_t *nv, uint64_t *ni) {
+    if (!inst) return OTTI_ERR_BAD_ARG;
+    if (nc) *nc = inst->I->num_cons; if (nv) *nv = inst->I->num_vars; if (ni) *ni = inst->I->num_inputs;
+    return OTTI_OK;
+}
+int32_t otti_instance_is_sat(const otti_instance *inst, const uint8_t *vars32, size_t nvars, const uint8_t *inputs32, size_t ninputs, int32_t *sat) {
+    return guarded([&] {
+        if (!inst || !sat) throw Error(OTTI_ERR_BAD_ARG, "null argument");
+        std::vector<Fr> vars, inputs; load_assignment(*inst->I, vars32, nvars, inputs32, ninputs, vars, inputs);
+        *sat = inst->I->is_sat(vars, inputs) ? 1 : 0; return OTTI_OK;
+    });
+}
+
+int32_t otti_gens_new(uint64_t nc, uint64_t nv, uint64_t ni, otti_gens **out) {
+    return guarded([&] {
+        if (!out) throw Error(OTTI_ERR_BAD_ARG, "null out pointer");
+        auto h = std::make_unique<otti_gens>(); h->g = gens_new(nc, nv, ni); *out = h.release(); return OTTI_OK;
+    });
+}
+void otti_gens_free(otti_gens *p) { delete p; }
+int32_t otti_gens_points(const otti_gens *gens, uint8_t *out32, size_t count) {
+    return guarded([&] {
+        if (!gens || count > gens->g->P.size()) throw Error(OTTI_ERR_BAD_ARG, "count exceeds the generator stream");
+        for (size_t i = 0; i < count; i++) pt_encode(out32 + 32 * i, gens->g->P[i]);
+        return OTTI_OK;
+    });
+}
+
+int32_t otti_prepare_device(otti_instance *inst, otti_gens *gens) {
+    return guarded([&] {
+        if (inst && !inst->I->dev) inst->I->dev = upload_instance(*inst->I);
+        if (inst && gens) ensure_device_objects(*inst->I, *gens->g);
+        return OTTI_OK;
+    });
+}
+
+static uint8_t *to_malloc(const std::vector<uint8_t> &v, size_t *len) {
+    uint8_t *p = (uint8_t *)malloc(std::max<size_t>(1, v.size())); memcpy(p, v.data(), v.size()); *len = v.size(); return p;
+}
+
+int32_t otti_nizk_prove(otti_instance *inst, const uint8_t *vars32, size_t nvars, const uint8_t *inputs32, size_t ninputs, otti_gens *gens,
+                        const uint8_t *tlabel, size_t tlabel_len, const uint8_t *seed32, uint32_t flags, uint8_t **proof, size_t *proof_len,
+                        double *stage_ms) {
+    return guarded([&] {
+        if (!inst || !gens || !proof || !proof_len) throw Error(OTTI_ERR_BAD_ARG, "null argument");
+        if (!(flags & OTTI_FLAG_GPU)) throw Error(OTTI_ERR_BAD_ARG, "OTTI_FLAG_GPU is the only proving backend; there is no CPU path");
+        std::vector<Fr> vars, inputs; load_assignment(*inst->I, vars32, nvars, inputs32, ninputs, vars, inputs);
+        ProveTimings tm{};
+        std::vector<uint8_t> pf = nizk_prove_gpu(*inst->I, vars, inputs, *gens->g, tlabel, tlabel_len, seed32, &tm);
+        if (stage_ms) memcpy(stage_ms, tm.ms, sizeof tm.ms);
+        *proof = to_malloc(pf, proof_len); return OTTI_OK;
+    });
+}
+int32_t otti_witness_upload(otti_instance *inst, const uint8_t *vars32, size_t nvars, const uint8_t *inputs32, size_t ninputs, otti_witness **out) {
+    return guarded([&] {
+        if (!inst || !out) throw Error(OTTI_ERR_BAD_ARG, "null argument");
+        std::vector<Fr> vars, inputs; load_assignment(*inst->I, vars32, nvars, inputs32, ninputs, vars, inputs);
+        auto h = std::make_unique<otti_witness>(); h->w = std::make_unique<DeviceWitness>(*inst->I, vars, inputs);
+        *out = h.release(); return OTTI_OK;
+    });
+}
+void otti_witness_free(otti_witness *w) { delete w; }
+int32_t otti_nizk_prove_resident(otti_instance *inst, otti_witness *wit, otti_gens *gens, const uint8_t *tlabel, size_t tlabel_len,
+                                 const uint8_t *seed32, uint8_t **proof, size_t *proof_len, double *stage_ms) {
+    return guarded([&] {
+        if (!inst || !wit || !gens || !proof || !proof_len) throw Error(OTTI_ERR_BAD_ARG, "null argument");
+        ProveTimings tm{};
+        std::vector<uint8_t> pf = nizk_prove_resident(*inst->I, *wit->w, *gens->g, tlabel, tlabel_len, seed32, &tm);
+        if (stage_ms) memcpy(stage_ms, tm.ms, sizeof tm.ms);
+        *proof = to_malloc(pf, proof_len); return OTTI_OK;
+    });
+}
+int32_t otti_nizk_verify(const otti_instance *inst, const uint8_t *inputs32, size_t ninputs, const otti_gens *gens, const uint8_t *tlabel,
+                         size_t tlabel_len, const uint8_t *proof, size_t proof_len) {
+    return guarded([&] {
+        if (!inst || !gens || !proof) throw Error(OTTI_ERR_BAD_ARG, "null argument");
+        std::vector<Fr> inputs = scalars_from_bytes(inputs32, ninputs);
+        int rc = nizk_verify(*inst->I, inputs, *gens->g, tlabel, tlabel_len, proof, proof_len);
+        if (rc) g_last_error = "proof rejected";
+        return rc;
+    });
+}
+
+// ------------------------------------------------------------------------------------------------ zkInterface / synthetic
+int32_t otti_zkif_load(const char *c, const char *i, const char *w, otti_r1cs **out) {
+    return guarded([&] { if (!c || !out) throw Error(OTTI_ERR_BAD_ARG, "null argument"); *out = zkif_load_impl(c, i, w); return OTTI_OK; });
+}
+int32_t otti_zkif_write(const otti_r1cs *r, const char *c, const char *i, const char *w) {
+    return guarded([&] { if (!r || !c || !i || !w) throw Error(OTTI_ERR_BAD_ARG, "null argument"); zkif_write_impl(r, c, i, w); return OTTI_OK; });
+}
+void otti_r1cs_free(otti_r1cs *r) { if (!r) return; free(r->A); free(r->B); free(r->C); free(r->vars32); free(r->inputs32); free(r); }
+int32_t otti_synth_r1cs(uint64_t n, uint64_t ni, uint64_t seed, otti_r1cs **out) {
+    return guarded([&] {
+        if (!out || n == 0) throw Error(OTTI_ERR_BAD_ARG, "bad argument");
+        std::vector<otti_entry> A, B, C; std::vector<uint8_t> vars, inputs;
+        synth_r1cs(n, ni, seed, A, B, C, vars, inputs);
+        *out = otti_r1cs_from(n, n, ni, A, B, C, vars, inputs); return OTTI_OK;
+    });
+}
+
+// ------------------------------------------------------------------------------------------------ kernel-level entry points
+namespace {
+struct Staged {                      // host Montgomery bytes -> device buffer
+    DevBuf<Fr> d;
+    Staged(DevCtx &c, const uint8_t *h, size_t n) : d(std::max<size_t>(1, n)) { if (n) OTTI_HIP(hipMemcpyAsync(d.p, h, n * sizeof(Fr), hipMemcpyHostToDevice, c.stream)); }
+};
+void download(DevCtx &c, uint8_t *h, const Fr *d, size_t n) { if (n) OTTI_HIP(hipMemcpyAsync(h, d, n * sizeof(Fr), hipMemcpyDeviceToHost, c.stream)); }
+struct KTimer {
+    DevCtx &c; float *out;
+    KTimer(DevCtx &c_, float *o) : c(c_), out(o) { if (out) OTTI_HIP(hipEventRecord(c.ev0, c.stream)); }
+    void stop() { if (out) { OTTI_HIP(hipEventRecord(c.ev1, c.stream)); OTTI_HIP(hipEventSynchronize(c.ev1)); OTTI_HIP(hipEventElapsedTime(out, c.ev0, c.ev1)); } }
+};
+Fr fr_load(const uint8_t *p) { Fr x; memcpy(x.v, p, 32); return x; }
+}  // namespace
+
+int32_t otti_k_fr_op(int32_t op, const uint8_t *a, const uint8_t *b, uint8_t *out, size_t n, float *ms) {
+    return guarded([&] {
+        DevCtx &c = DevCtx::get(); Staged A(c, a, n), B(c, b, n); DevBuf<Fr> O(std::max<size_t>(1, n));
+        KTimer t(c, ms); dev_fr_op(c, op, A.d.p, B.d.p, O.p, n); t.stop();
+        download(c, out, O.p, n); c.sync(); return OTTI_OK;
+    });
+}
+int32_t otti_k_fr_from_canonical(const uint8_t *in, uint8_t *out, size_t n) {
+    return guarded([&] { DevCtx &c = DevCtx::get(); Staged A(c, in, n); dev_from_canonical(c, A.d.p, A.d.p, n); download(c, out, A.d.p, n); c.sync(); return OTTI_OK; });
+}
+int32_t otti_k_fr_to_canonical(const uint8_t *in, uint8_t *out, size_t n) {
+    return guarded([&] { DevCtx &c = DevCtx::get(); Staged A(c, in, n); dev_to_canonical(c, A.d.p, A.d.p, n); download(c, out, A.d.p, n); c.sync(); return OTTI_OK; });
+}
+int32_t otti_k_multiply_vec(otti_instance *inst, const uint8_t *z, uint8_t *Az, uint8_t *Bz, uint8_t *Cz, float *ms) {
+    return guarded([&] {
+        DevCtx &c = DevCtx::get(); Instance &I = *inst->I; if (!I.dev) I.dev = upload_instance(I);
+        Staged Z(c, z, 2 * I.num_vars); DevBuf<Fr> a(I.num_cons), b(I.num_cons), d(I.num_cons);
+        KTimer t(c, ms); dev_spmv3(c, I.dev->by_row, Z.d.p, a.p, b.p, d.p, false, nullptr); t.stop();
+        download(c, Az, a.p, I.num_cons); download(c, Bz, b.p, I.num_cons); download(c, Cz, d.p, I.num_cons); c.sync(); return OTTI_OK;
+    });
+}
+int32_t otti_k_eval_table_sparse(otti_instance *inst, const uint8_t *eq_rx, const uint8_t *rABC, uint8_t *out, float *ms) {
+    return guarded([&] {
+        DevCtx &c = DevCtx::get(); Instance &I = *inst->I; if (!I.dev) I.dev = upload_instance(I);
+        Staged E(c, eq_rx, I.num_cons); DevBuf<Fr> o(2 * I.num_vars);
+        Fr coef[3] = {fr_load(rABC), fr_load(rABC + 32), fr_load(rABC + 64)};
+        KTimer t(c, ms); dev_spmv3(c, I.dev->by_col, E.d.p, o.p, nullptr, nullptr, true, coef); t.stop();
+        download(c, out, o.p, 2 * I.num_vars); c.sync(); return OTTI_OK;
+    });
+}
+int32_t otti_k_eq_evals(const uint8_t *r, size_t ell, uint8_t *out, float *ms) {
+    return guarded([&] {
+        if (ell > 24) throw Error(OTTI_ERR_BAD_ARG, "ell > 24");
+        DevCtx &c = DevCtx::get(); std::vector<Fr> rr(ell + 1); for (size_t i = 0; i < ell; i++) rr[i] = fr_load(r + 32 * i);
+        size_t n = (size_t)1 << ell; DevBuf<Fr> o(n), s(3 * 4096);
+        KTimer t(c, ms); dev_eq_evals(c, rr.data(), ell, o.p, s.p); t.stop();
+        download(c, out, o.p, n); c.sync(); return OTTI_OK;
+    });
+}
+int32_t otti_k_fold_top(const uint8_t *Z, size_t len, const uint8_t *r, uint8_t *out, float *ms) {
+    return guarded([&] {
+        DevCtx &c = DevCtx::get(); Staged z(c, Z, len);
+        KTimer t(c, ms); dev_fold_top(c, z.d.p, len, fr_load(r)); t.stop();
+        download(c, out, z.d.p, len / 2); c.sync(); return OTTI_OK;
+    });
+}
+int32_t otti_k_fold_bot(const uint8_t *Z, size_t len, const uint8_t *r, uint8_t *out, float *ms) {
+    return guarded([&] {
+        DevCtx &c = DevCtx::get(); Staged z(c, Z, len); DevBuf<Fr> o(std::max<size_t>(1, len / 2));
+        KTimer t(c, ms); dev_fold_bot(c, z.d.p, o.p, len, fr_load(r)); t.stop();
+        download(c, out, o.p, len / 2); c.sync(); return OTTI_OK;
+    });
+}
+int32_t otti_k_sc_cubic_round(const uint8_t *A, const uint8_t *B, const uint8_t *C, const uint8_t *D, size_t len, uint8_t *e3, float *ms) {
+    return guarded([&] {
+        DevCtx &c = DevCtx::get(); Staged a(c, A, len), b(c, B, len), cc(c, C, len), d(c, D, len);
+        KTimer t(c, ms); dev_sc_cubic_eval(c, a.d.p, b.d.p, cc.d.p, d.d.p, len, 0); t.stop();
+        c.sync(); memcpy(e3, c.h_results, 96); return OTTI_OK;
+    });
+}
+int32_t otti_k_sc_cubic_fold_round(const uint8_t *A, const uint8_t *B, const uint8_t *C, const uint8_t *D, size_t len, const uint8_t *r,
+                                   uint8_t *out4, uint8_t *e3, float *ms) {
+    return guarded([&] {
+        DevCtx &c = DevCtx::get(); Staged a(c, A, len), b(c, B, len), cc(c, C, len), d(c, D, len);
+        KTimer t(c, ms); dev_sc_cubic_fold_eval(c, a.d.p, b.d.p, cc.d.p, d.d.p, len, fr_load(r), 0); t.stop();
+        size_t h = len / 2;
+        download(c, out4, a.d.p, h); download(c, out4 + 32 * h, b.d.p, h); download(c, out4 + 64 * h, cc.d.p, h); download(c, out4 + 96 * h, d.d.p, h);
+        c.sync(); memcpy(e3, c.h_results, 96); return OTTI_OK;
+    });
+}
+int32_t otti_k_sc_quad_round(const uint8_t *A, const uint8_t *B, size_t len, uint8_t *e2, float *ms) {
+    return guarded([&] {
+        DevCtx &c = DevCtx::get(); Staged a(c, A, len), b(c, B, len);
+        KTimer t(c, ms); dev_sc_quad_eval(c, a.d.p, b.d.p, len, 0); t.stop();
+        c.sync(); memcpy(e2, c.h_results, 64); return OTTI_OK;
+    });
+}
+int32_t otti_k_sc_quad_fold_round(const uint8_t *A, const uint8_t *B, size_t len, const uint8_t *r, uint8_t *out2, uint8_t *e2, float *ms) {
+    return guarded([&] {
+        DevCtx &c = DevCtx::get(); Staged a(c, A, len), b(c, B, len);
+        KTimer t(c, ms); dev_sc_quad_fold_eval(c, a.d.p, b.d.p, len, fr_load(r), 0); t.stop();
+        size_t h = len / 2; download(c, out2, a.d.p, h); download(c, out2 + 32 * h, b.d.p, h);
+        c.sync(); memcpy(e2, c.h_results, 64); return OTTI_OK;
+    });
+}
+int32_t otti_k_msm_rows(otti_gens *gens, const uint8_t *Z, size_t L, size_t R, const uint8_t *blinds, uint8_t *out32, float *ms) {
+    return guarded([&] {
+        DevCtx &c = DevCtx::get(); Gens &g = *gens->g;
+        if (R != g.R) throw Error(OTTI_ERR_BAD_ARG, "row length differs from the generator count");
+        if (!g.dev) g.dev = build_device_gens(g, getenv("OTTI_MSM_WINDOW") ? atoi(getenv("OTTI_MSM_WINDOW")) : 8);
+        Staged z(c, Z, L * R), bl(c, blinds, L);
+        uint32_t hb = g.pc_n.h;
+        KTimer t(c, ms); dev_msm_rows(c, *g.dev, z.d.p, R, R, L, bl.d.p, &hb, 1); t.stop();
+        c.sync(); memcpy(out32, c.h_points, 32 * L); return OTTI_OK;
+    });
+}
+
+// ------------------------------------------------------------------------------------------------ u64-lane transport of Fr sums
+void otti_lanes_pack(const uint8_t *fr, size_t n, uint64_t *lanes) {
+    for (size_t i = 0; i < n; i++) for (int k = 0; k < 8; k++) { uint32_t w; memcpy(&w, fr + 32 * i + 4 * k, 4); lanes[8 * i + k] = w; }
+}
+void otti_lanes_unpack(const uint64_t *lanes, size_t n, uint8_t *fr) {
+    // each lane holds a sum of up to 2^32 32-bit limbs: propagate carries into a 320-bit integer, then reduce mod l.
+    // value = sum_k lane_k 2^(32k) < 2^32 * 2^256; write it as lo (256 bits) + hi * 2^256 with hi < 2^32.
+    for (size_t i = 0; i < n; i++) {
+        uint32_t w[9]; unsigned __int128 c = 0;
+        for (int k = 0; k < 8; k++) { c += lanes[8 * i + k]; w[k] = (uint32_t)c; c >>= 32; }
+        w[8] = (uint32_t)c;
+        // lo may be >= l (it is an arbitrary 256-bit number): reduce both parts through Montgomery products with R^2:
+        // x*R^2/R = x*R, then multiply by 1 to drop back: (x*R)*1/R = x mod l.  The inputs were Montgomery values, and the
+        // sum of Montgomery values is the Montgomery value of the sum, so the result stays in Montgomery form.
+        Fr lo, hi = fr_zero(); for (int k = 0; k < 8; k++) lo.v[k] = w[k]; hi.v[0] = w[8];
+        Fr one_raw = fr_zero(); one_raw.v[0] = 1;
+        Fr lo_red = fr_mul(fr_mul(lo, fr_R2()), one_raw);                 // lo mod l
+        Fr hi_red = fr_mul(hi, fr_R2());                                  // hi * R^2 / R = hi * 2^256 mod l
+        Fr s = fr_add(lo_red, hi_red);
+        memcpy(fr + 32 * i, s.v, 32);
+    }
+}
+
+}  // extern "C"

@@ -1,0 +1,103 @@
+// Device layer of the proving path: HBM-resident objects and the kernel launch functions (kernels.hip).
+// Everything runs on one HIP stream owned by DevCtx; results that the Fiat-Shamir transcript needs come back through
+// a small pinned buffer.  No function here falls back to the host: without a gfx950 device they throw Error(OTTI_ERR_NO_DEVICE).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <vector>
+#include "spartan.h"
+
+namespace otti {
+
+#define OTTI_HIP(expr) ::otti::hip_check((expr), #expr, __FILE__, __LINE__)
+void hip_check(hipError_t e, const char *what, const char *file, int line);
+
+template <class T> struct DevBuf {
+    T *p = nullptr; size_t n = 0;
+    DevBuf() {}
+    explicit DevBuf(size_t count) { alloc(count); }
+    DevBuf(const DevBuf &) = delete; DevBuf &operator=(const DevBuf &) = delete;
+    DevBuf(DevBuf &&o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    DevBuf &operator=(DevBuf &&o) noexcept { if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; } return *this; }
+    ~DevBuf() { release(); }
+    void alloc(size_t count) { release(); n = count; if (count) OTTI_HIP(hipMalloc((void **)&p, count * sizeof(T))); }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
+// three CSR matrices side by side (A, B, C), by value into kernels
+struct DCsr3 { const uint32_t *ptr[3]; const uint32_t *idx[3]; const Fr *val[3]; };
+struct DeviceCsrSet {
+    DevBuf<uint32_t> ptr[3], idx[3]; DevBuf<Fr> val[3];
+    DevBuf<uint32_t> heavy;                                   // ids of rows whose longest list exceeds kHeavyRow
+    size_t rows = 0, n_heavy = 0;
+    DCsr3 view() const { DCsr3 v; for (int k = 0; k < 3; k++) { v.ptr[k] = ptr[k].p; v.idx[k] = idx[k].p; v.val[k] = val[k].p; } return v; }
+};
+struct DeviceInstance { DeviceCsrSet by_row, by_col; size_t nnz = 0; };
+
+// fixed-base window table: entry (base b, window w, digit d in 1..E) = d * 2^(c*w) * P[b] in affine Niels form
+struct DeviceGens {
+    DevBuf<Niels> table; int c = 0, W = 0; size_t E = 0, nbases = 0;
+    const Niels *entry0(size_t base) const { return table.p + base * (size_t)W * E; }
+};
+
+struct DevCtx {
+    hipStream_t stream = nullptr;
+    int device = 0, num_cu = 256;
+    DevBuf<Fr> partials;                                      // [kMaxBlocks][4] per-block partial sums
+    DevBuf<Fr> results;                                       // small device result slots
+    Fr *h_results = nullptr;                                  // pinned mirror of `results`
+    DevBuf<Pt> msm_partial;                                   // [rows][splits]
+    uint8_t *h_points = nullptr;                              // pinned: compressed points coming back
+    DevBuf<uint8_t> d_points;
+    size_t msm_partial_cap = 0, points_cap = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    static DevCtx &get();                                     // throws Error(OTTI_ERR_NO_DEVICE) when no device is usable
+    void sync() { OTTI_HIP(hipStreamSynchronize(stream)); }
+    void ensure_points(size_t rows, size_t splits);
+};
+constexpr int kResultSlots = 64;
+
+// witness resident in HBM: z = vars || 1 || inputs || 0..  (2 * num_vars Montgomery-form elements)
+struct DeviceWitness {
+    DevBuf<Fr> z; std::vector<Fr> inputs;
+    DeviceWitness(const Instance &I, const std::vector<Fr> &vars_padded, const std::vector<Fr> &inputs);
+};
+void ensure_device_objects(Instance &I, Gens &g);
+std::vector<uint8_t> nizk_prove_resident(Instance &I, DeviceWitness &wit, Gens &g, const void *tlabel, size_t tlabel_len, const uint8_t *seed32,
+                                         ProveTimings *tm);
+
+std::shared_ptr<DeviceInstance> upload_instance(const Instance &I);
+std::shared_ptr<DeviceGens> build_device_gens(const Gens &g, int window_bits);
+
+// ---- element-wise / conversion
+void dev_fr_op(DevCtx &c, int op, const Fr *a, const Fr *b, Fr *out, size_t n);
+void dev_from_canonical(DevCtx &c, const Fr *in, Fr *out, size_t n);      // raw LE integer -> Montgomery (must be < l)
+void dev_to_canonical(DevCtx &c, const Fr *in, Fr *out, size_t n);
+void dev_fill_zero(DevCtx &c, Fr *p, size_t n);
+// ---- K1 / K6: sparse products.  combine == false: out[k][r] = sum_p val_k[p] * x[idx_k[p]];  true: out[0][r] = sum_k coef[k] * (...)
+void dev_spmv3(DevCtx &c, const DeviceCsrSet &m, const Fr *x, Fr *out0, Fr *out1, Fr *out2, bool combine, const Fr coef[3]);
+// ---- K2: eq tables.  r is a HOST array (challenges come from the transcript)
+void dev_eq_evals(DevCtx &c, const Fr *r_host, size_t ell, Fr *out, Fr *scratch /* >= 2 * 2^min(ell,12) */);
+// ---- K3/K4/K5/K7: sum-check rounds.  Results land in c.h_results[slot .. slot+k) after c.sync()
+void dev_sc_cubic_eval(DevCtx &c, const Fr *A, const Fr *B, const Fr *C, const Fr *D, size_t len, int slot);
+void dev_sc_cubic_fold_eval(DevCtx &c, Fr *A, Fr *B, Fr *C, Fr *D, size_t len, const Fr &r, int slot);   // len >= 4; folds to len/2, sums over the folded tables
+void dev_sc_quad_eval(DevCtx &c, const Fr *A, const Fr *B, size_t len, int slot);
+void dev_sc_quad_fold_eval(DevCtx &c, Fr *A, Fr *B, size_t len, const Fr &r, int slot);
+void dev_fold_top(DevCtx &c, Fr *Z, size_t len, const Fr &r);
+void dev_fold_bot(DevCtx &c, const Fr *Z, Fr *out, size_t len, const Fr &r);
+void dev_fetch(DevCtx &c, const Fr *src, int slot, size_t n);              // async copy of n elements into h_results[slot..]
+// ---- K8: fixed-base MSM rows.  Row i: sum_j dense[i*stride + j] * P[j] (j < n_dense) + sum_e extra_s[i*n_extra+e] * P[extra_base[e]]
+// Compressed results land in c.h_points[32*i ..] after c.sync(); they also stay in c.d_points.
+void dev_msm_rows(DevCtx &c, const DeviceGens &g, const Fr *dense, size_t stride, size_t n_dense, size_t rows, const Fr *extra_s,
+                  const uint32_t *extra_base_host, size_t n_extra);
+// ---- K9: LZ[j] = sum_i Lv[i] * Z[i*R + j]
+void dev_poly_bound(DevCtx &c, const Fr *Z, size_t L, size_t R, const Fr *Lv, Fr *out, Fr *scratch /* >= 64*R */);
+// dot product of two device vectors -> h_results[slot]
+void dev_dot(DevCtx &c, const Fr *a, const Fr *b, size_t n, int slot);
+// ---- K10: bullet reduction bookkeeping on the ORIGINAL generators (see prover.cpp)
+// One launch per round.  If fold_first, a and b (length 2*n_cur) are folded to n_cur with (u, u_inv) and s is updated; then, for
+// n_cur >= 2, the next round's c_L, c_R go to extra_out[0], extra_out[2] and the dense scalar rows sL, sR (length R each) to rows[0..2R).
+void dev_bullet_step(DevCtx &c, Fr *a, Fr *b, Fr *s, size_t R, size_t n_cur, bool fold_first, const Fr &u, const Fr &u_inv, Fr *rows, Fr *extra_out);
+void dev_scale(DevCtx &c, const Fr *in, const Fr &k, Fr *out, size_t n);
+void dev_fill_one(DevCtx &c, Fr *p, size_t n);
+
+}  // namespace otti

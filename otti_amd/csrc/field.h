@@ -1,0 +1,305 @@
+// Field arithmetic for the MI355X Spartan proving path: Fr = GF(l) (curve25519 scalar field, Montgomery form, R = 2^256)
+// and Fp = GF(2^255-19).  One 32-byte little-endian storage format for host and device; on gfx950 the multiplies are
+// 8x u32 limb chains (v_mad_u64_u32), on the host 4x u64 with 128-bit products.
+//
+// Replaces, for this path, upstream libspartan `src/scalar/ristretto255.rs::Scalar` and curve25519-dalek's FieldElement
+// (Cargo dependencies of /root/reference/Spartan, an empty submodule: /root/reference/.gitmodules:4-6).
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define HD __host__ __device__ __forceinline__
+#else
+#define HD inline
+#endif
+
+namespace otti {
+
+struct alignas(16) Fr { uint32_t v[8]; };   // Montgomery form, always < l
+struct alignas(16) Fp { uint32_t v[8]; };   // any representative < 2^256 of the class mod p (loosely reduced)
+
+// ------------------------------------------------------------------------------------------------ constants
+// l = 2^252 + 27742317777372353535851937790883648493
+#define OTTI_L0 0x5cf5d3edu
+#define OTTI_L1 0x5812631au
+#define OTTI_L2 0xa2f79cd6u
+#define OTTI_L3 0x14def9deu
+#define OTTI_L7 0x10000000u
+#define OTTI_LINV32 0x12547e1bu              // -l^{-1} mod 2^32
+
+HD Fr fr_zero() { Fr r; for (int i = 0; i < 8; i++) r.v[i] = 0; return r; }
+HD Fr fr_one() {                              // R mod l
+    Fr r; r.v[0] = 0x8d98951du; r.v[1] = 0xd6ec3174u; r.v[2] = 0x737dcf70u; r.v[3] = 0xc6ef5bf4u;
+    r.v[4] = 0xfffffffeu; r.v[5] = 0xffffffffu; r.v[6] = 0xffffffffu; r.v[7] = 0x0fffffffu; return r;
+}
+HD Fr fr_R2() {                               // R^2 mod l
+    Fr r; r.v[0] = 0x449c0f01u; r.v[1] = 0xa40611e3u; r.v[2] = 0x68859347u; r.v[3] = 0xd00e1ba7u;
+    r.v[4] = 0x17f5be65u; r.v[5] = 0xceec73d2u; r.v[6] = 0x7c309a3du; r.v[7] = 0x0399411bu; return r;
+}
+HD Fr fr_R3() {                               // R^3 mod l
+    Fr r; r.v[0] = 0x7b83a2dbu; r.v[1] = 0x2a9e4968u; r.v[2] = 0xaef7f3ecu; r.v[3] = 0x278324e6u;
+    r.v[4] = 0x04ec5b65u; r.v[5] = 0x8065dc6cu; r.v[6] = 0x3599cec7u; r.v[7] = 0x0e530b77u; return r;
+}
+HD uint32_t fr_L(int i) { return i == 0 ? OTTI_L0 : i == 1 ? OTTI_L1 : i == 2 ? OTTI_L2 : i == 3 ? OTTI_L3 : i == 7 ? OTTI_L7 : 0u; }
+
+// ------------------------------------------------------------------------------------------------ Fr add / sub
+// r = a - l if a >= l (a < 2l), branch-free
+HD Fr fr_cond_sub_l(const uint32_t a[8], uint32_t top) {
+    uint32_t t[8]; uint64_t br = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { uint64_t d = (uint64_t)a[i] - fr_L(i) - br; t[i] = (uint32_t)d; br = (d >> 32) & 1; }
+    bool use_t = top || !br;
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.v[i] = use_t ? t[i] : a[i];
+    return r;
+}
+HD Fr fr_add(const Fr &a, const Fr &b) {
+    uint32_t s[8]; uint64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { c += (uint64_t)a.v[i] + b.v[i]; s[i] = (uint32_t)c; c >>= 32; }
+    return fr_cond_sub_l(s, 0);               // a,b < l < 2^253: no carry out of 256 bits
+}
+HD Fr fr_sub(const Fr &a, const Fr &b) {
+    uint32_t s[8]; uint64_t br = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { uint64_t d = (uint64_t)a.v[i] - b.v[i] - br; s[i] = (uint32_t)d; br = (d >> 32) & 1; }
+    uint32_t m = (uint32_t)0 - (uint32_t)br;  // all ones if borrow
+    Fr r; uint64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { c += (uint64_t)s[i] + (fr_L(i) & m); r.v[i] = (uint32_t)c; c >>= 32; }
+    return r;
+}
+HD Fr fr_neg(const Fr &a) { return fr_sub(fr_zero(), a); }
+HD Fr fr_dbl(const Fr &a) { return fr_add(a, a); }
+HD bool fr_eq(const Fr &a, const Fr &b) { uint32_t d = 0; for (int i = 0; i < 8; i++) d |= a.v[i] ^ b.v[i]; return d == 0; }
+HD bool fr_is_zero(const Fr &a) { uint32_t d = 0; for (int i = 0; i < 8; i++) d |= a.v[i]; return d == 0; }
+
+// ------------------------------------------------------------------------------------------------ Fr Montgomery multiply
+// Device: CIOS over 8 u32 limbs (l has limbs 4..6 == 0 and limb 7 == 2^28, so a reduction row needs 4 real multiplies).
+// Host: the same recurrence over 4 u64 limbs.
+HD Fr fr_mul(const Fr &a, const Fr &b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t t[10];
+#pragma unroll
+    for (int i = 0; i < 10; i++) t[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint64_t c = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) { c += (uint64_t)a.v[j] * b.v[i] + t[j]; t[j] = (uint32_t)c; c >>= 32; }
+        c += t[8]; t[8] = (uint32_t)c; t[9] = (uint32_t)(c >> 32);
+        uint32_t m = t[0] * OTTI_LINV32;
+        c = (uint64_t)m * OTTI_L0 + t[0]; c >>= 32;
+        c += (uint64_t)m * OTTI_L1 + t[1]; t[0] = (uint32_t)c; c >>= 32;
+        c += (uint64_t)m * OTTI_L2 + t[2]; t[1] = (uint32_t)c; c >>= 32;
+        c += (uint64_t)m * OTTI_L3 + t[3]; t[2] = (uint32_t)c; c >>= 32;
+        c += t[4]; t[3] = (uint32_t)c; c >>= 32;
+        c += t[5]; t[4] = (uint32_t)c; c >>= 32;
+        c += t[6]; t[5] = (uint32_t)c; c >>= 32;
+        c += ((uint64_t)m << 28) + t[7]; t[6] = (uint32_t)c; c >>= 32;
+        c += t[8]; t[7] = (uint32_t)c; c >>= 32;
+        t[8] = t[9] + (uint32_t)c;
+    }
+    return fr_cond_sub_l(t, t[8]);
+#else
+    typedef unsigned __int128 u128;
+    static const uint64_t L[4] = {0x5812631a5cf5d3edULL, 0x14def9dea2f79cd6ULL, 0, 0x1000000000000000ULL};
+    const uint64_t INV = 0xd2b51da312547e1bULL;
+    uint64_t x[4], y[4], t[6] = {0, 0, 0, 0, 0, 0};
+    memcpy(x, a.v, 32); memcpy(y, b.v, 32);
+    for (int i = 0; i < 4; i++) {
+        u128 c = 0;
+        for (int j = 0; j < 4; j++) { c += (u128)x[j] * y[i] + t[j]; t[j] = (uint64_t)c; c >>= 64; }
+        c += t[4]; t[4] = (uint64_t)c; t[5] = (uint64_t)(c >> 64);
+        uint64_t m = t[0] * INV;
+        c = (u128)m * L[0] + t[0]; c >>= 64;
+        c += (u128)m * L[1] + t[1]; t[0] = (uint64_t)c; c >>= 64;
+        c += t[2]; t[1] = (uint64_t)c; c >>= 64;
+        c += (u128)m * L[3] + t[3]; t[2] = (uint64_t)c; c >>= 64;
+        c += t[4]; t[3] = (uint64_t)c; c >>= 64;
+        t[4] = t[5] + (uint64_t)c;
+    }
+    uint32_t w[8]; memcpy(w, t, 32);
+    return fr_cond_sub_l(w, (uint32_t)t[4]);
+#endif
+}
+HD Fr fr_sqr(const Fr &a) { return fr_mul(a, a); }
+
+HD Fr fr_from_u64(uint64_t x) { Fr t = fr_zero(); t.v[0] = (uint32_t)x; t.v[1] = (uint32_t)(x >> 32); return fr_mul(t, fr_R2()); }
+// canonical integer (out of Montgomery form)
+HD Fr fr_to_raw(const Fr &a) { Fr one = fr_zero(); one.v[0] = 1; return fr_mul(a, one); }
+HD void fr_to_bytes(uint8_t b[32], const Fr &a) {
+    Fr r = fr_to_raw(a);
+    for (int i = 0; i < 8; i++) { b[4 * i] = (uint8_t)r.v[i]; b[4 * i + 1] = (uint8_t)(r.v[i] >> 8); b[4 * i + 2] = (uint8_t)(r.v[i] >> 16); b[4 * i + 3] = (uint8_t)(r.v[i] >> 24); }
+}
+HD bool fr_raw_is_canonical(const uint32_t w[8]) {
+    for (int i = 7; i >= 0; i--) { uint32_t li = fr_L(i); if (w[i] < li) return true; if (w[i] > li) return false; }
+    return false;
+}
+HD bool fr_from_bytes(Fr &o, const uint8_t b[32]) {       // false if >= l (upstream: InvalidScalar)
+    Fr t;
+    for (int i = 0; i < 8; i++) t.v[i] = (uint32_t)b[4 * i] | ((uint32_t)b[4 * i + 1] << 8) | ((uint32_t)b[4 * i + 2] << 16) | ((uint32_t)b[4 * i + 3] << 24);
+    if (!fr_raw_is_canonical(t.v)) { o = fr_zero(); return false; }
+    o = fr_mul(t, fr_R2());
+    return true;
+}
+HD Fr fr_from_bytes_wide(const uint8_t b[64]) {           // 512-bit LE mod l: lo*R2/R + hi*R3/R
+    Fr lo, hi;
+    for (int i = 0; i < 8; i++) {
+        lo.v[i] = (uint32_t)b[4 * i] | ((uint32_t)b[4 * i + 1] << 8) | ((uint32_t)b[4 * i + 2] << 16) | ((uint32_t)b[4 * i + 3] << 24);
+        hi.v[i] = (uint32_t)b[32 + 4 * i] | ((uint32_t)b[32 + 4 * i + 1] << 8) | ((uint32_t)b[32 + 4 * i + 2] << 16) | ((uint32_t)b[32 + 4 * i + 3] << 24);
+    }
+    return fr_add(fr_mul(lo, fr_R2()), fr_mul(hi, fr_R3()));
+}
+HD Fr fr_inv(const Fr &a) {                               // a^(l-2); 0 -> 0
+    Fr e; e.v[0] = OTTI_L0 - 2; e.v[1] = OTTI_L1; e.v[2] = OTTI_L2; e.v[3] = OTTI_L3; e.v[4] = e.v[5] = e.v[6] = 0; e.v[7] = OTTI_L7;
+    Fr acc = fr_one();
+    for (int i = 252; i >= 0; i--) { acc = fr_sqr(acc); if ((e.v[i >> 5] >> (i & 31)) & 1) acc = fr_mul(acc, a); }
+    return acc;
+}
+
+// ================================================================================================ Fp = GF(2^255 - 19)
+HD Fp fp_zero() { Fp r; for (int i = 0; i < 8; i++) r.v[i] = 0; return r; }
+HD Fp fp_one() { Fp r = fp_zero(); r.v[0] = 1; return r; }
+HD Fp fp_from_words(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t a4, uint32_t a5, uint32_t a6, uint32_t a7) {
+    Fp r; r.v[0] = a0; r.v[1] = a1; r.v[2] = a2; r.v[3] = a3; r.v[4] = a4; r.v[5] = a5; r.v[6] = a6; r.v[7] = a7; return r;
+}
+HD Fp fp_D() { return fp_from_words(0x135978a3u, 0x75eb4dcau, 0x4141d8abu, 0x00700a4du, 0x7779e898u, 0x8cc74079u, 0x2b6ffe73u, 0x52036ceeu); }
+HD Fp fp_2D() { return fp_from_words(0x26b2f159u, 0xebd69b94u, 0x8283b156u, 0x00e0149au, 0xeef3d130u, 0x198e80f2u, 0x56dffce7u, 0x2406d9dcu); }
+HD Fp fp_SQRT_M1() { return fp_from_words(0x4a0ea0b0u, 0xc4ee1b27u, 0xad2fe478u, 0x2f431806u, 0x3dfbd7a7u, 0x2b4d0099u, 0x4fc1df0bu, 0x2b832480u); }
+HD Fp fp_SQRT_AD_MINUS_ONE() { return fp_from_words(0x497b2e1bu, 0x7e97f6a0u, 0x1b7854bdu, 0xaf9d8e0cu, 0x31f5d1fdu, 0x0f3cfcc9u, 0x2b8348acu, 0x376931bfu); }
+HD Fp fp_INVSQRT_A_MINUS_D() { return fp_from_words(0x805d40eau, 0x99c8fdaau, 0x5a4172beu, 0x9d2f1617u, 0xfe01d840u, 0x16c27b91u, 0xcfaffca2u, 0x786c8905u); }
+HD Fp fp_ONE_MINUS_D_SQ() { return fp_from_words(0x945fc176u, 0xe27c09c1u, 0xcd5e350fu, 0x2c81a138u, 0xbe70dfe4u, 0x9994abddu, 0xb2b3e0d7u, 0x029072a8u); }
+HD Fp fp_D_MINUS_ONE_SQ() { return fp_from_words(0x44ed4d20u, 0x31ad5aaau, 0xb01e1999u, 0xd29e4a2cu, 0x529b4eebu, 0x4cdcd32fu, 0xf66c2241u, 0x5968b37au); }
+
+// 2^256 = 38 (mod p): a carry out of 256 bits folds back as +38, a borrow as -38
+HD Fp fp_add(const Fp &a, const Fp &b) {
+    Fp r; uint64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { c += (uint64_t)a.v[i] + b.v[i]; r.v[i] = (uint32_t)c; c >>= 32; }
+    c *= 38;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { c += r.v[i]; r.v[i] = (uint32_t)c; c >>= 32; }
+    r.v[0] += (uint32_t)c * 38;               // second wrap leaves the low limb tiny: cannot carry again
+    return r;
+}
+HD Fp fp_sub(const Fp &a, const Fp &b) {
+    Fp r; uint64_t br = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { uint64_t d = (uint64_t)a.v[i] - b.v[i] - br; r.v[i] = (uint32_t)d; br = (d >> 32) & 1; }
+    uint64_t s = br * 38; br = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { uint64_t d = (uint64_t)r.v[i] - s - br; r.v[i] = (uint32_t)d; br = (d >> 32) & 1; s = 0; }
+    r.v[0] -= (uint32_t)br * 38;              // second wrap: value is now close to 2^256, cannot borrow again
+    return r;
+}
+HD Fp fp_neg(const Fp &a) { return fp_sub(fp_zero(), a); }
+
+HD Fp fp_reduce512(const uint32_t t[16]) {
+    // r = lo + 38*hi, then fold the (<= 38) top word twice
+    Fp r; uint64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { c += (uint64_t)t[8 + i] * 38u + t[i]; r.v[i] = (uint32_t)c; c >>= 32; }
+    c *= 38;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { c += r.v[i]; r.v[i] = (uint32_t)c; c >>= 32; }
+    r.v[0] += (uint32_t)c * 38;
+    return r;
+}
+HD Fp fp_mul(const Fp &a, const Fp &b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t t[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) t[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint64_t c = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) { c += (uint64_t)a.v[j] * b.v[i] + t[i + j]; t[i + j] = (uint32_t)c; c >>= 32; }
+        t[i + 8] = (uint32_t)c;
+    }
+    return fp_reduce512(t);
+#else
+    typedef unsigned __int128 u128;
+    uint64_t x[4], y[4], t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    memcpy(x, a.v, 32); memcpy(y, b.v, 32);
+    for (int i = 0; i < 4; i++) {
+        u128 c = 0;
+        for (int j = 0; j < 4; j++) { c += (u128)x[j] * y[i] + t[i + j]; t[i + j] = (uint64_t)c; c >>= 64; }
+        t[i + 4] = (uint64_t)c;
+    }
+    uint64_t r[4]; u128 c = 0;
+    for (int i = 0; i < 4; i++) { c += (u128)t[4 + i] * 38u + t[i]; r[i] = (uint64_t)c; c >>= 64; }
+    c *= 38;
+    for (int i = 0; i < 4; i++) { c += r[i]; r[i] = (uint64_t)c; c >>= 64; }
+    r[0] += (uint64_t)c * 38;
+    Fp o; memcpy(o.v, r, 32); return o;
+#endif
+}
+HD Fp fp_sqr(const Fp &a) { return fp_mul(a, a); }
+
+HD Fp fp_sqr_n(Fp a, int n) { for (int i = 0; i < n; i++) a = fp_sqr(a); return a; }
+// a^(2^250-1) and a^11 (shared prefix of the inversion and (p-5)/8 chains)
+HD void fp_pow_2_250_1(const Fp &a, Fp &t250, Fp &a11) {
+    Fp z2 = fp_sqr(a), z9 = fp_mul(fp_sqr_n(z2, 2), a), z11 = fp_mul(z9, z2);
+    Fp t5 = fp_mul(fp_sqr(z11), z9);
+    Fp t10 = fp_mul(fp_sqr_n(t5, 5), t5), t20 = fp_mul(fp_sqr_n(t10, 10), t10), t40 = fp_mul(fp_sqr_n(t20, 20), t20);
+    Fp t50 = fp_mul(fp_sqr_n(t40, 10), t10), t100 = fp_mul(fp_sqr_n(t50, 50), t50), t200 = fp_mul(fp_sqr_n(t100, 100), t100);
+    t250 = fp_mul(fp_sqr_n(t200, 50), t50); a11 = z11;
+}
+HD Fp fp_inv(const Fp &a) { Fp t, a11; fp_pow_2_250_1(a, t, a11); return fp_mul(fp_sqr_n(t, 5), a11); }
+HD Fp fp_pow22523(const Fp &a) { Fp t, a11; fp_pow_2_250_1(a, t, a11); return fp_mul(fp_sqr_n(t, 2), a); }
+
+// canonical representative in [0, p)
+HD Fp fp_canon(const Fp &a) {
+    Fp r = a;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {             // fold bit 255 (2^255 = 19) twice
+        uint64_t c = (uint64_t)(r.v[7] >> 31) * 19; r.v[7] &= 0x7fffffffu;
+        for (int i = 0; i < 8; i++) { c += r.v[i]; r.v[i] = (uint32_t)c; c >>= 32; }
+    }
+    // now r < 2^255 + small; subtract p if r >= p:  r + 19 >= 2^255 ?
+    uint32_t t[8]; uint64_t c = 19;
+    for (int i = 0; i < 8; i++) { c += r.v[i]; t[i] = (uint32_t)c; c >>= 32; }
+    bool ge = (t[7] >> 31) != 0;
+    t[7] &= 0x7fffffffu;
+    for (int i = 0; i < 8; i++) r.v[i] = ge ? t[i] : r.v[i];
+    return r;
+}
+HD void fp_to_bytes(uint8_t b[32], const Fp &a) {
+    Fp r = fp_canon(a);
+    for (int i = 0; i < 8; i++) { b[4 * i] = (uint8_t)r.v[i]; b[4 * i + 1] = (uint8_t)(r.v[i] >> 8); b[4 * i + 2] = (uint8_t)(r.v[i] >> 16); b[4 * i + 3] = (uint8_t)(r.v[i] >> 24); }
+}
+HD Fp fp_from_bytes(const uint8_t b[32]) {                 // top bit ignored
+    Fp t;
+    for (int i = 0; i < 8; i++) t.v[i] = (uint32_t)b[4 * i] | ((uint32_t)b[4 * i + 1] << 8) | ((uint32_t)b[4 * i + 2] << 16) | ((uint32_t)b[4 * i + 3] << 24);
+    t.v[7] &= 0x7fffffffu;
+    return t;
+}
+HD bool fp_bytes_canonical(const uint8_t b[32]) {
+    if (b[31] & 0x80) return false;
+    Fp t = fp_from_bytes(b), c = fp_canon(t);
+    uint32_t d = 0; for (int i = 0; i < 8; i++) d |= t.v[i] ^ c.v[i];
+    return d == 0;
+}
+HD bool fp_is_negative(const Fp &a) { return fp_canon(a).v[0] & 1; }
+HD bool fp_is_zero(const Fp &a) { Fp c = fp_canon(a); uint32_t d = 0; for (int i = 0; i < 8; i++) d |= c.v[i]; return d == 0; }
+HD bool fp_eq(const Fp &a, const Fp &b) { return fp_is_zero(fp_sub(a, b)); }
+HD Fp fp_abs(const Fp &a) { return fp_is_negative(a) ? fp_neg(a) : a; }
+
+// RFC 9496 4.2 SQRT_RATIO_M1
+HD bool fp_sqrt_ratio_m1(Fp &r_out, const Fp &u, const Fp &v) {
+    Fp v3 = fp_mul(fp_sqr(v), v), v7 = fp_mul(fp_sqr(v3), v);
+    Fp r = fp_mul(fp_mul(u, v3), fp_pow22523(fp_mul(u, v7)));
+    Fp check = fp_mul(v, fp_sqr(r));
+    Fp neg_u = fp_neg(u), neg_u_i = fp_mul(neg_u, fp_SQRT_M1());
+    bool correct = fp_eq(check, u), flipped = fp_eq(check, neg_u), flipped_i = fp_eq(check, neg_u_i);
+    if (flipped || flipped_i) r = fp_mul(fp_SQRT_M1(), r);
+    r_out = fp_abs(r);
+    return correct || flipped;
+}
+
+}  // namespace otti

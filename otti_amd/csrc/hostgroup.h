@@ -1,0 +1,25 @@
+// Host-side group helpers: variable-base MSM (verifier), fixed-base window tables (the prover's per-round O(1)
+// Pedersen commitments, which sit on the sequential Fiat-Shamir critical path and are latency- not throughput-bound).
+// Replaces upstream libspartan `src/commitments.rs` (MultiCommitGens, Commitments) on the host side [RECALL].
+#pragma once
+#include <vector>
+#include <utility>
+#include "point.h"
+
+namespace otti {
+
+Pt host_scalarmul(const Pt &p, const Fr &s);
+Pt host_msm(const Fr *s, const Pt *P, size_t n);            // sum s[i] * P[i]
+void host_batch_invert(Fp *x, size_t n);                    // in place, no zeros allowed
+
+// signed radix-2^c digits (c <= 16) of a Montgomery-form scalar; nwin = floor(253/c) + 1
+void scalar_digits(const Fr &s, int c, int nwin, int *digits);
+
+constexpr int kHostWinBits = 8, kHostWindows = 32, kHostWinEntries = 128;   // 2^(c-1) entries per window
+struct FixedBaseTable {
+    std::vector<Niels> t;                                   // [w * 128 + (|d| - 1)] = |d| * 2^(8w) * B
+    void build(const Pt &base);
+    void accumulate(Pt &acc, const Fr &s) const;            // acc += s * B  (32 mixed additions)
+};
+
+}  // namespace otti

@@ -1,0 +1,487 @@
+// gfx950 (MI355X, CDNA4) kernels of the Spartan NIZK proving path.  Wave64; 256 CUs in 8 XCDs; every kernel here is integer
+// work on 256-bit field elements (8 x u32 limbs, v_mad_u64_u32 chains) — no MFMA applies.  Streaming kernels (K1-K7, K9)
+// move 32-byte elements with two 16-byte accesses per lane and are HBM-bound; the fixed-base MSM (K8) is integer-ALU-bound.
+//
+// Kernel <-> upstream hot loop [RECALL: the reference's Spartan/ submodule is empty]:
+//   k_spmv3_*            K1 sparse_mlpoly.rs SparseMatPolynomial::multiply_vec, K6 compute_eval_table_sparse (transposed copy)
+//   k_eq_small/_expand   K2 dense_mlpoly.rs EqPolynomial::evals
+//   k_sc_*               K3/K7 sumcheck.rs prove_cubic_with_additive_term / prove_quad inner loops, fused with
+//                        K4 dense_mlpoly.rs DensePolynomial::bound_poly_var_top of the previous round
+//   k_fold_top/_bot      K4/K5 bound_poly_var_top / bound_poly_var_bot
+//   k_msm_rows/_finish   K8 DensePolynomial::commit_inner -> Commitments::commit (dalek vartime_multiscalar_mul), also K10's L/R
+//   k_poly_bound_*       K9 DensePolynomial::bound
+//   k_bullet_step        K10 nizk/bullet.rs BulletReductionProof::prove scalar bookkeeping
+#include "device.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <algorithm>
+#include <mutex>
+
+namespace otti {
+
+void hip_check(hipError_t e, const char *what, const char *file, int line) {
+    if (e == hipSuccess) return;
+    char buf[512]; snprintf(buf, sizeof buf, "HIP error %d (%s) at %s:%d: %s", (int)e, hipGetErrorString(e), file, line, what);
+    throw Error(OTTI_ERR_NO_DEVICE, buf);
+}
+
+constexpr int kBlock = 256;
+constexpr int kMaxBlocks = 2048;           // 8 workgroups per CU; grid-stride beyond that
+constexpr int kHeavyRow = 64;              // sparse rows longer than this go to the one-workgroup-per-row kernel
+
+static inline int grid_for(size_t n) { size_t b = (n + kBlock - 1) / kBlock; return (int)std::max<size_t>(1, std::min<size_t>(b, kMaxBlocks)); }
+
+// ------------------------------------------------------------------------------------------------ context
+DevCtx &DevCtx::get() {
+    static std::mutex mu; static DevCtx *ctx = nullptr; static bool failed = false; static std::string why;
+    std::lock_guard<std::mutex> lk(mu);
+    if (ctx) return *ctx;
+    if (failed) throw Error(OTTI_ERR_NO_DEVICE, why);
+    try {
+        int count = 0;
+        hipError_t e = hipGetDeviceCount(&count);
+        if (e != hipSuccess || count == 0) throw Error(OTTI_ERR_NO_DEVICE, "no HIP device visible: the MI355X proving path has no CPU fallback");
+        int dev = 0;
+        const char *env = getenv("OTTI_DEVICE"); if (!env) env = getenv("LOCAL_RANK");
+        if (env) dev = atoi(env) % count;
+        OTTI_HIP(hipSetDevice(dev));
+        hipDeviceProp_t prop; OTTI_HIP(hipGetDeviceProperties(&prop, dev));
+        if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+            char buf[256]; snprintf(buf, sizeof buf, "device %d is %s; this library carries gfx950 code objects only", dev, prop.gcnArchName);
+            throw Error(OTTI_ERR_NO_DEVICE, buf);
+        }
+        DevCtx *c = new DevCtx();
+        c->device = dev; c->num_cu = prop.multiProcessorCount;
+        OTTI_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->partials.alloc((size_t)kMaxBlocks * 4);
+        c->results.alloc(kResultSlots);
+        OTTI_HIP(hipHostMalloc((void **)&c->h_results, kResultSlots * sizeof(Fr), hipHostMallocDefault));
+        OTTI_HIP(hipEventCreate(&c->ev0)); OTTI_HIP(hipEventCreate(&c->ev1));
+        ctx = c;
+        return *ctx;
+    } catch (const Error &e) { failed = true; why = e.what(); throw; }
+}
+
+void DevCtx::ensure_points(size_t rows, size_t splits) {
+    if (rows * splits > msm_partial_cap) { msm_partial.alloc(rows * splits); msm_partial_cap = rows * splits; }
+    if (rows > points_cap) {
+        if (h_points) (void)hipHostFree(h_points);
+        OTTI_HIP(hipHostMalloc((void **)&h_points, rows * 32, hipHostMallocDefault));
+        d_points.alloc(rows * 32); points_cap = rows;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ wave / block reductions of Fr
+__device__ __forceinline__ Fr shfl_xor_fr(const Fr &x, int mask) {
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.v[i] = (uint32_t)__shfl_xor((int)x.v[i], mask, 64);
+    return r;
+}
+// sums acc[0..K) over the workgroup (blockDim.x a multiple of 64, <= 1024); thread 0 ends up with the totals
+template <int K> __device__ __forceinline__ void block_reduce(Fr (&acc)[K]) {
+    __shared__ Fr sm[K][16];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1)
+#pragma unroll
+        for (int k = 0; k < K; k++) acc[k] = fr_add(acc[k], shfl_xor_fr(acc[k], off));
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();                         // protects sm against a previous use
+    if (lane == 0) for (int k = 0; k < K; k++) sm[k][wave] = acc[k];
+    __syncthreads();
+    if (threadIdx.x == 0)
+        for (int k = 0; k < K; k++) { Fr t = sm[k][0]; for (int w = 1; w < nw; w++) t = fr_add(t, sm[k][w]); acc[k] = t; }
+}
+template <int K> __global__ __launch_bounds__(kBlock) void k_reduce_partials(const Fr *partials, int nblocks, Fr *out) {
+    Fr acc[K];
+    for (int k = 0; k < K; k++) acc[k] = fr_zero();
+    for (int b = threadIdx.x; b < nblocks; b += blockDim.x)
+        for (int k = 0; k < K; k++) acc[k] = fr_add(acc[k], partials[(size_t)b * K + k]);
+    block_reduce<K>(acc);
+    if (threadIdx.x == 0) for (int k = 0; k < K; k++) out[k] = acc[k];
+}
+
+// ------------------------------------------------------------------------------------------------ element-wise
+__global__ void k_fr_op(int op, const Fr *a, const Fr *b, Fr *out, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        Fr x = a[i], y = b[i];
+        out[i] = op == 0 ? fr_mul(x, y) : op == 1 ? fr_add(x, y) : fr_sub(x, y);
+    }
+}
+__global__ void k_fr_scale(const Fr *in, Fr k, Fr *out, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = fr_mul(in[i], k);
+}
+__global__ void k_fr_fill(Fr *p, Fr v, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+void dev_fr_op(DevCtx &c, int op, const Fr *a, const Fr *b, Fr *out, size_t n) { if (n) hipLaunchKernelGGL(k_fr_op, grid_for(n), kBlock, 0, c.stream, op, a, b, out, n); }
+void dev_scale(DevCtx &c, const Fr *in, const Fr &k, Fr *out, size_t n) { if (n) hipLaunchKernelGGL(k_fr_scale, grid_for(n), kBlock, 0, c.stream, in, k, out, n); }
+void dev_from_canonical(DevCtx &c, const Fr *in, Fr *out, size_t n) { dev_scale(c, in, fr_R2(), out, n); }
+void dev_to_canonical(DevCtx &c, const Fr *in, Fr *out, size_t n) { Fr one = fr_zero(); one.v[0] = 1; dev_scale(c, in, one, out, n); }
+void dev_fill_zero(DevCtx &c, Fr *p, size_t n) { if (n) OTTI_HIP(hipMemsetAsync(p, 0, n * sizeof(Fr), c.stream)); }
+void dev_fill_one(DevCtx &c, Fr *p, size_t n) { if (n) hipLaunchKernelGGL(k_fr_fill, grid_for(n), kBlock, 0, c.stream, p, fr_one(), n); }
+void dev_fetch(DevCtx &c, const Fr *src, int slot, size_t n) { OTTI_HIP(hipMemcpyAsync(c.h_results + slot, src, n * sizeof(Fr), hipMemcpyDeviceToHost, c.stream)); }
+
+// ------------------------------------------------------------------------------------------------ K1 / K6 sparse products
+__device__ __forceinline__ Fr row_dot(const uint32_t *ptr, const uint32_t *idx, const Fr *val, const Fr *x, size_t r) {
+    Fr acc = fr_zero();
+    uint32_t p0 = ptr[r], p1 = ptr[r + 1];
+    for (uint32_t p = p0; p < p1; p++) acc = fr_add(acc, fr_mul(val[p], x[idx[p]]));
+    return acc;
+}
+__global__ __launch_bounds__(kBlock) void k_spmv3_light(DCsr3 m, size_t rows, const Fr *x, Fr *o0, Fr *o1, Fr *o2, int combine, Fr c0, Fr c1, Fr c2) {
+    for (size_t r = blockIdx.x * (size_t)blockDim.x + threadIdx.x; r < rows; r += (size_t)gridDim.x * blockDim.x) {
+        uint32_t l0 = m.ptr[0][r + 1] - m.ptr[0][r], l1 = m.ptr[1][r + 1] - m.ptr[1][r], l2 = m.ptr[2][r + 1] - m.ptr[2][r];
+        if (max(l0, max(l1, l2)) > (uint32_t)kHeavyRow) continue;
+        Fr a0 = row_dot(m.ptr[0], m.idx[0], m.val[0], x, r);
+        Fr a1 = row_dot(m.ptr[1], m.idx[1], m.val[1], x, r);
+        Fr a2 = row_dot(m.ptr[2], m.idx[2], m.val[2], x, r);
+        if (combine) o0[r] = fr_add(fr_add(fr_mul(c0, a0), fr_mul(c1, a1)), fr_mul(c2, a2));
+        else { o0[r] = a0; o1[r] = a1; o2[r] = a2; }
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_spmv3_heavy(DCsr3 m, const uint32_t *heavy, const Fr *x, Fr *o0, Fr *o1, Fr *o2, int combine, Fr c0, Fr c1, Fr c2) {
+    size_t r = heavy[blockIdx.x];
+    Fr acc[3];
+    for (int k = 0; k < 3; k++) {
+        acc[k] = fr_zero();
+        uint32_t p0 = m.ptr[k][r], p1 = m.ptr[k][r + 1];
+        for (uint32_t p = p0 + threadIdx.x; p < p1; p += blockDim.x) acc[k] = fr_add(acc[k], fr_mul(m.val[k][p], x[m.idx[k][p]]));
+    }
+    block_reduce<3>(acc);
+    if (threadIdx.x == 0) {
+        if (combine) o0[r] = fr_add(fr_add(fr_mul(c0, acc[0]), fr_mul(c1, acc[1])), fr_mul(c2, acc[2]));
+        else { o0[r] = acc[0]; o1[r] = acc[1]; o2[r] = acc[2]; }
+    }
+}
+void dev_spmv3(DevCtx &c, const DeviceCsrSet &m, const Fr *x, Fr *o0, Fr *o1, Fr *o2, bool combine, const Fr coef[3]) {
+    Fr z = fr_zero();
+    Fr c0 = coef ? coef[0] : z, c1 = coef ? coef[1] : z, c2 = coef ? coef[2] : z;
+    hipLaunchKernelGGL(k_spmv3_light, grid_for(m.rows), kBlock, 0, c.stream, m.view(), m.rows, x, o0, o1, o2, (int)combine, c0, c1, c2);
+    if (m.n_heavy) hipLaunchKernelGGL(k_spmv3_heavy, (int)m.n_heavy, kBlock, 0, c.stream, m.view(), m.heavy.p, x, o0, o1, o2, (int)combine, c0, c1, c2);
+}
+
+static void upload_csr_set(DeviceCsrSet &d, const SparseMat M[3], bool by_col) {
+    size_t rows = by_col ? M[0].by_col.rows : M[0].by_row.rows;
+    d.rows = rows;
+    std::vector<uint32_t> heavy;
+    for (int k = 0; k < 3; k++) {
+        const Csr &s = by_col ? M[k].by_col : M[k].by_row;
+        d.ptr[k].alloc(s.ptr.size()); d.idx[k].alloc(std::max<size_t>(1, s.idx.size())); d.val[k].alloc(std::max<size_t>(1, s.val.size()));
+        OTTI_HIP(hipMemcpy(d.ptr[k].p, s.ptr.data(), s.ptr.size() * 4, hipMemcpyHostToDevice));
+        if (!s.idx.empty()) {
+            OTTI_HIP(hipMemcpy(d.idx[k].p, s.idx.data(), s.idx.size() * 4, hipMemcpyHostToDevice));
+            OTTI_HIP(hipMemcpy(d.val[k].p, s.val.data(), s.val.size() * sizeof(Fr), hipMemcpyHostToDevice));
+        }
+    }
+    for (size_t r = 0; r < rows; r++) {
+        uint32_t mx = 0;
+        for (int k = 0; k < 3; k++) { const Csr &s = by_col ? M[k].by_col : M[k].by_row; mx = std::max(mx, s.ptr[r + 1] - s.ptr[r]); }
+        if (mx > (uint32_t)kHeavyRow) heavy.push_back((uint32_t)r);
+    }
+    d.n_heavy = heavy.size();
+    if (!heavy.empty()) { d.heavy.alloc(heavy.size()); OTTI_HIP(hipMemcpy(d.heavy.p, heavy.data(), heavy.size() * 4, hipMemcpyHostToDevice)); }
+}
+std::shared_ptr<DeviceInstance> upload_instance(const Instance &I) {
+    DevCtx::get();
+    auto d = std::make_shared<DeviceInstance>();
+    upload_csr_set(d->by_row, I.M, false); upload_csr_set(d->by_col, I.M, true);
+    d->nnz = I.M[0].val.size() + I.M[1].val.size() + I.M[2].val.size();
+    return d;
+}
+
+// ------------------------------------------------------------------------------------------------ K2 eq tables
+struct FrArgs { Fr v[13]; };
+// one workgroup builds eq(r, .) for ell <= 12 by doubling, ping-ponging between two global buffers
+__global__ __launch_bounds__(1024) void k_eq_small(FrArgs r, int ell, Fr *out, Fr *tmp) {
+    Fr *cur = (ell & 1) ? tmp : out, *nxt = (ell & 1) ? out : tmp;   // after ell swaps the result sits in `out`
+    if (threadIdx.x == 0) cur[0] = fr_one();
+    __syncthreads();
+    size_t size = 1;
+    for (int j = 0; j < ell; j++) {
+        Fr rj = r.v[j];
+        for (size_t k = threadIdx.x; k < size; k += blockDim.x) { Fr v = cur[k], hi = fr_mul(v, rj); nxt[2 * k + 1] = hi; nxt[2 * k] = fr_sub(v, hi); }
+        __syncthreads();
+        Fr *t = cur; cur = nxt; nxt = t; size *= 2;
+    }
+}
+// out[i] = hi[i >> lo_bits] * lo[i & (2^lo_bits - 1)]  (index bits are MSB-first over r, so the product of two sub-tables is the table)
+__global__ __launch_bounds__(kBlock) void k_eq_expand(const Fr *hi, const Fr *lo, int lo_bits, Fr *out, size_t n) {
+    size_t mask = ((size_t)1 << lo_bits) - 1;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = fr_mul(hi[i >> lo_bits], lo[i & mask]);
+}
+void dev_eq_evals(DevCtx &c, const Fr *r, size_t ell, Fr *out, Fr *scratch) {
+    auto small = [&](const Fr *rr, int e, Fr *dst, Fr *tmp) {
+        FrArgs a; for (int i = 0; i < 13; i++) a.v[i] = i < e ? rr[i] : fr_zero();
+        hipLaunchKernelGGL(k_eq_small, 1, 1024, 0, c.stream, a, e, dst, tmp);
+    };
+    if (ell <= 12) { small(r, (int)ell, out, scratch); return; }
+    int lo_bits = 12, hi_bits = (int)ell - 12;
+    if (hi_bits > 12) throw Error(OTTI_ERR_BAD_ARG, "eq table larger than 2^24");
+    Fr *lo = scratch, *hi = scratch + 4096, *tmp = scratch + 8192;       // scratch >= 3 * 4096
+    small(r + hi_bits, lo_bits, lo, tmp);
+    small(r, hi_bits, hi, tmp);                                          // same stream: ordered after the first use of tmp
+    size_t n = (size_t)1 << ell;
+    hipLaunchKernelGGL(k_eq_expand, grid_for(n), kBlock, 0, c.stream, hi, lo, lo_bits, out, n);
+}
+
+// ------------------------------------------------------------------------------------------------ K3/K4/K7 sum-check rounds
+struct Pair { Fr lo, hi; };
+__device__ __forceinline__ void cubic_accum(Fr (&acc)[3], const Pair &a, const Pair &b, const Pair &c, const Pair &d) {
+    // comb = A * (B * C - D) at t = 0, 2, 3 with X(2) = 2 X[hi] - X[lo], X(3) = X(2) + X[hi] - X[lo]
+    acc[0] = fr_add(acc[0], fr_mul(a.lo, fr_sub(fr_mul(b.lo, c.lo), d.lo)));
+    Fr da = fr_sub(a.hi, a.lo), db = fr_sub(b.hi, b.lo), dc = fr_sub(c.hi, c.lo), dd = fr_sub(d.hi, d.lo);
+    Fr a2 = fr_add(a.hi, da), b2 = fr_add(b.hi, db), c2 = fr_add(c.hi, dc), d2 = fr_add(d.hi, dd);
+    acc[1] = fr_add(acc[1], fr_mul(a2, fr_sub(fr_mul(b2, c2), d2)));
+    Fr a3 = fr_add(a2, da), b3 = fr_add(b2, db), c3 = fr_add(c2, dc), d3 = fr_add(d2, dd);
+    acc[2] = fr_add(acc[2], fr_mul(a3, fr_sub(fr_mul(b3, c3), d3)));
+}
+__device__ __forceinline__ void quad_accum(Fr (&acc)[2], const Pair &a, const Pair &b) {
+    acc[0] = fr_add(acc[0], fr_mul(a.lo, b.lo));
+    Fr a2 = fr_sub(fr_add(a.hi, a.hi), a.lo), b2 = fr_sub(fr_add(b.hi, b.hi), b.lo);
+    acc[1] = fr_add(acc[1], fr_mul(a2, b2));
+}
+__device__ __forceinline__ Pair load_pair(const Fr *T, size_t i, size_t half) { Pair p; p.lo = T[i]; p.hi = T[i + half]; return p; }
+// fold the table of length 4q by r (bound_poly_var_top) for the two entries that form pair i of the folded table
+__device__ __forceinline__ Pair fold_pair(Fr *T, size_t i, size_t q, const Fr &r) {
+    Fr a = T[i], b = T[i + q], c = T[i + 2 * q], d = T[i + 3 * q];
+    Pair p; p.lo = fr_add(a, fr_mul(r, fr_sub(c, a))); p.hi = fr_add(b, fr_mul(r, fr_sub(d, b)));
+    T[i] = p.lo; T[i + q] = p.hi;
+    return p;
+}
+template <int K> __device__ __forceinline__ void store_partials(Fr (&acc)[K], Fr *partials) {
+    block_reduce<K>(acc);
+    if (threadIdx.x == 0) for (int k = 0; k < K; k++) partials[(size_t)blockIdx.x * K + k] = acc[k];
+}
+__global__ __launch_bounds__(kBlock) void k_sc_cubic_eval(const Fr *A, const Fr *B, const Fr *C, const Fr *D, size_t half, Fr *partials) {
+    Fr acc[3] = {fr_zero(), fr_zero(), fr_zero()};
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x)
+        cubic_accum(acc, load_pair(A, i, half), load_pair(B, i, half), load_pair(C, i, half), load_pair(D, i, half));
+    store_partials<3>(acc, partials);
+}
+__global__ __launch_bounds__(kBlock) void k_sc_cubic_fold_eval(Fr *A, Fr *B, Fr *C, Fr *D, size_t q, Fr r, Fr *partials) {
+    Fr acc[3] = {fr_zero(), fr_zero(), fr_zero()};
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < q; i += (size_t)gridDim.x * blockDim.x) {
+        Pair a = fold_pair(A, i, q, r), b = fold_pair(B, i, q, r), c = fold_pair(C, i, q, r), d = fold_pair(D, i, q, r);
+        cubic_accum(acc, a, b, c, d);
+    }
+    store_partials<3>(acc, partials);
+}
+__global__ __launch_bounds__(kBlock) void k_sc_quad_eval(const Fr *A, const Fr *B, size_t half, Fr *partials) {
+    Fr acc[2] = {fr_zero(), fr_zero()};
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x)
+        quad_accum(acc, load_pair(A, i, half), load_pair(B, i, half));
+    store_partials<2>(acc, partials);
+}
+__global__ __launch_bounds__(kBlock) void k_sc_quad_fold_eval(Fr *A, Fr *B, size_t q, Fr r, Fr *partials) {
+    Fr acc[2] = {fr_zero(), fr_zero()};
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < q; i += (size_t)gridDim.x * blockDim.x) {
+        Pair a = fold_pair(A, i, q, r), b = fold_pair(B, i, q, r);
+        quad_accum(acc, a, b);
+    }
+    store_partials<2>(acc, partials);
+}
+__global__ __launch_bounds__(kBlock) void k_fold_top(Fr *Z, size_t half, Fr r) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x) {
+        Fr a = Z[i], b = Z[i + half]; Z[i] = fr_add(a, fr_mul(r, fr_sub(b, a)));
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_fold_bot(const Fr *Z, Fr *out, size_t half, Fr r) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x) {
+        Fr a = Z[2 * i], b = Z[2 * i + 1]; out[i] = fr_add(a, fr_mul(r, fr_sub(b, a)));
+    }
+}
+template <int K> static void finish_round(DevCtx &c, int nblocks, int slot) {
+    hipLaunchKernelGGL(k_reduce_partials<K>, 1, kBlock, 0, c.stream, (const Fr *)c.partials.p, nblocks, c.results.p + slot);
+    dev_fetch(c, c.results.p + slot, slot, K);
+}
+void dev_sc_cubic_eval(DevCtx &c, const Fr *A, const Fr *B, const Fr *C, const Fr *D, size_t len, int slot) {
+    size_t half = len / 2; int g = grid_for(half);
+    hipLaunchKernelGGL(k_sc_cubic_eval, g, kBlock, 0, c.stream, A, B, C, D, half, c.partials.p);
+    finish_round<3>(c, g, slot);
+}
+void dev_sc_cubic_fold_eval(DevCtx &c, Fr *A, Fr *B, Fr *C, Fr *D, size_t len, const Fr &r, int slot) {
+    if (len < 4) throw Error(OTTI_ERR_INTERNAL, "fold_eval needs len >= 4");
+    size_t q = len / 4; int g = grid_for(q);
+    hipLaunchKernelGGL(k_sc_cubic_fold_eval, g, kBlock, 0, c.stream, A, B, C, D, q, r, c.partials.p);
+    finish_round<3>(c, g, slot);
+}
+void dev_sc_quad_eval(DevCtx &c, const Fr *A, const Fr *B, size_t len, int slot) {
+    size_t half = len / 2; int g = grid_for(half);
+    hipLaunchKernelGGL(k_sc_quad_eval, g, kBlock, 0, c.stream, A, B, half, c.partials.p);
+    finish_round<2>(c, g, slot);
+}
+void dev_sc_quad_fold_eval(DevCtx &c, Fr *A, Fr *B, size_t len, const Fr &r, int slot) {
+    if (len < 4) throw Error(OTTI_ERR_INTERNAL, "fold_eval needs len >= 4");
+    size_t q = len / 4; int g = grid_for(q);
+    hipLaunchKernelGGL(k_sc_quad_fold_eval, g, kBlock, 0, c.stream, A, B, q, r, c.partials.p);
+    finish_round<2>(c, g, slot);
+}
+void dev_fold_top(DevCtx &c, Fr *Z, size_t len, const Fr &r) { size_t h = len / 2; if (h) hipLaunchKernelGGL(k_fold_top, grid_for(h), kBlock, 0, c.stream, Z, h, r); }
+void dev_fold_bot(DevCtx &c, const Fr *Z, Fr *out, size_t len, const Fr &r) { size_t h = len / 2; if (h) hipLaunchKernelGGL(k_fold_bot, grid_for(h), kBlock, 0, c.stream, Z, out, h, r); }
+
+__global__ __launch_bounds__(kBlock) void k_dot(const Fr *a, const Fr *b, size_t n, Fr *partials) {
+    Fr acc[1] = {fr_zero()};
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) acc[0] = fr_add(acc[0], fr_mul(a[i], b[i]));
+    store_partials<1>(acc, partials);
+}
+void dev_dot(DevCtx &c, const Fr *a, const Fr *b, size_t n, int slot) {
+    int g = grid_for(n);
+    hipLaunchKernelGGL(k_dot, g, kBlock, 0, c.stream, a, b, n, c.partials.p);
+    finish_round<1>(c, g, slot);
+}
+
+// ------------------------------------------------------------------------------------------------ K9 DensePolynomial::bound
+__global__ __launch_bounds__(kBlock) void k_poly_bound_slab(const Fr *Z, size_t L, size_t R, const Fr *Lv, size_t rows_per_slab, Fr *scratch) {
+    size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (j >= R) return;
+    size_t i0 = blockIdx.y * rows_per_slab, i1 = min(L, i0 + rows_per_slab);
+    Fr acc = fr_zero();
+    for (size_t i = i0; i < i1; i++) acc = fr_add(acc, fr_mul(Lv[i], Z[i * R + j]));
+    scratch[(size_t)blockIdx.y * R + j] = acc;
+}
+__global__ __launch_bounds__(kBlock) void k_colsum(const Fr *scratch, size_t slabs, size_t R, Fr *out) {
+    size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (j >= R) return;
+    Fr acc = scratch[j];
+    for (size_t s = 1; s < slabs; s++) acc = fr_add(acc, scratch[s * R + j]);
+    out[j] = acc;
+}
+void dev_poly_bound(DevCtx &c, const Fr *Z, size_t L, size_t R, const Fr *Lv, Fr *out, Fr *scratch) {
+    size_t slabs = std::min<size_t>(L, 64), rps = (L + slabs - 1) / slabs;
+    dim3 grid((unsigned)((R + kBlock - 1) / kBlock), (unsigned)slabs);
+    hipLaunchKernelGGL(k_poly_bound_slab, grid, kBlock, 0, c.stream, Z, L, R, Lv, rps, scratch);
+    hipLaunchKernelGGL(k_colsum, (unsigned)((R + kBlock - 1) / kBlock), kBlock, 0, c.stream, (const Fr *)scratch, slabs, R, out);
+}
+
+// ------------------------------------------------------------------------------------------------ K8 fixed-base MSM
+// acc += s * P[base] using the window table slice `tbl` (W windows x E entries) of that base
+__device__ __forceinline__ void msm_accumulate(Pt &acc, const Niels *tbl, const Fr &s, int c, int W, size_t E) {
+    if (fr_is_zero(s)) return;
+    Fr raw = fr_to_raw(s);
+    int carry = 0, half = 1 << (c - 1);
+    for (int w = 0; w < W; w++) {
+        int d = scalar_window(raw.v, w * c, c) + carry;
+        carry = 0;
+        if (d > half) { d -= (1 << c); carry = 1; }
+        if (d > 0) { Niels e = tbl[(size_t)w * E + (d - 1)]; acc = pt_madd(acc, e); }
+        else if (d < 0) { Niels e = tbl[(size_t)w * E + (-d - 1)]; acc = pt_msub(acc, e); }
+    }
+}
+struct ExtraBases { uint32_t b[8]; };
+__global__ __launch_bounds__(kBlock) void k_msm_rows(const Niels *table, int c, int W, size_t E, const Fr *dense, size_t stride, size_t n_dense,
+                                                     const Fr *extra_s, ExtraBases eb, int n_extra, int splits, Pt *partial) {
+    __shared__ Pt sm[kBlock];
+    size_t row = blockIdx.y; int split = blockIdx.x;
+    size_t chunk = (n_dense + splits - 1) / splits, j0 = split * chunk, j1 = min(n_dense, j0 + chunk);
+    size_t WE = (size_t)W * E;
+    Pt acc = pt_identity();
+    for (size_t j = j0 + threadIdx.x; j < j1; j += blockDim.x) msm_accumulate(acc, table + j * WE, dense[row * stride + j], c, W, E);
+    if (split == 0 && (int)threadIdx.x < n_extra) msm_accumulate(acc, table + (size_t)eb.b[threadIdx.x] * WE, extra_s[row * n_extra + threadIdx.x], c, W, E);
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = kBlock / 2; s >= 1; s >>= 1) {
+        if ((int)threadIdx.x < s) { acc = pt_add(acc, sm[threadIdx.x + s]); sm[threadIdx.x] = acc; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[row * splits + split] = acc;
+}
+__global__ __launch_bounds__(64) void k_msm_finish(const Pt *partial, int splits, size_t rows, uint8_t *out32) {
+    size_t row = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (row >= rows) return;
+    Pt acc = partial[row * splits];
+    for (int s = 1; s < splits; s++) acc = pt_add(acc, partial[row * splits + s]);
+    uint8_t enc[32]; pt_encode(enc, acc);
+    uint32_t *o = (uint32_t *)(out32 + 32 * row);
+    for (int i = 0; i < 8; i++) o[i] = (uint32_t)enc[4 * i] | ((uint32_t)enc[4 * i + 1] << 8) | ((uint32_t)enc[4 * i + 2] << 16) | ((uint32_t)enc[4 * i + 3] << 24);
+}
+void dev_msm_rows(DevCtx &c, const DeviceGens &g, const Fr *dense, size_t stride, size_t n_dense, size_t rows, const Fr *extra_s,
+                  const uint32_t *extra_base, size_t n_extra) {
+    if (n_extra > 8) throw Error(OTTI_ERR_INTERNAL, "msm: too many extra terms");
+    if (!rows) return;
+    // enough workgroups to fill 256 CUs a few times over, but never slices shorter than one term per thread
+    size_t splits = 1;
+    while (rows * splits < 1024 && n_dense / (splits * 2) >= (size_t)kBlock) splits *= 2;
+    c.ensure_points(rows, splits);
+    ExtraBases eb; for (int i = 0; i < 8; i++) eb.b[i] = i < (int)n_extra ? extra_base[i] : 0;
+    dim3 grid((unsigned)splits, (unsigned)rows);
+    hipLaunchKernelGGL(k_msm_rows, grid, kBlock, 0, c.stream, (const Niels *)g.table.p, g.c, g.W, g.E, dense, stride, n_dense, extra_s, eb, (int)n_extra,
+                       (int)splits, c.msm_partial.p);
+    hipLaunchKernelGGL(k_msm_finish, (unsigned)((rows + 63) / 64), 64, 0, c.stream, (const Pt *)c.msm_partial.p, (int)splits, rows, c.d_points.p);
+    OTTI_HIP(hipMemcpyAsync(c.h_points, c.d_points.p, rows * 32, hipMemcpyDeviceToHost, c.stream));
+}
+
+// table build: one thread per (base, window); extended points first, then a per-thread batch inversion to affine Niels
+__global__ __launch_bounds__(kBlock) void k_table_ext(const Pt *bases, size_t nb, int c, int W, size_t E, Pt *tmp) {
+    size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (t >= nb * W) return;
+    size_t b = t / W; int w = (int)(t % W);
+    Pt B = bases[b];
+    for (int k = 0; k < c * w; k++) B = pt_dbl(B);
+    Pt acc = B; Pt *row = tmp + t * E;
+    row[0] = acc;
+    for (size_t d = 1; d < E; d++) { acc = pt_add(acc, B); row[d] = acc; }
+}
+__global__ __launch_bounds__(kBlock) void k_table_affine(Pt *tmp, size_t nrows, size_t E, Niels *out) {
+    size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (t >= nrows) return;
+    Pt *row = tmp + t * E; Niels *orow = out + t * E;
+    Fp prod = fp_one();
+    for (size_t d = 0; d < E; d++) { row[d].T = prod; prod = fp_mul(prod, row[d].Z); }     // T is not needed for the affine form
+    Fp inv = fp_inv(prod);
+    for (size_t d = E; d-- > 0;) { Pt p = row[d]; Fp zinv = fp_mul(inv, p.T); inv = fp_mul(inv, p.Z); orow[d] = pt_to_niels(p, zinv); }
+}
+std::shared_ptr<DeviceGens> build_device_gens(const Gens &g, int c) {
+    DevCtx &ctx = DevCtx::get();
+    auto d = std::make_shared<DeviceGens>();
+    d->c = c; d->W = 253 / c + 1; d->E = (size_t)1 << (c - 1); d->nbases = g.P.size();
+    size_t per_base = (size_t)d->W * d->E;
+    d->table.alloc(d->nbases * per_base);
+    DevBuf<Pt> bases(d->nbases);
+    OTTI_HIP(hipMemcpy(bases.p, g.P.data(), d->nbases * sizeof(Pt), hipMemcpyHostToDevice));
+    size_t chunk = std::max<size_t>(1, ((size_t)1 << 30) / (per_base * sizeof(Pt)));            // <= 1 GiB of extended temporaries
+    chunk = std::min(chunk, d->nbases);
+    DevBuf<Pt> tmp(chunk * per_base);
+    for (size_t b0 = 0; b0 < d->nbases; b0 += chunk) {
+        size_t nb = std::min(chunk, d->nbases - b0), nthreads = nb * d->W;
+        unsigned grid = (unsigned)((nthreads + kBlock - 1) / kBlock);
+        hipLaunchKernelGGL(k_table_ext, grid, kBlock, 0, ctx.stream, (const Pt *)(bases.p + b0), nb, c, d->W, d->E, tmp.p);
+        hipLaunchKernelGGL(k_table_affine, grid, kBlock, 0, ctx.stream, tmp.p, nthreads, d->E, d->table.p + b0 * per_base);
+    }
+    ctx.sync();
+    return d;
+}
+
+// ------------------------------------------------------------------------------------------------ K10 bullet reduction bookkeeping
+// Instead of folding the generator vector (n/2 two-scalar multiplications per round upstream), keep the ORIGINAL generators and a
+// coefficient vector s with G^(k)_i = sum_{j = i mod n} s[j] * P[j]; L and R of each round are then fixed-base MSM rows over P.
+__global__ __launch_bounds__(1024) void k_bullet_step(Fr *a, Fr *b, Fr *s, size_t R, size_t n, int fold_first, Fr u, Fr uinv, Fr *rows, Fr *extra_out) {
+    if (fold_first) {
+        for (size_t i = threadIdx.x; i < n; i += blockDim.x) {
+            a[i] = fr_add(fr_mul(a[i], u), fr_mul(uinv, a[n + i]));
+            b[i] = fr_add(fr_mul(b[i], uinv), fr_mul(u, b[n + i]));
+        }
+        for (size_t j = threadIdx.x; j < R; j += blockDim.x) s[j] = fr_mul(s[j], ((j & (2 * n - 1)) < n) ? uinv : u);
+        __syncthreads();
+    }
+    if (n < 2) return;
+    size_t h = n / 2;
+    Fr acc[2] = {fr_zero(), fr_zero()};
+    for (size_t i = threadIdx.x; i < h; i += blockDim.x) {
+        acc[0] = fr_add(acc[0], fr_mul(a[i], b[h + i]));       // c_L = <a_L, b_R>
+        acc[1] = fr_add(acc[1], fr_mul(a[h + i], b[i]));       // c_R = <a_R, b_L>
+    }
+    block_reduce<2>(acc);
+    if (threadIdx.x == 0) { extra_out[0] = acc[0]; extra_out[2] = acc[1]; }
+    for (size_t j = threadIdx.x; j < R; j += blockDim.x) {
+        size_t i = j & (n - 1);
+        Fr sj = s[j];
+        rows[j] = i >= h ? fr_mul(a[i - h], sj) : fr_zero();       // L = <a_L, G_R> : generator slots in the upper half
+        rows[R + j] = i < h ? fr_mul(a[i + h], sj) : fr_zero();    // R = <a_R, G_L>
+    }
+}
+void dev_bullet_step(DevCtx &c, Fr *a, Fr *b, Fr *s, size_t R, size_t n_cur, bool fold_first, const Fr &u, const Fr &u_inv, Fr *rows, Fr *extra_out) {
+    hipLaunchKernelGGL(k_bullet_step, 1, 1024, 0, c.stream, a, b, s, R, n_cur, (int)fold_first, u, u_inv, rows, extra_out);
+}
+
+}  // namespace otti

@@ -1,0 +1,525 @@
+// Host-side objects of the proving path: instance building, generator derivation, proof (de)serialisation, sigma protocols,
+// verifier, synthetic instances.  See spartan.h for what each piece replaces upstream.
+#include "spartan.h"
+#include <algorithm>
+#include <numeric>
+
+namespace otti {
+
+// ================================================================================================ instance (lib.rs Instance::new)
+static void build_csr(Csr &out, const std::vector<uint32_t> &major, const std::vector<uint32_t> &minor, const std::vector<Fr> &val, size_t rows) {
+    out.rows = rows; out.ptr.assign(rows + 1, 0);
+    for (uint32_t r : major) out.ptr[r + 1]++;
+    for (size_t i = 0; i < rows; i++) out.ptr[i + 1] += out.ptr[i];
+    out.idx.resize(major.size()); out.val.resize(major.size());
+    std::vector<uint32_t> cur(out.ptr.begin(), out.ptr.end() - 1);
+    for (size_t i = 0; i < major.size(); i++) { uint32_t p = cur[major[i]]++; out.idx[p] = minor[i]; out.val[p] = val[i]; }
+}
+
+std::unique_ptr<Instance> instance_new(size_t num_cons, size_t num_vars, size_t num_inputs, const otti_entry *A, size_t nA,
+                                       const otti_entry *B, size_t nB, const otti_entry *C, size_t nC) {
+    size_t nvp = next_pow2(std::max(num_vars, num_inputs + 1));
+    size_t ncp = num_cons < 2 ? 2 : next_pow2(num_cons);
+    if (ncp > ((size_t)1 << 30) || nvp > ((size_t)1 << 30)) throw Error(OTTI_ERR_BAD_ARG, "instance too large for 32-bit indices");
+    auto I = std::make_unique<Instance>();
+    I->num_cons = ncp; I->num_vars = nvp; I->num_inputs = num_inputs;
+    const otti_entry *src[3] = {A, B, C}; size_t cnt[3] = {nA, nB, nC};
+    for (int k = 0; k < 3; k++) {
+        SparseMat &m = I->M[k];
+        m.row.reserve(cnt[k]); m.col.reserve(cnt[k]); m.val.reserve(cnt[k]);
+        for (size_t i = 0; i < cnt[k]; i++) {
+            const otti_entry &e = src[k][i];
+            if (e.row >= num_cons) throw Error(OTTI_ERR_INVALID_INDEX, "row index out of range");
+            if (e.col >= num_vars + 1 + num_inputs) throw Error(OTTI_ERR_INVALID_INDEX, "column index out of range");
+            Fr v; if (!fr_from_bytes(v, e.val)) throw Error(OTTI_ERR_INVALID_SCALAR, "non-canonical scalar in matrix");
+            // columns >= num_vars reference the constant 1 or an input: shift by the padding of the variable block
+            size_t col = e.col >= num_vars ? e.col + nvp - num_vars : e.col;
+            m.row.push_back((uint32_t)e.row); m.col.push_back((uint32_t)col); m.val.push_back(v);
+        }
+        // (upstream also appends explicit zero entries when num_cons < 2; zeros change nothing and are not stored)
+        build_csr(m.by_row, m.row, m.col, m.val, ncp);
+        build_csr(m.by_col, m.col, m.row, m.val, 2 * nvp);
+    }
+    return I;
+}
+
+std::vector<Fr> eq_evals_host(const Fr *r, size_t ell) {
+    std::vector<Fr> ev((size_t)1 << ell);
+    ev[0] = fr_one();
+    size_t size = 1;
+    for (size_t j = 0; j < ell; j++) {
+        for (size_t k = size; k-- > 0;) { Fr hi = fr_mul(ev[k], r[j]); ev[2 * k] = fr_sub(ev[k], hi); ev[2 * k + 1] = hi; }
+        size *= 2;
+    }
+    return ev;
+}
+
+void Instance::evaluate(const std::vector<Fr> &rx, const std::vector<Fr> &ry, Fr out[3]) const {
+    std::vector<Fr> ex = eq_evals_host(rx.data(), rx.size()), ey = eq_evals_host(ry.data(), ry.size());
+    for (int k = 0; k < 3; k++) {
+        Fr acc = fr_zero();
+        const SparseMat &m = M[k];
+        for (size_t i = 0; i < m.val.size(); i++) acc = fr_add(acc, fr_mul(fr_mul(ex[m.row[i]], ey[m.col[i]]), m.val[i]));
+        out[k] = acc;
+    }
+}
+
+static std::vector<Fr> build_z(const Instance &I, const std::vector<Fr> &vars, const std::vector<Fr> &inputs) {
+    std::vector<Fr> z(2 * I.num_vars, fr_zero());
+    std::copy(vars.begin(), vars.end(), z.begin());
+    z[I.num_vars] = fr_one();
+    std::copy(inputs.begin(), inputs.end(), z.begin() + I.num_vars + 1);
+    return z;
+}
+
+bool Instance::is_sat(const std::vector<Fr> &vars, const std::vector<Fr> &inputs) const {
+    std::vector<Fr> z = build_z(*this, vars, inputs);
+    std::vector<Fr> Mz[3];
+    for (int k = 0; k < 3; k++) {
+        Mz[k].assign(num_cons, fr_zero());
+        const Csr &c = M[k].by_row;
+        for (size_t r = 0; r < num_cons; r++) { Fr acc = fr_zero(); for (uint32_t p = c.ptr[r]; p < c.ptr[r + 1]; p++) acc = fr_add(acc, fr_mul(c.val[p], z[c.idx[p]])); Mz[k][r] = acc; }
+    }
+    for (size_t r = 0; r < num_cons; r++) if (!fr_eq(fr_mul(Mz[0][r], Mz[1][r]), Mz[2][r])) return false;
+    return true;
+}
+
+// ================================================================================================ generators (commitments.rs)
+static const uint8_t kBasepointCompressed[32] = {
+    0xe2, 0xf2, 0xae, 0x0a, 0x6a, 0xbc, 0x4e, 0x71, 0xa8, 0x84, 0xa9, 0x61, 0xc5, 0x00, 0x51, 0x5f,
+    0x58, 0xe3, 0x0b, 0x6a, 0xa5, 0x82, 0xdd, 0x8d, 0xb6, 0xa6, 0x59, 0x45, 0xe0, 0x8d, 0x2d, 0x76};
+
+std::vector<Pt> derive_generators(const char *label, size_t count) {
+    Shake256 xof; xof.absorb(label, strlen(label)); xof.absorb(kBasepointCompressed, 32);
+    std::vector<Pt> out(count);
+    for (auto &p : out) { uint8_t u[64]; xof.squeeze(u, 64); p = pt_from_uniform_bytes(u); }
+    return out;
+}
+
+std::unique_ptr<Gens> gens_new(size_t num_cons, size_t num_vars, size_t num_inputs) {
+    (void)num_cons;
+    auto g = std::make_unique<Gens>();
+    size_t nvp = next_pow2(std::max(num_vars, num_inputs + 1));
+    size_t ell = ilog2(nvp);
+    size_t R = (size_t)1 << (ell - ell / 2);
+    g->num_vars_padded = nvp; g->R = R;
+    g->P = derive_generators("gens_r1cs_sat", std::max(R + 2, (size_t)5));
+    g->pc_n.G.resize(R); std::iota(g->pc_n.G.begin(), g->pc_n.G.end(), 0u); g->pc_n.h = (uint32_t)(R + 1);
+    g->pc_1.G = {(uint32_t)R}; g->pc_1.h = (uint32_t)(R + 1);
+    g->sc_1 = g->pc_1;
+    g->sc_3.G = {0, 1, 2}; g->sc_3.h = 3;
+    g->sc_4.G = {0, 1, 2, 3}; g->sc_4.h = 4;
+    g->small_slot.assign(g->P.size(), -1);
+    const size_t small[7] = {0, 1, 2, 3, 4, R, R + 1};
+    for (size_t idx : small) {
+        if (g->small_slot[idx] >= 0) continue;
+        g->small_slot[idx] = (int)g->small_tables.size();
+        g->small_tables.emplace_back(); g->small_tables.back().build(g->P[idx]);
+    }
+    return g;
+}
+
+Pt Gens::commit_terms(const Term *t, size_t n) const {
+    Pt acc = pt_identity();
+    for (size_t i = 0; i < n; i++) {
+        int slot = small_slot[t[i].base];
+        if (slot < 0) throw Error(OTTI_ERR_INTERNAL, "commit_terms: base without a host table");
+        small_tables[slot].accumulate(acc, t[i].s);
+    }
+    return acc;
+}
+Pt Gens::commit_generic(const Fr *v, size_t n, const Fr &blind, const GensView &gv) const {
+    std::vector<Fr> s(v, v + n); s.push_back(blind);
+    std::vector<Pt> pts(n + 1);
+    for (size_t i = 0; i < n; i++) pts[i] = P[gv.G[i]];
+    pts[n] = P[gv.h];
+    return host_msm(s.data(), pts.data(), n + 1);
+}
+
+// ================================================================================================ unipoly.rs
+void unipoly_from_evals(Fr *c, const Fr *e, size_t n) {
+    Fr two_inv = fr_inv(fr_from_u64(2));
+    if (n == 3) {
+        Fr a = fr_mul(two_inv, fr_add(fr_sub(fr_sub(e[2], e[1]), e[1]), e[0]));
+        c[0] = e[0]; c[1] = fr_sub(fr_sub(e[1], e[0]), a); c[2] = a;
+    } else {
+        Fr six_inv = fr_inv(fr_from_u64(6));
+        Fr e1x3 = fr_add(fr_dbl(e[1]), e[1]), e2x3 = fr_add(fr_dbl(e[2]), e[2]);
+        Fr a = fr_mul(six_inv, fr_sub(fr_add(fr_sub(e[3], e2x3), e1x3), e[0]));
+        Fr e1x5 = fr_add(fr_dbl(fr_dbl(e[1])), e[1]), e2x4 = fr_dbl(fr_dbl(e[2]));
+        Fr b = fr_mul(two_inv, fr_sub(fr_add(fr_sub(fr_dbl(e[0]), e1x5), e2x4), e[3]));
+        c[0] = e[0]; c[1] = fr_sub(fr_sub(fr_sub(e[1], e[0]), a), b); c[2] = b; c[3] = a;
+    }
+}
+Fr unipoly_eval(const Fr *c, size_t n, const Fr &r) {
+    Fr ev = c[0], pw = r;
+    for (size_t i = 1; i < n; i++) { ev = fr_add(ev, fr_mul(pw, c[i])); pw = fr_mul(pw, r); }
+    return ev;
+}
+
+// ================================================================================================ sigma protocols (nizk/mod.rs), prover side
+static inline CPoint commit2(const Gens &g, uint32_t b0, const Fr &s0, uint32_t b1, const Fr &s1) {
+    Term t[2] = {{b0, s0}, {b1, s1}}; CPoint c; g.commit_terms_c(c.b, t, 2); return c;
+}
+static inline CPoint commit_scalar(const Gens &g, const GensView &g1, const Fr &x, const Fr &blind) { return commit2(g, g1.G[0], x, g1.h, blind); }
+static CPoint commit_vec(const Gens &g, const GensView &gn, const Fr *v, size_t n, const Fr &blind) {
+    Term t[8]; for (size_t i = 0; i < n; i++) t[i] = {gn.G[i], v[i]}; t[n] = {gn.h, blind};
+    CPoint c; g.commit_terms_c(c.b, t, n + 1); return c;
+}
+
+KnowledgeProof knowledge_prove(CPoint &C, const Gens &g, Transcript &tr, RandomTape &tape, const Fr &x, const Fr &r) {
+    tr.append_protocol_name("knowledge proof");
+    Fr t1 = tape.random_scalar("t1"), t2 = tape.random_scalar("t2");
+    C = commit_scalar(g, g.sc_1, x, r); tr.append_point("C", C.b);
+    KnowledgeProof pf;
+    pf.alpha = commit_scalar(g, g.sc_1, t1, t2); tr.append_point("alpha", pf.alpha.b);
+    Fr c = tr.challenge_scalar("c");
+    pf.z1 = fr_add(fr_mul(x, c), t1); pf.z2 = fr_add(fr_mul(r, c), t2);
+    return pf;
+}
+
+EqualityProof equality_prove(const Gens &g, Transcript &tr, RandomTape &tape, const Fr &v1, const Fr &s1, const Fr &v2, const Fr &s2) {
+    tr.append_protocol_name("equality proof");
+    Fr r = tape.random_scalar("r");
+    CPoint C1 = commit_scalar(g, g.sc_1, v1, s1); tr.append_point("C1", C1.b);
+    CPoint C2 = commit_scalar(g, g.sc_1, v2, s2); tr.append_point("C2", C2.b);
+    EqualityProof pf;
+    Term t = {g.sc_1.h, r}; g.commit_terms_c(pf.alpha.b, &t, 1); tr.append_point("alpha", pf.alpha.b);
+    Fr c = tr.challenge_scalar("c");
+    pf.z = fr_add(fr_mul(c, fr_sub(s1, s2)), r);
+    return pf;
+}
+
+ProductProof product_prove(CPoint &X, CPoint &Y, CPoint &Z, const Gens &g, Transcript &tr, RandomTape &tape, const Fr &x, const Fr &rX,
+                           const Fr &y, const Fr &rY, const Fr &z, const Fr &rZ) {
+    tr.append_protocol_name("product proof");
+    Fr b1 = tape.random_scalar("b1"), b2 = tape.random_scalar("b2"), b3 = tape.random_scalar("b3"), b4 = tape.random_scalar("b4"),
+       b5 = tape.random_scalar("b5");
+    const GensView &g1 = g.sc_1;
+    X = commit_scalar(g, g1, x, rX); tr.append_point("X", X.b);
+    Y = commit_scalar(g, g1, y, rY); tr.append_point("Y", Y.b);
+    Z = commit_scalar(g, g1, z, rZ); tr.append_point("Z", Z.b);
+    ProductProof pf;
+    pf.alpha = commit_scalar(g, g1, b1, b2); tr.append_point("alpha", pf.alpha.b);
+    pf.beta = commit_scalar(g, g1, b3, b4); tr.append_point("beta", pf.beta.b);
+    // delta = b3*X + b5*h with X = x*G + rX*h, i.e. (b3*x)*G + (b3*rX + b5)*h: stays on the fixed-base tables
+    pf.delta = commit_scalar(g, g1, fr_mul(b3, x), fr_add(fr_mul(b3, rX), b5)); tr.append_point("delta", pf.delta.b);
+    Fr c = tr.challenge_scalar("c");
+    pf.z[0] = fr_add(b1, fr_mul(c, x)); pf.z[1] = fr_add(b2, fr_mul(c, rX)); pf.z[2] = fr_add(b3, fr_mul(c, y));
+    pf.z[3] = fr_add(b4, fr_mul(c, rY)); pf.z[4] = fr_add(b5, fr_mul(c, fr_sub(rZ, fr_mul(rX, y))));
+    return pf;
+}
+
+DotProductProof dotproduct_prove(const Gens &g, const GensView &gn, Transcript &tr, RandomTape &tape, const Fr *x, size_t n,
+                                 const Fr &blind_x, const Fr *a, const Fr &y, const Fr &blind_y, const CPoint *Cx_known) {
+    tr.append_protocol_name("dot product proof");
+    std::vector<Fr> d = tape.random_vector("d_vec", n);
+    Fr r_delta = tape.random_scalar("r_delta"), r_beta = tape.random_scalar("r_beta");
+    CPoint Cx = Cx_known ? *Cx_known : commit_vec(g, gn, x, n, blind_x);     // the round's comm_poly is this same commitment
+    tr.append_point("Cx", Cx.b);
+    CPoint Cy = commit_scalar(g, g.sc_1, y, blind_y); tr.append_point("Cy", Cy.b);
+    tr.append_scalars("a", a, n);
+    DotProductProof pf;
+    pf.delta = commit_vec(g, gn, d.data(), n, r_delta); tr.append_point("delta", pf.delta.b);
+    Fr ad = fr_zero(); for (size_t i = 0; i < n; i++) ad = fr_add(ad, fr_mul(a[i], d[i]));
+    pf.beta = commit_scalar(g, g.sc_1, ad, r_beta); tr.append_point("beta", pf.beta.b);
+    Fr c = tr.challenge_scalar("c");
+    pf.z.resize(n); for (size_t i = 0; i < n; i++) pf.z[i] = fr_add(fr_mul(c, x[i]), d[i]);
+    pf.z_delta = fr_add(fr_mul(c, blind_x), r_delta); pf.z_beta = fr_add(fr_mul(c, blind_y), r_beta);
+    return pf;
+}
+
+// sumcheck.rs: the transcript work of one round, split at the challenge so the device can fold while the host finishes
+RoundPart1 sumcheck_round_begin(ZKSumcheckProof &pf, size_t j, const Fr *evals, size_t ne, const SumcheckState &st, const Gens &g,
+                                const GensView &gn, Transcript &tr) {
+    RoundPart1 p; p.ne = ne;
+    unipoly_from_evals(p.poly, evals, ne);
+    pf.comm_polys[j] = commit_vec(g, gn, p.poly, ne, st.blinds_poly[j]);
+    tr.append_point("comm_poly", pf.comm_polys[j].b);
+    p.r_j = tr.challenge_scalar("challenge_nextround");
+    return p;
+}
+void sumcheck_round_finish(ZKSumcheckProof &pf, size_t j, const RoundPart1 &p1, SumcheckState &st, const Gens &g, const GensView &gn,
+                           Transcript &tr, RandomTape &tape) {
+    size_t ne = p1.ne;
+    Fr eval = unipoly_eval(p1.poly, ne, p1.r_j);
+    CPoint comm_eval = commit_scalar(g, g.sc_1, eval, st.blinds_evals[j]);
+    tr.append_point("comm_claim_per_round", st.comm_claim.b);
+    tr.append_point("comm_eval", comm_eval.b);
+    std::vector<Fr> w = tr.challenge_vector("combine_two_claims_to_one", 2);
+    Fr target = fr_add(fr_mul(w[0], st.claim), fr_mul(w[1], eval));
+    const Fr &blind_sc = j == 0 ? st.blind_claim : st.blinds_evals[j - 1];
+    Fr blind = fr_add(fr_mul(w[0], blind_sc), fr_mul(w[1], st.blinds_evals[j]));
+    Fr a[4], pw = fr_one(), two = fr_from_u64(2);
+    for (size_t i = 0; i < ne; i++) { a[i] = fr_add(fr_mul(w[0], i == 0 ? two : fr_one()), fr_mul(w[1], pw)); pw = fr_mul(pw, p1.r_j); }
+    pf.proofs[j] = dotproduct_prove(g, gn, tr, tape, p1.poly, ne, st.blinds_poly[j], a, target, blind, &pf.comm_polys[j]);
+    st.claim = eval; st.comm_claim = comm_eval; pf.comm_evals[j] = comm_eval;
+}
+
+// ================================================================================================ bincode layout
+namespace {
+struct Writer {
+    std::vector<uint8_t> b;
+    void raw(const void *p, size_t n) { const uint8_t *q = (const uint8_t *)p; b.insert(b.end(), q, q + n); }
+    void u64(uint64_t x) { uint8_t t[8]; for (int i = 0; i < 8; i++) { t[i] = (uint8_t)x; x >>= 8; } raw(t, 8); }
+    void pt(const CPoint &c) { raw(c.b, 32); }
+    void fr(const Fr &x) { raw(x.v, 32); }                      // upstream serialises Scalar's Montgomery limbs
+    void pts(const std::vector<CPoint> &v) { u64(v.size()); for (auto &c : v) pt(c); }
+    void frs(const std::vector<Fr> &v) { u64(v.size()); for (auto &x : v) fr(x); }
+    void sc(const ZKSumcheckProof &s) {
+        pts(s.comm_polys); pts(s.comm_evals); u64(s.proofs.size());
+        for (auto &d : s.proofs) { pt(d.delta); pt(d.beta); frs(d.z); fr(d.z_delta); fr(d.z_beta); }
+    }
+};
+struct Reader {
+    const uint8_t *p; size_t n, pos = 0;
+    void need(size_t k) { if (pos + k > n) throw Error(OTTI_ERR_MALFORMED_PROOF, "proof truncated"); }
+    uint64_t u64() { need(8); uint64_t x = 0; for (int i = 7; i >= 0; i--) x = (x << 8) | p[pos + i]; pos += 8; return x; }
+    CPoint pt() { need(32); CPoint c; memcpy(c.b, p + pos, 32); pos += 32; return c; }
+    Fr fr() { need(32); Fr x; memcpy(x.v, p + pos, 32); pos += 32; if (!fr_raw_is_canonical(x.v)) throw Error(OTTI_ERR_MALFORMED_PROOF, "scalar out of range"); return x; }
+    size_t len(size_t max) { uint64_t k = u64(); if (k > max) throw Error(OTTI_ERR_MALFORMED_PROOF, "vector length out of range"); return (size_t)k; }
+    std::vector<CPoint> pts(size_t max) { size_t k = len(max); std::vector<CPoint> v(k); for (auto &c : v) c = pt(); return v; }
+    std::vector<Fr> frs(size_t max) { size_t k = len(max); std::vector<Fr> v(k); for (auto &x : v) x = fr(); return v; }
+    ZKSumcheckProof sc() {
+        ZKSumcheckProof s; s.comm_polys = pts(64); s.comm_evals = pts(64); size_t k = len(64); s.proofs.resize(k);
+        for (auto &d : s.proofs) { d.delta = pt(); d.beta = pt(); d.z = frs(4); d.z_delta = fr(); d.z_beta = fr(); }
+        return s;
+    }
+};
+}  // namespace
+
+std::vector<uint8_t> NizkProof::serialize() const {
+    Writer w;
+    w.pts(comm_vars); w.sc(sc1);
+    for (int i = 0; i < 4; i++) w.pt(claims_phase2[i]);
+    w.pt(pok.alpha); w.fr(pok.z1); w.fr(pok.z2);
+    w.pt(prod.alpha); w.pt(prod.beta); w.pt(prod.delta); for (int i = 0; i < 5; i++) w.fr(prod.z[i]);
+    w.pt(eq1.alpha); w.fr(eq1.z);
+    w.sc(sc2);
+    w.pt(comm_vars_at_ry);
+    w.pts(polyeval.L_vec); w.pts(polyeval.R_vec); w.pt(polyeval.delta); w.pt(polyeval.beta); w.fr(polyeval.z1); w.fr(polyeval.z2);
+    w.pt(eq2.alpha); w.fr(eq2.z);
+    w.frs(rx); w.frs(ry);
+    return std::move(w.b);
+}
+
+NizkProof NizkProof::parse(const uint8_t *p, size_t n) {
+    Reader r{p, n}; NizkProof P;
+    P.comm_vars = r.pts((size_t)1 << 20); P.sc1 = r.sc();
+    for (int i = 0; i < 4; i++) P.claims_phase2[i] = r.pt();
+    P.pok.alpha = r.pt(); P.pok.z1 = r.fr(); P.pok.z2 = r.fr();
+    P.prod.alpha = r.pt(); P.prod.beta = r.pt(); P.prod.delta = r.pt(); for (int i = 0; i < 5; i++) P.prod.z[i] = r.fr();
+    P.eq1.alpha = r.pt(); P.eq1.z = r.fr();
+    P.sc2 = r.sc();
+    P.comm_vars_at_ry = r.pt();
+    P.polyeval.L_vec = r.pts(64); P.polyeval.R_vec = r.pts(64); P.polyeval.delta = r.pt(); P.polyeval.beta = r.pt();
+    P.polyeval.z1 = r.fr(); P.polyeval.z2 = r.fr();
+    P.eq2.alpha = r.pt(); P.eq2.z = r.fr();
+    P.rx = r.frs(64); P.ry = r.frs(64);
+    if (r.pos != n) throw Error(OTTI_ERR_MALFORMED_PROOF, "trailing bytes after proof");
+    return P;
+}
+
+// ================================================================================================ verifier
+namespace {
+struct VerifyFail { int code; };
+Pt dec(const CPoint &c) { Pt p; if (!pt_decode(p, c.b)) throw VerifyFail{OTTI_ERR_VERIFY_DECOMPRESS}; return p; }
+void require(bool ok) { if (!ok) throw VerifyFail{OTTI_ERR_VERIFY_INTERNAL}; }
+Pt commit_scalar_pt(const Gens &g, const GensView &g1, const Fr &x, const Fr &blind) { return g.commit_generic(&x, 1, blind, g1); }
+
+void knowledge_verify(const KnowledgeProof &pf, const Gens &g, Transcript &tr, const CPoint &C) {
+    tr.append_protocol_name("knowledge proof");
+    tr.append_point("C", C.b); tr.append_point("alpha", pf.alpha.b);
+    Fr c = tr.challenge_scalar("c");
+    Pt lhs = commit_scalar_pt(g, g.sc_1, pf.z1, pf.z2);
+    Pt rhs = pt_add(host_scalarmul(dec(C), c), dec(pf.alpha));
+    require(pt_eq(lhs, rhs));
+}
+void equality_verify(const EqualityProof &pf, const Gens &g, Transcript &tr, const CPoint &C1, const CPoint &C2) {
+    tr.append_protocol_name("equality proof");
+    tr.append_point("C1", C1.b); tr.append_point("C2", C2.b); tr.append_point("alpha", pf.alpha.b);
+    Fr c = tr.challenge_scalar("c");
+    Pt rhs = pt_add(host_scalarmul(pt_sub(dec(C1), dec(C2)), c), dec(pf.alpha));
+    Pt lhs = host_scalarmul(g.P[g.sc_1.h], pf.z);
+    require(pt_eq(lhs, rhs));
+}
+bool product_check(const CPoint &P, const Pt &X, const Fr &c, const Pt &G, const Pt &h, const Fr &z1, const Fr &z2) {
+    Pt lhs = pt_add(dec(P), host_scalarmul(X, c));
+    Pt rhs = pt_add(host_scalarmul(G, z1), host_scalarmul(h, z2));
+    return pt_eq(lhs, rhs);
+}
+void product_verify(const ProductProof &pf, const Gens &g, Transcript &tr, const CPoint &X, const CPoint &Y, const CPoint &Z) {
+    tr.append_protocol_name("product proof");
+    tr.append_point("X", X.b); tr.append_point("Y", Y.b); tr.append_point("Z", Z.b);
+    tr.append_point("alpha", pf.alpha.b); tr.append_point("beta", pf.beta.b); tr.append_point("delta", pf.delta.b);
+    Fr c = tr.challenge_scalar("c");
+    const Pt &G = g.P[g.sc_1.G[0]], &h = g.P[g.sc_1.h];
+    Pt Xp = dec(X), Yp = dec(Y), Zp = dec(Z);
+    require(product_check(pf.alpha, Xp, c, G, h, pf.z[0], pf.z[1]) && product_check(pf.beta, Yp, c, G, h, pf.z[2], pf.z[3]) &&
+            product_check(pf.delta, Zp, c, Xp, h, pf.z[2], pf.z[4]));
+}
+void dotproduct_verify(const DotProductProof &pf, const Gens &g, const GensView &gn, Transcript &tr, const Fr *a, size_t n,
+                       const CPoint &Cx, const CPoint &Cy) {
+    require(pf.z.size() == n && gn.G.size() == n);
+    tr.append_protocol_name("dot product proof");
+    tr.append_point("Cx", Cx.b); tr.append_point("Cy", Cy.b);
+    tr.append_scalars("a", a, n);
+    tr.append_point("delta", pf.delta.b); tr.append_point("beta", pf.beta.b);
+    Fr c = tr.challenge_scalar("c");
+    bool ok = pt_eq(pt_add(host_scalarmul(dec(Cx), c), dec(pf.delta)), g.commit_generic(pf.z.data(), n, pf.z_delta, gn));
+    Fr za = fr_zero(); for (size_t i = 0; i < n; i++) za = fr_add(za, fr_mul(pf.z[i], a[i]));
+    ok = ok && pt_eq(pt_add(host_scalarmul(dec(Cy), c), dec(pf.beta)), commit_scalar_pt(g, g.sc_1, za, pf.z_beta));
+    require(ok);
+}
+// ZKSumcheckInstanceProof::verify
+CPoint sumcheck_verify(const ZKSumcheckProof &pf, const CPoint &comm_claim, size_t num_rounds, size_t degree, const Gens &g,
+                       const GensView &gn, Transcript &tr, std::vector<Fr> &r) {
+    require(gn.G.size() == degree + 1 && pf.comm_polys.size() == num_rounds && pf.comm_evals.size() == num_rounds &&
+            pf.proofs.size() == num_rounds);
+    size_t ne = degree + 1; r.clear();
+    for (size_t i = 0; i < num_rounds; i++) {
+        tr.append_point("comm_poly", pf.comm_polys[i].b);
+        Fr r_i = tr.challenge_scalar("challenge_nextround");
+        const CPoint &ccpr = i == 0 ? comm_claim : pf.comm_evals[i - 1];
+        tr.append_point("comm_claim_per_round", ccpr.b); tr.append_point("comm_eval", pf.comm_evals[i].b);
+        std::vector<Fr> w = tr.challenge_vector("combine_two_claims_to_one", 2);
+        CPoint comm_target; pt_encode(comm_target.b, pt_add(host_scalarmul(dec(ccpr), w[0]), host_scalarmul(dec(pf.comm_evals[i]), w[1])));
+        Fr a[4], pw = fr_one(), two = fr_from_u64(2);
+        for (size_t k = 0; k < ne; k++) { a[k] = fr_add(fr_mul(w[0], k == 0 ? two : fr_one()), fr_mul(w[1], pw)); pw = fr_mul(pw, r_i); }
+        dotproduct_verify(pf.proofs[i], g, gn, tr, a, ne, pf.comm_polys[i], comm_target);
+        r.push_back(r_i);
+    }
+    return pf.comm_evals[num_rounds - 1];
+}
+// BulletReductionProof::verify
+void bullet_verify(const DotProductProofLog &pf, size_t n, const Fr *a, Transcript &tr, const Pt &Gamma, const Gens &g, Pt &g_hat,
+                   Pt &Gamma_hat, Fr &a_hat) {
+    size_t lg = pf.L_vec.size();
+    require(pf.R_vec.size() == lg && lg < 32 && n == ((size_t)1 << lg));
+    std::vector<Fr> ch(lg), chi(lg);
+    for (size_t i = 0; i < lg; i++) { tr.append_point("L", pf.L_vec[i].b); tr.append_point("R", pf.R_vec[i].b); ch[i] = tr.challenge_scalar("u"); }
+    Fr allinv = fr_one();
+    for (size_t i = 0; i < lg; i++) { chi[i] = fr_inv(ch[i]); allinv = fr_mul(allinv, chi[i]); }
+    for (size_t i = 0; i < lg; i++) { ch[i] = fr_sqr(ch[i]); chi[i] = fr_sqr(chi[i]); }
+    std::vector<Fr> s(n); s[0] = allinv;
+    for (size_t i = 1; i < n; i++) { size_t lg_i = ilog2(i + 1) - 1; size_t k = (size_t)1 << lg_i; s[i] = fr_mul(s[i - k], ch[(lg - 1) - lg_i]); }
+    std::vector<Pt> G(n); for (size_t i = 0; i < n; i++) G[i] = g.P[g.pc_n.G[i]];
+    g_hat = host_msm(s.data(), G.data(), n);
+    a_hat = fr_zero(); for (size_t i = 0; i < n; i++) a_hat = fr_add(a_hat, fr_mul(a[i], s[i]));
+    std::vector<Fr> sc; std::vector<Pt> pts;
+    for (size_t i = 0; i < lg; i++) { sc.push_back(ch[i]); pts.push_back(dec(pf.L_vec[i])); }
+    for (size_t i = 0; i < lg; i++) { sc.push_back(chi[i]); pts.push_back(dec(pf.R_vec[i])); }
+    sc.push_back(fr_one()); pts.push_back(Gamma);
+    Gamma_hat = host_msm(sc.data(), pts.data(), sc.size());
+}
+void dotproductlog_verify(const DotProductProofLog &pf, size_t n, const Gens &g, Transcript &tr, const Fr *a, const CPoint &Cx, const CPoint &Cy) {
+    require(g.pc_n.G.size() == n);
+    tr.append_protocol_name("dot product proof (log)");
+    tr.append_point("Cx", Cx.b); tr.append_point("Cy", Cy.b);
+    Pt Gamma = pt_add(dec(Cx), dec(Cy)), g_hat, Gamma_hat; Fr a_hat;
+    bullet_verify(pf, n, a, tr, Gamma, g, g_hat, Gamma_hat, a_hat);
+    tr.append_point("delta", pf.delta.b); tr.append_point("beta", pf.beta.b);
+    Fr c = tr.challenge_scalar("c");
+    Pt lhs = pt_add(host_scalarmul(pt_add(host_scalarmul(Gamma_hat, c), dec(pf.beta)), a_hat), dec(pf.delta));
+    Pt rhs = pt_add(host_scalarmul(pt_add(g_hat, host_scalarmul(g.P[g.pc_1.G[0]], a_hat)), pf.z1), host_scalarmul(g.P[g.pc_1.h], pf.z2));
+    require(pt_eq(lhs, rhs));
+}
+}  // namespace
+
+int nizk_verify(const Instance &I, const std::vector<Fr> &inputs, const Gens &g, const void *tlabel, size_t tlabel_len, const uint8_t *proof,
+                size_t proof_len) {
+    try {
+        if (inputs.size() != I.num_inputs) return OTTI_ERR_INVALID_NUM_INPUTS;
+        NizkProof P = NizkProof::parse(proof, proof_len);
+        size_t N = I.num_cons, V = I.num_vars, nrx = ilog2(N), nry = ilog2(2 * V);
+        size_t ell = ilog2(V), Lsz = (size_t)1 << (ell / 2), Rsz = (size_t)1 << (ell - ell / 2);
+        require(g.num_vars_padded == V && P.rx.size() == nrx && P.ry.size() == nry && P.comm_vars.size() == Lsz);
+        Transcript tr(tlabel, tlabel_len);
+        tr.append_protocol_name("Spartan NIZK proof");
+        Fr inst_evals[3]; I.evaluate(P.rx, P.ry, inst_evals);
+        // R1CSProof::verify
+        tr.append_protocol_name("R1CS proof");
+        tr.append_message("poly_commitment", "poly_commitment_begin", 21);
+        for (auto &c : P.comm_vars) tr.append_point("poly_commitment_share", c.b);
+        tr.append_message("poly_commitment", "poly_commitment_end", 19);
+        std::vector<Fr> tau = tr.challenge_vector("challenge_tau", nrx), rx, ry;
+        CPoint claim_phase1; pt_encode(claim_phase1.b, commit_scalar_pt(g, g.sc_1, fr_zero(), fr_zero()));
+        CPoint comm_post1 = sumcheck_verify(P.sc1, claim_phase1, nrx, 3, g, g.sc_4, tr, rx);
+        const CPoint &cAz = P.claims_phase2[0], &cBz = P.claims_phase2[1], &cCz = P.claims_phase2[2], &cPr = P.claims_phase2[3];
+        knowledge_verify(P.pok, g, tr, cCz);
+        product_verify(P.prod, g, tr, cAz, cBz, cPr);
+        tr.append_point("comm_Az_claim", cAz.b); tr.append_point("comm_Bz_claim", cBz.b);
+        tr.append_point("comm_Cz_claim", cCz.b); tr.append_point("comm_prod_Az_Bz_claims", cPr.b);
+        Fr taus_bound = fr_one(), one = fr_one();
+        for (size_t i = 0; i < nrx; i++) taus_bound = fr_mul(taus_bound, fr_add(fr_mul(rx[i], tau[i]), fr_mul(fr_sub(one, rx[i]), fr_sub(one, tau[i]))));
+        CPoint expected1; pt_encode(expected1.b, host_scalarmul(pt_sub(dec(cPr), dec(cCz)), taus_bound));
+        equality_verify(P.eq1, g, tr, expected1, comm_post1);
+        Fr rA = tr.challenge_scalar("challenege_Az"), rB = tr.challenge_scalar("challenege_Bz"), rC = tr.challenge_scalar("challenege_Cz");
+        CPoint comm_claim2;
+        pt_encode(comm_claim2.b, pt_add(pt_add(host_scalarmul(dec(cAz), rA), host_scalarmul(dec(cBz), rB)), host_scalarmul(dec(cCz), rC)));
+        CPoint comm_post2 = sumcheck_verify(P.sc2, comm_claim2, nry, 2, g, g.sc_3, tr, ry);
+        // PolyEvalProof::verify
+        {
+            tr.append_protocol_name("polynomial evaluation proof");
+            size_t rl = nry - 1, lv = rl / 2;
+            std::vector<Fr> Lv = eq_evals_host(ry.data() + 1, lv), Rv = eq_evals_host(ry.data() + 1 + lv, rl - lv);
+            std::vector<Pt> Cs(Lsz); for (size_t i = 0; i < Lsz; i++) Cs[i] = dec(P.comm_vars[i]);
+            CPoint C_LZ; pt_encode(C_LZ.b, host_msm(Lv.data(), Cs.data(), Lsz));
+            require(P.polyeval.L_vec.size() == ilog2(Rsz));
+            dotproductlog_verify(P.polyeval, Rsz, g, tr, Rv.data(), C_LZ, P.comm_vars_at_ry);
+        }
+        // SparsePolynomial over (1, inputs) evaluated at ry[1..], MSB-first index bits
+        Fr poly_input_eval = fr_zero();
+        for (size_t idx = 0; idx <= inputs.size(); idx++) {
+            Fr chi = fr_one();
+            for (size_t j = 0; j < ell; j++) { bool bit = (idx >> (ell - j - 1)) & 1; chi = fr_mul(chi, bit ? ry[1 + j] : fr_sub(one, ry[1 + j])); }
+            poly_input_eval = fr_add(poly_input_eval, fr_mul(chi, idx == 0 ? one : inputs[idx - 1]));
+        }
+        Pt comm_eval_Z = pt_add(host_scalarmul(dec(P.comm_vars_at_ry), fr_sub(one, ry[0])),
+                                host_scalarmul(commit_scalar_pt(g, g.pc_1, poly_input_eval, fr_zero()), ry[0]));
+        Fr comb = fr_add(fr_add(fr_mul(rA, inst_evals[0]), fr_mul(rB, inst_evals[1])), fr_mul(rC, inst_evals[2]));
+        CPoint expected2; pt_encode(expected2.b, host_scalarmul(comm_eval_Z, comb));
+        equality_verify(P.eq2, g, tr, expected2, comm_post2);
+        for (size_t i = 0; i < nrx; i++) require(fr_eq(rx[i], P.rx[i]));
+        for (size_t i = 0; i < nry; i++) require(fr_eq(ry[i], P.ry[i]));
+        return OTTI_OK;
+    } catch (const VerifyFail &f) { return f.code; }
+    catch (const Error &e) { return e.code; }
+}
+
+// ================================================================================================ synthetic R1CS
+void synth_r1cs(size_t n, size_t ni, uint64_t seed, std::vector<otti_entry> &A, std::vector<otti_entry> &B, std::vector<otti_entry> &C,
+                std::vector<uint8_t> &vars32, std::vector<uint8_t> &inputs32) {
+    size_t size_z = n + ni + 1;
+    std::vector<Fr> Z(size_z);
+    for (size_t k = 0; k < size_z; k++) {
+        Shake256 xof; uint8_t le[16], w[64];
+        for (int i = 0; i < 8; i++) { le[i] = (uint8_t)(seed >> (8 * i)); le[8 + i] = (uint8_t)((uint64_t)k >> (8 * i)); }
+        xof.absorb("otti-synth", 10); xof.absorb(le, 16); xof.squeeze(w, 64);
+        Z[k] = fr_from_bytes_wide(w);
+    }
+    Z[n] = fr_one();
+    A.resize(n); B.resize(n); C.resize(n);
+    uint8_t one_bytes[32]; fr_to_bytes(one_bytes, fr_one());
+    // batch the inversions Z[c]^-1
+    std::vector<Fr> zc(n), pre(n);
+    Fr acc = fr_one();
+    for (size_t i = 0; i < n; i++) { zc[i] = Z[(i + 3) % size_z]; pre[i] = acc; if (!fr_is_zero(zc[i])) acc = fr_mul(acc, zc[i]); }
+    acc = fr_inv(acc);
+    std::vector<Fr> inv(n);
+    for (size_t i = n; i-- > 0;) { if (fr_is_zero(zc[i])) { inv[i] = fr_zero(); continue; } inv[i] = fr_mul(acc, pre[i]); acc = fr_mul(acc, zc[i]); }
+    for (size_t i = 0; i < n; i++) {
+        size_t a = i % size_z, b = (i + 2) % size_z, c = (i + 3) % size_z;
+        A[i].row = i; A[i].col = a; memcpy(A[i].val, one_bytes, 32);
+        B[i].row = i; B[i].col = b; memcpy(B[i].val, one_bytes, 32);
+        Fr ab = fr_mul(Z[a], Z[b]);
+        C[i].row = i;
+        if (fr_is_zero(Z[c])) { C[i].col = n; fr_to_bytes(C[i].val, ab); }
+        else { C[i].col = c; fr_to_bytes(C[i].val, fr_mul(ab, inv[i])); }
+    }
+    vars32.resize(32 * n); inputs32.resize(32 * ni);
+    for (size_t k = 0; k < n; k++) fr_to_bytes(&vars32[32 * k], Z[k]);
+    for (size_t k = 0; k < ni; k++) fr_to_bytes(&inputs32[32 * k], Z[n + 1 + k]);
+}
+
+}  // namespace otti

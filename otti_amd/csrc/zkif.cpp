@@ -1,0 +1,312 @@
+// zkInterface ingest for the spzk boundary: a hand-written, bounds-checked FlatBuffers reader (and a writer used to emit
+// synthetic instances as real .zkif triples).  Replaces the `zkinterface` crate + R1CS builder inside spartan-zkinterface
+// [RECALL; /root/reference/spartan-zkinterface is an empty submodule]; the three-file split follows
+// /root/reference/run.py:47-49 (X.zkif = header + constraints, X.inp.zkif = header with instance values, X.wit.zkif = witness).
+//
+// Schema (zkinterface 1.x): Root{message: union{CircuitHeader=1, ConstraintSystem=2, Witness=3, Command=4}};
+// CircuitHeader{instance_variables: Variables, free_variable_id: u64, field_maximum: [u8], configuration};
+// ConstraintSystem{constraints: [BilinearConstraint{linear_combination_a, _b, _c: Variables}]}; Witness{assigned_variables: Variables};
+// Variables{variable_ids: [u64], values: [u8], info}.  Files are concatenations of size-prefixed buffers with identifier "zkif".
+#include "spartan.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <map>
+#include <algorithm>
+
+namespace otti {
+
+namespace {
+struct Buf {
+    const uint8_t *p; size_t n;
+    void chk(size_t off, size_t len) const { if (off > n || len > n - off) throw Error(OTTI_ERR_IO, "zkif: offset out of bounds"); }
+    uint8_t u8(size_t o) const { chk(o, 1); return p[o]; }
+    uint16_t u16(size_t o) const { chk(o, 2); return (uint16_t)(p[o] | (p[o + 1] << 8)); }
+    uint32_t u32(size_t o) const { chk(o, 4); return (uint32_t)p[o] | ((uint32_t)p[o + 1] << 8) | ((uint32_t)p[o + 2] << 16) | ((uint32_t)p[o + 3] << 24); }
+    int32_t i32(size_t o) const { return (int32_t)u32(o); }
+    uint64_t u64(size_t o) const { return (uint64_t)u32(o) | ((uint64_t)u32(o + 4) << 32); }
+};
+struct Table {
+    const Buf *b; size_t pos = 0; bool present = false;
+    // absolute position of field `id`, or 0 when absent
+    size_t field(int id) const {
+        if (!present) return 0;
+        int64_t vt = (int64_t)pos - b->i32(pos);
+        if (vt < 0) throw Error(OTTI_ERR_IO, "zkif: bad vtable offset");
+        uint16_t vsize = b->u16((size_t)vt);
+        size_t slot = 4 + 2 * (size_t)id;
+        if (slot + 2 > vsize) return 0;
+        uint16_t off = b->u16((size_t)vt + slot);
+        return off ? pos + off : 0;
+    }
+    Table sub(int id) const { Table t; t.b = b; size_t f = field(id); if (f) { t.pos = f + b->u32(f); t.present = true; b->chk(t.pos, 4); } return t; }
+    // vector field: returns element start and count
+    bool vec(int id, size_t &start, size_t &count) const {
+        size_t f = field(id); if (!f) { start = count = 0; return false; }
+        size_t v = f + b->u32(f); count = b->u32(v); start = v + 4; return true;
+    }
+    uint64_t u64f(int id, uint64_t dflt) const { size_t f = field(id); return f ? b->u64(f) : dflt; }
+    uint8_t u8f(int id, uint8_t dflt) const { size_t f = field(id); return f ? b->u8(f) : dflt; }
+};
+struct VarList { std::vector<uint64_t> ids; std::vector<std::array<uint8_t, 32>> vals; bool has_vals = false; };
+
+VarList read_variables(const Table &t) {
+    VarList v; if (!t.present) return v;
+    size_t s, n; t.vec(0, s, n);
+    t.b->chk(s, n * 8);
+    v.ids.resize(n); for (size_t i = 0; i < n; i++) v.ids[i] = t.b->u64(s + 8 * i);
+    size_t vs, vn;
+    if (t.vec(1, vs, vn) && vn) {
+        if (n == 0 || vn % n) throw Error(OTTI_ERR_IO, "zkif: values length not a multiple of the variable count");
+        size_t w = vn / n; t.b->chk(vs, vn);
+        v.vals.resize(n); v.has_vals = true;
+        for (size_t i = 0; i < n; i++) {
+            v.vals[i].fill(0);
+            for (size_t k = 0; k < w; k++) {
+                uint8_t byte = t.b->p[vs + i * w + k];
+                if (k < 32) v.vals[i][k] = byte; else if (byte) throw Error(OTTI_ERR_INVALID_SCALAR, "zkif: element wider than 32 bytes");
+            }
+        }
+    }
+    return v;
+}
+
+std::vector<uint8_t> read_file(const char *path) {
+    FILE *f = fopen(path, "rb");
+    if (!f) throw Error(OTTI_ERR_IO, std::string("cannot open ") + path);
+    std::vector<uint8_t> d; uint8_t tmp[1 << 16]; size_t k;
+    while ((k = fread(tmp, 1, sizeof tmp, f)) > 0) d.insert(d.end(), tmp, tmp + k);
+    fclose(f);
+    return d;
+}
+
+struct Messages {
+    bool have_header = false; VarList instance; uint64_t free_variable_id = 0; std::vector<uint8_t> field_maximum;
+    std::vector<std::array<VarList, 3>> constraints;
+    VarList witness; bool have_witness = false;
+};
+void parse_messages(const std::vector<uint8_t> &file, Messages &m) {
+    size_t off = 0;
+    while (off + 4 <= file.size()) {
+        uint32_t sz = (uint32_t)file[off] | ((uint32_t)file[off + 1] << 8) | ((uint32_t)file[off + 2] << 16) | ((uint32_t)file[off + 3] << 24);
+        if (sz < 8 || sz > file.size() - off - 4) throw Error(OTTI_ERR_IO, "zkif: bad message size prefix");
+        Buf b{file.data() + off + 4, sz};
+        if (memcmp(b.p + 4, "zkif", 4) != 0) throw Error(OTTI_ERR_IO, "zkif: missing file identifier");
+        Table root; root.b = &b; root.pos = b.u32(0); root.present = true; b.chk(root.pos, 4);
+        uint8_t type = root.u8f(0, 0);
+        Table msg = root.sub(1);
+        if (type == 1) {                       // CircuitHeader
+            VarList iv = read_variables(msg.sub(0));
+            if (!m.have_header || iv.has_vals) m.instance = iv;           // the .inp.zkif header carries the values
+            m.free_variable_id = std::max(m.free_variable_id, msg.u64f(1, 0));
+            size_t s, n; if (msg.vec(2, s, n)) { b.chk(s, n); m.field_maximum.assign(b.p + s, b.p + s + n); }
+            m.have_header = true;
+        } else if (type == 2) {                // ConstraintSystem
+            size_t s, n; msg.vec(0, s, n); b.chk(s, n * 4);
+            for (size_t i = 0; i < n; i++) {
+                Table bc; bc.b = &b; bc.pos = s + 4 * i + b.u32(s + 4 * i); bc.present = true; b.chk(bc.pos, 4);
+                m.constraints.push_back({read_variables(bc.sub(0)), read_variables(bc.sub(1)), read_variables(bc.sub(2))});
+            }
+        } else if (type == 3) {                // Witness
+            VarList w = read_variables(msg.sub(0));
+            m.witness.ids.insert(m.witness.ids.end(), w.ids.begin(), w.ids.end());
+            m.witness.vals.insert(m.witness.vals.end(), w.vals.begin(), w.vals.end());
+            m.have_witness = true;
+        }                                      // Command and unknown messages are skipped
+        off += 4 + sz;
+    }
+    if (off != file.size()) throw Error(OTTI_ERR_IO, "zkif: trailing bytes");
+}
+
+// ---- forward-laid-out FlatBuffers writer (every uoffset points forward; vtables sit right before their tables)
+struct Fbw {
+    std::vector<uint8_t> b;
+    void pad_to(size_t align, size_t bias = 0) { while ((b.size() + bias) % align) b.push_back(0); }
+    void u16(uint16_t x) { b.push_back((uint8_t)x); b.push_back((uint8_t)(x >> 8)); }
+    void u32(uint32_t x) { for (int i = 0; i < 4; i++) b.push_back((uint8_t)(x >> (8 * i))); }
+    void u64(uint64_t x) { for (int i = 0; i < 8; i++) b.push_back((uint8_t)(x >> (8 * i))); }
+    void patch(size_t at, size_t target) { uint32_t v = (uint32_t)(target - at); for (int i = 0; i < 4; i++) b[at + i] = (uint8_t)(v >> (8 * i)); }
+    // table with fields given as (size in {1,4,8}, inline value); size 4 = offset placeholder.  Returns table pos and placeholder positions.
+    struct F { int size; uint64_t v; };
+    size_t table(const std::vector<F> &fs, std::vector<size_t> &slots) {
+        std::vector<uint16_t> off(fs.size()); size_t cur = 4;
+        for (size_t i = 0; i < fs.size(); i++) { if (fs[i].size == 0) { off[i] = 0; continue; } cur = (cur + fs[i].size - 1) / fs[i].size * fs[i].size; off[i] = (uint16_t)cur; cur += fs[i].size; }
+        size_t vsize = 4 + 2 * fs.size();
+        pad_to(8, vsize);                      // table start 8-aligned
+        size_t vt = b.size();
+        u16((uint16_t)vsize); u16((uint16_t)cur); for (auto o : off) u16(o);
+        size_t tp = b.size();
+        u32((uint32_t)(tp - vt));
+        slots.assign(fs.size(), 0);
+        size_t written = 4;
+        for (size_t i = 0; i < fs.size(); i++) {
+            if (!fs[i].size) continue;
+            while (written < off[i]) { b.push_back(0); written++; }
+            if (fs[i].size == 1) b.push_back((uint8_t)fs[i].v); else if (fs[i].size == 4) { slots[i] = b.size(); u32(0); } else u64(fs[i].v);
+            written += fs[i].size;
+        }
+        return tp;
+    }
+    size_t vec_u64(const std::vector<uint64_t> &v) { pad_to(8, 4); size_t p = b.size(); u32((uint32_t)v.size()); for (auto x : v) u64(x); return p; }
+    size_t vec_u8(const uint8_t *d, size_t n) { pad_to(4); size_t p = b.size(); u32((uint32_t)n); b.insert(b.end(), d, d + n); return p; }
+    size_t variables(const std::vector<uint64_t> &ids, const std::vector<uint8_t> &values) {
+        std::vector<size_t> sl; size_t tp = table({{4, 0}, {4, 0}}, sl);
+        patch(sl[0], vec_u64(ids)); patch(sl[1], vec_u8(values.data(), values.size()));
+        return tp;
+    }
+};
+void begin_message(Fbw &w) { w.b.clear(); w.u32(0); w.b.insert(w.b.end(), {'z', 'k', 'i', 'f'}); }
+void finish_message(Fbw &w, size_t root_pos, FILE *f) {
+    w.patch(0, root_pos);                      // root uoffset is relative to position 0
+    w.pad_to(8);
+    uint32_t sz = (uint32_t)w.b.size(); uint8_t pre[4] = {(uint8_t)sz, (uint8_t)(sz >> 8), (uint8_t)(sz >> 16), (uint8_t)(sz >> 24)};
+    if (fwrite(pre, 1, 4, f) != 4 || fwrite(w.b.data(), 1, w.b.size(), f) != w.b.size()) throw Error(OTTI_ERR_IO, "zkif: write failed");
+}
+size_t root_with(Fbw &w, uint8_t type, size_t &msg_slot) {
+    std::vector<size_t> sl; size_t tp = w.table({{1, type}, {4, 0}}, sl); msg_slot = sl[1]; return tp;
+}
+void write_header(FILE *f, const std::vector<uint64_t> &inst_ids, const std::vector<uint8_t> &inst_vals, uint64_t free_id) {
+    static const uint8_t lm1[32] = {0xec, 0xd3, 0xf5, 0x5c, 0x1a, 0x63, 0x12, 0x58, 0xd6, 0x9c, 0xf7, 0xa2, 0xde, 0xf9, 0xde, 0x14,
+                                    0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0x10};
+    Fbw w; begin_message(w);
+    size_t slot; size_t root = root_with(w, 1, slot);
+    std::vector<size_t> sl; size_t hdr = w.table({{4, 0}, {8, free_id}, {4, 0}}, sl);
+    w.patch(slot, hdr);
+    w.patch(sl[0], w.variables(inst_ids, inst_vals));
+    w.patch(sl[2], w.vec_u8(lm1, 32));
+    finish_message(w, root, f);
+}
+}  // namespace
+
+// column of a zkInterface variable id in Spartan's z = [vars | 1 | inputs]
+struct IdMap {
+    std::map<uint64_t, size_t> inst, wit; size_t num_vars = 0, num_inputs = 0;
+    size_t col(uint64_t id) const {
+        if (id == 0) return num_vars;
+        auto i = inst.find(id); if (i != inst.end()) return num_vars + 1 + i->second;
+        auto w = wit.find(id); if (w != wit.end()) return w->second;
+        throw Error(OTTI_ERR_INVALID_INDEX, "zkif: constraint references an undeclared variable id");
+    }
+};
+
+}  // namespace otti
+
+using namespace otti;
+
+static otti_entry *copy_entries(const std::vector<otti_entry> &v) {
+    otti_entry *p = (otti_entry *)malloc(std::max<size_t>(1, v.size()) * sizeof(otti_entry));
+    if (!v.empty()) memcpy(p, v.data(), v.size() * sizeof(otti_entry));
+    return p;
+}
+static uint8_t *copy_bytes(const std::vector<uint8_t> &v) {
+    uint8_t *p = (uint8_t *)malloc(std::max<size_t>(1, v.size()));
+    if (!v.empty()) memcpy(p, v.data(), v.size());
+    return p;
+}
+
+otti_r1cs *otti_r1cs_from(size_t nc, size_t nv, size_t ni, const std::vector<otti_entry> &A, const std::vector<otti_entry> &B,
+                          const std::vector<otti_entry> &C, const std::vector<uint8_t> &vars, const std::vector<uint8_t> &inputs) {
+    otti_r1cs *r = (otti_r1cs *)calloc(1, sizeof *r);
+    r->num_cons = nc; r->num_vars = nv; r->num_inputs = ni;
+    r->A = copy_entries(A); r->nA = A.size(); r->B = copy_entries(B); r->nB = B.size(); r->C = copy_entries(C); r->nC = C.size();
+    r->vars32 = copy_bytes(vars); r->nvars = vars.size() / 32; r->inputs32 = copy_bytes(inputs); r->ninputs = inputs.size() / 32;
+    return r;
+}
+
+otti_r1cs *zkif_load_impl(const char *circuit_path, const char *inputs_path, const char *witness_path) {
+    Messages m;
+    parse_messages(read_file(circuit_path), m);
+    if (inputs_path) parse_messages(read_file(inputs_path), m);
+    if (witness_path) parse_messages(read_file(witness_path), m);
+    if (!m.have_header) throw Error(OTTI_ERR_IO, "zkif: no CircuitHeader message");
+    if (!m.field_maximum.empty()) {
+        static const uint8_t lm1[32] = {0xec, 0xd3, 0xf5, 0x5c, 0x1a, 0x63, 0x12, 0x58, 0xd6, 0x9c, 0xf7, 0xa2, 0xde, 0xf9, 0xde, 0x14,
+                                        0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0x10};
+        std::vector<uint8_t> fm = m.field_maximum; while (!fm.empty() && fm.back() == 0) fm.pop_back();
+        std::vector<uint8_t> want(lm1, lm1 + 32); while (!want.empty() && want.back() == 0) want.pop_back();
+        if (fm != want) throw Error(OTTI_ERR_IO, "zkif: field_maximum is not l-1 for the curve25519 scalar field");
+    }
+    IdMap map;
+    for (size_t i = 0; i < m.instance.ids.size(); i++) map.inst[m.instance.ids[i]] = i;
+    map.num_inputs = m.instance.ids.size();
+    // witness variables: every id in [1, free_variable_id) that is not an instance variable, in increasing order
+    uint64_t free_id = m.free_variable_id;
+    for (auto id : m.witness.ids) free_id = std::max(free_id, id + 1);
+    size_t k = 0;
+    for (uint64_t id = 1; id < free_id; id++) if (!map.inst.count(id)) map.wit[id] = k++;
+    map.num_vars = k;
+    std::vector<otti_entry> M[3];
+    for (size_t row = 0; row < m.constraints.size(); row++)
+        for (int t = 0; t < 3; t++) {
+            const VarList &lc = m.constraints[row][t];
+            if (!lc.ids.empty() && !lc.has_vals) throw Error(OTTI_ERR_IO, "zkif: linear combination without coefficients");
+            for (size_t i = 0; i < lc.ids.size(); i++) {
+                otti_entry e; e.row = row; e.col = map.col(lc.ids[i]); memcpy(e.val, lc.vals[i].data(), 32);
+                M[t].push_back(e);
+            }
+        }
+    std::vector<uint8_t> vars(32 * map.num_vars, 0), inputs(32 * map.num_inputs, 0);
+    if (m.instance.has_vals) for (size_t i = 0; i < map.num_inputs; i++) memcpy(&inputs[32 * i], m.instance.vals[i].data(), 32);
+    else if (map.num_inputs && inputs_path) throw Error(OTTI_ERR_IO, "zkif: inputs file carries no instance values");
+    if (m.have_witness) {
+        if (m.witness.ids.size() != m.witness.vals.size()) throw Error(OTTI_ERR_IO, "zkif: witness without values");
+        std::vector<bool> seen(map.num_vars, false);
+        for (size_t i = 0; i < m.witness.ids.size(); i++) {
+            auto it = map.wit.find(m.witness.ids[i]);
+            if (it == map.wit.end()) throw Error(OTTI_ERR_INVALID_INDEX, "zkif: witness assigns an instance or unknown variable");
+            memcpy(&vars[32 * it->second], m.witness.vals[i].data(), 32); seen[it->second] = true;
+        }
+        for (bool s : seen) if (!s) throw Error(OTTI_ERR_IO, "zkif: witness does not assign every variable");
+    }
+    return otti_r1cs_from(m.constraints.size(), map.num_vars, map.num_inputs, M[0], M[1], M[2], vars, inputs);
+}
+
+void zkif_write_impl(const otti_r1cs *r, const char *circuit_path, const char *inputs_path, const char *witness_path) {
+    // ids: 0 = one, 1..ni = instance variables, ni+1.. = witness variables
+    const size_t ni = r->num_inputs, nv = r->num_vars;
+    auto id_of_col = [&](uint64_t col) -> uint64_t { return col < nv ? ni + 1 + col : col == nv ? 0 : col - nv; };
+    std::vector<uint64_t> inst_ids(ni); for (size_t i = 0; i < ni; i++) inst_ids[i] = i + 1;
+    uint64_t free_id = ni + nv + 1;
+    FILE *f = fopen(circuit_path, "wb"); if (!f) throw Error(OTTI_ERR_IO, "zkif: cannot create circuit file");
+    try {
+        write_header(f, inst_ids, {}, free_id);
+        // constraints, grouped by row, in chunks of 2^16 rows per ConstraintSystem message
+        const otti_entry *src[3] = {r->A, r->B, r->C}; size_t cnt[3] = {r->nA, r->nB, r->nC};
+        std::vector<std::vector<std::pair<uint64_t, const uint8_t *>>> rows[3];
+        for (int t = 0; t < 3; t++) { rows[t].resize(r->num_cons); for (size_t i = 0; i < cnt[t]; i++) rows[t][src[t][i].row].push_back({id_of_col(src[t][i].col), src[t][i].val}); }
+        const size_t chunk = 1 << 16;
+        for (size_t r0 = 0; r0 < r->num_cons || r0 == 0; r0 += chunk) {
+            size_t r1 = std::min<size_t>(r->num_cons, r0 + chunk);
+            Fbw w; begin_message(w);
+            size_t slot; size_t root = root_with(w, 2, slot);
+            std::vector<size_t> sl; size_t cs = w.table({{4, 0}}, sl); w.patch(slot, cs);
+            w.pad_to(4); size_t vpos = w.b.size(); w.patch(sl[0], vpos);
+            w.u32((uint32_t)(r1 - r0)); size_t elems = w.b.size();
+            for (size_t i = r0; i < r1; i++) w.u32(0);
+            for (size_t i = r0; i < r1; i++) {
+                std::vector<size_t> s3; size_t bc = w.table({{4, 0}, {4, 0}, {4, 0}}, s3);
+                w.patch(elems + 4 * (i - r0), bc);
+                for (int t = 0; t < 3; t++) {
+                    std::vector<uint64_t> ids; std::vector<uint8_t> vals;
+                    for (auto &e : rows[t][i]) { ids.push_back(e.first); vals.insert(vals.end(), e.second, e.second + 32); }
+                    w.patch(s3[t], w.variables(ids, vals));
+                }
+            }
+            finish_message(w, root, f);
+            if (r->num_cons == 0) break;
+        }
+        fclose(f); f = nullptr;
+        f = fopen(inputs_path, "wb"); if (!f) throw Error(OTTI_ERR_IO, "zkif: cannot create inputs file");
+        write_header(f, inst_ids, std::vector<uint8_t>(r->inputs32, r->inputs32 + 32 * ni), free_id);
+        fclose(f); f = nullptr;
+        f = fopen(witness_path, "wb"); if (!f) throw Error(OTTI_ERR_IO, "zkif: cannot create witness file");
+        {
+            Fbw w; begin_message(w);
+            size_t slot; size_t root = root_with(w, 3, slot);
+            std::vector<size_t> sl; size_t wt = w.table({{4, 0}}, sl); w.patch(slot, wt);
+            std::vector<uint64_t> ids(nv); for (size_t i = 0; i < nv; i++) ids[i] = ni + 1 + i;
+            w.patch(sl[0], w.variables(ids, std::vector<uint8_t>(r->vars32, r->vars32 + 32 * nv)));
+            finish_message(w, root, f);
+        }
+        fclose(f); f = nullptr;
+    } catch (...) { if (f) fclose(f); throw; }
+}

@@ -1,0 +1,215 @@
+"""GPU parity tests proper: every HIP kernel and the whole proof, called through the C ABI, against the CPU oracle
+(oracle/, plain C) on the same seeded inputs.  Bit-exact: all arithmetic on this path is integer (GF(l), GF(2^255-19))."""
+import hashlib
+import numpy as np
+import pytest
+
+import otti_amd as oa
+import orc
+
+pytestmark = pytest.mark.gpu
+K = oa.kernels
+
+
+def setup_module(module):
+    assert oa.device_count() >= 1, "no MI355X visible"
+
+
+def eq(a, b):
+    return np.array_equal(np.asarray(a), np.asarray(b))
+
+
+# ------------------------------------------------------------------------------------------------ field ops
+@pytest.mark.parametrize("n", [1, 63, 64, 1000, 1 << 16])
+def test_fr_ops(rng, n):
+    a, b = orc.rand_fr(rng, n), orc.rand_fr(rng, n)
+    xa, xb = orc.fr_to_ints(a), orc.fr_to_ints(b)
+    for op, f in (("mul", lambda x, y: x * y), ("add", lambda x, y: x + y), ("sub", lambda x, y: x - y)):
+        out, _ = K.fr_op(op, a, b)
+        assert orc.fr_to_ints(out) == [f(x, y) % orc.L_ORDER for x, y in zip(xa, xb)], op
+
+
+def test_fr_edge_values():
+    l = orc.L_ORDER
+    vals = [0, 1, 2, l - 1, l - 2, (l - 1) // 2, 2 ** 252, 2 ** 128, 2 ** 32 - 1, 2 ** 64 - 1]
+    a = orc.fr_from_ints([x for x in vals for _ in vals]); b = orc.fr_from_ints([y for _ in vals for y in vals])
+    xa, xb = orc.fr_to_ints(a), orc.fr_to_ints(b)
+    for op, f in (("mul", lambda x, y: x * y), ("add", lambda x, y: x + y), ("sub", lambda x, y: x - y)):
+        out, _ = K.fr_op(op, a, b)
+        assert orc.fr_to_ints(out) == [f(x, y) % l for x, y in zip(xa, xb)]
+
+
+def test_canonical_roundtrip(rng):
+    a = orc.rand_fr(rng, 500)
+    canon = K.to_canonical(a)
+    assert [int.from_bytes(c.tobytes(), "little") for c in canon] == orc.fr_to_ints(a)
+    assert eq(K.from_canonical(canon), a)
+
+
+# ------------------------------------------------------------------------------------------------ K2 eq tables
+@pytest.mark.parametrize("ell", [0, 1, 2, 5, 10, 12, 13, 16])
+def test_eq_evals(rng, ell):
+    r = orc.rand_fr(rng, ell)
+    out, _ = K.eq_evals(r)
+    assert eq(out, orc.eq_evals(r))
+
+
+# ------------------------------------------------------------------------------------------------ K4/K5 folds, K3/K7 round sums
+@pytest.mark.parametrize("n", [2, 4, 8, 1 << 10, 1 << 15])
+def test_fold_top_bot(rng, n):
+    Z, r = orc.rand_fr(rng, n), orc.rand_fr(rng, 1)
+    assert eq(K.fold_top(Z, r)[0], orc.fold_top(Z, r))
+    assert eq(K.fold_bot(Z, r)[0], orc.fold_bot(Z, r))
+
+
+@pytest.mark.parametrize("n", [2, 4, 64, 1 << 10, 1 << 16])
+def test_sumcheck_round_sums(rng, n):
+    A, B, C, D = (orc.rand_fr(rng, n) for _ in range(4))
+    assert eq(K.sc_cubic_round(A, B, C, D)[0], orc.sc_cubic_evals(A, B, C, D))
+    assert eq(K.sc_quad_round(A, B)[0], orc.sc_quad_evals(A, B))
+
+
+@pytest.mark.parametrize("n", [4, 8, 1 << 10, 1 << 16])
+def test_sumcheck_fused_fold_round(rng, n):
+    A, B, C, D = (orc.rand_fr(rng, n) for _ in range(4)); r = orc.rand_fr(rng, 1)
+    fa, fb, fc, fd = (orc.fold_top(x, r) for x in (A, B, C, D))
+    out, e, _ = K.sc_cubic_fold_round(A, B, C, D, r)
+    assert eq(out[0], fa) and eq(out[1], fb) and eq(out[2], fc) and eq(out[3], fd)
+    assert eq(e, orc.sc_cubic_evals(fa, fb, fc, fd))
+    out2, e2, _ = K.sc_quad_fold_round(A, B, r)
+    assert eq(out2[0], fa) and eq(out2[1], fb)
+    assert eq(e2, orc.sc_quad_evals(fa, fb))
+
+
+# ------------------------------------------------------------------------------------------------ K1/K6 sparse products
+def _random_instance(rng, nc, nv, ni, nnz_per_row, heavy_rows=()):
+    """ragged random matrices (not satisfiable — only multiply_vec / eval tables are exercised)"""
+    mats = []
+    for _ in range(3):
+        rows, cols = [], []
+        for r in range(nc):
+            k = int(rng.integers(0, nnz_per_row + 1))
+            if r in heavy_rows:
+                k = 300
+            rows += [r] * k; cols += list(rng.integers(0, nv + 1 + ni, size=k))
+        e = np.zeros(len(rows), dtype=oa.ENTRY_DTYPE)
+        e["row"], e["col"] = rows, cols
+        vals = rng.integers(0, 256, size=(len(rows), 32), dtype=np.uint8); vals[:, 31] &= 0x0f
+        e["val"] = vals
+        mats.append(e)
+    return mats
+
+
+@pytest.mark.parametrize("nc,nv,ni,nnz,heavy", [(8, 8, 2, 3, ()), (1000, 700, 10, 4, (5, 77)), (1 << 12, 1 << 12, 10, 2, (0,))])
+def test_multiply_vec_and_eval_table(rng, nc, nv, ni, nnz, heavy):
+    A, B, C = _random_instance(rng, nc, nv, ni, nnz, heavy)
+    inst, oinst = oa.Instance.new(nc, nv, ni, A, B, C), orc.OInstance(nc, nv, ni, A, B, C)
+    ncp, nvp, _ = inst.dims
+    assert (ncp, nvp) == (oinst.num_cons, oinst.num_vars)
+    z = orc.rand_fr(rng, 2 * nvp)
+    ga, gb, gc, _ = K.multiply_vec(inst, z)
+    oa_, ob_, oc_ = orc.multiply_vec(oinst, z)
+    assert eq(ga, oa_) and eq(gb, ob_) and eq(gc, oc_)
+    eqrx, coef = orc.rand_fr(rng, ncp), orc.rand_fr(rng, 3)
+    got, _ = K.eval_table_sparse(inst, eqrx, coef)
+    eA, eB, eC = (orc.fr_to_ints(x) for x in orc.eval_table_sparse(oinst, eqrx))
+    c = orc.fr_to_ints(coef)
+    want = [(c[0] * a + c[1] * b + c[2] * d) % orc.L_ORDER for a, b, d in zip(eA, eB, eC)]
+    assert orc.fr_to_ints(got) == want
+
+
+# ------------------------------------------------------------------------------------------------ K8 MSM rows (Pedersen commitments)
+@pytest.mark.parametrize("lg", [2, 6, 10])
+def test_msm_rows(rng, lg):
+    nv = 1 << lg
+    gens, ogens = oa.NIZKGens.new(nv, nv, 1), orc.OGens(nv, nv, 1)
+    R = ogens.R; L = nv // R
+    assert eq(gens.points(R + 2), ogens.points())
+    Z, blinds = orc.rand_fr(rng, L * R), orc.rand_fr(rng, L)
+    # scalars with special shapes: zero, one, l-1, small, all-ones digits
+    special = orc.fr_from_ints([0, 1, orc.L_ORDER - 1, 255, 256, 2 ** 252, int("80" * 31, 16)])
+    Z[: min(len(special), L * R)] = special[: min(len(special), L * R)]
+    got, _ = K.msm_rows(gens, Z, L, R, blinds)
+    assert eq(got, orc.commit_rows(ogens, Z, L, R, blinds))
+
+
+# ------------------------------------------------------------------------------------------------ whole proof
+def _prove_both(n, ni, seed=b"\x2a" * 32, label=b"nizk_example"):
+    r = oa.synth_r1cs(n, ni, 1)
+    inst = oa.Instance.new(r["num_cons"], r["num_vars"], r["num_inputs"], r["A"], r["B"], r["C"])
+    gens = oa.NIZKGens.new(r["num_cons"], r["num_vars"], r["num_inputs"])
+    vars_, inputs = oa.VarsAssignment.new(r["vars"]), oa.InputsAssignment.new(r["inputs"])
+    proof = oa.NIZK.prove(inst, vars_, inputs, gens, label, seed)
+    oinst = orc.OInstance(r["num_cons"], r["num_vars"], r["num_inputs"], r["A"], r["B"], r["C"])
+    ogens = orc.OGens(r["num_cons"], r["num_vars"], r["num_inputs"])
+    oproof, _ = orc.nizk_prove(oinst, r["vars"], r["inputs"], ogens, label, seed)
+    return r, inst, gens, inputs, proof, oinst, ogens, oproof
+
+
+@pytest.mark.parametrize("n,ni", [(2, 0), (4, 1), (16, 3), (64, 10), (1 << 10, 10), (1 << 14, 10)])
+def test_proof_bytes_identical_to_oracle(n, ni):
+    r, inst, gens, inputs, proof, oinst, ogens, oproof = _prove_both(n, ni)
+    assert proof.bytes == oproof, f"GPU proof differs from oracle (sha {hashlib.sha256(proof.bytes).hexdigest()[:16]} vs {hashlib.sha256(oproof).hexdigest()[:16]})"
+    proof.verify(inst, inputs, gens)                                        # product verifier accepts
+    assert orc.nizk_verify(oinst, r["inputs"], ogens, proof.bytes) == 0     # oracle verifier accepts the GPU proof
+
+
+def test_proof_nonsquare_and_padded():
+    # num_vars not a power of two, fewer constraints than variables: exercises padding and the column shift of Instance::new
+    r = oa.synth_r1cs(24, 5, 3)
+    nv = 40
+    vars_pad = np.zeros((nv, 32), dtype=np.uint8); vars_pad[:24] = r["vars"]
+    A, B, C = r["A"].copy(), r["B"].copy(), r["C"].copy()
+    for m in (A, B, C):
+        m["col"] = np.where(m["col"] >= 24, m["col"] + (nv - 24), m["col"])
+    inst = oa.Instance.new(24, nv, 5, A, B, C)
+    assert inst.dims == (32, 64, 5)
+    gens = oa.NIZKGens.new(24, nv, 5)
+    v, i = oa.VarsAssignment.new(vars_pad), oa.InputsAssignment.new(r["inputs"])
+    assert inst.is_sat(v, i)
+    proof = oa.NIZK.prove(inst, v, i, gens, b"pad", b"\x07" * 32)
+    proof.verify(inst, i, gens, b"pad")
+    oinst, ogens = orc.OInstance(24, nv, 5, A, B, C), orc.OGens(24, nv, 5)
+    oproof, _ = orc.nizk_prove(oinst, vars_pad, r["inputs"], ogens, b"pad", b"\x07" * 32)
+    assert proof.bytes == oproof
+
+
+def test_resident_witness_and_determinism():
+    r = oa.synth_r1cs(1 << 12, 10, 1)
+    inst = oa.Instance.new(r["num_cons"], r["num_vars"], r["num_inputs"], r["A"], r["B"], r["C"])
+    gens = oa.NIZKGens.new(r["num_cons"], r["num_vars"], r["num_inputs"])
+    v, i = oa.VarsAssignment.new(r["vars"]), oa.InputsAssignment.new(r["inputs"])
+    w = oa.Witness(inst, v, i)
+    p1 = oa.NIZK.prove(inst, w, None, gens, seed=b"\x01" * 32)
+    p2 = oa.NIZK.prove(inst, w, None, gens, seed=b"\x01" * 32)
+    p3 = oa.NIZK.prove(inst, v, i, gens, seed=b"\x01" * 32)
+    assert p1.bytes == p2.bytes == p3.bytes
+    p4 = oa.NIZK.prove(inst, w, None, gens, seed=b"\x02" * 32)
+    assert p4.bytes != p1.bytes
+    p4.verify(inst, i, gens)
+    p5 = oa.NIZK.prove(inst, w, None, gens)       # OS entropy
+    p5.verify(inst, i, gens)
+
+
+def test_tampered_proof_and_wrong_input_rejected():
+    r, inst, gens, inputs, proof, *_ = _prove_both(256, 10)
+    bad = bytearray(proof.bytes); bad[len(bad) // 3] ^= 0x10
+    with pytest.raises(oa.ProofVerifyError):
+        oa.NIZK(bytes(bad)).verify(inst, inputs, gens)
+    wrong = r["inputs"].copy(); wrong[0, 0] ^= 1
+    with pytest.raises(oa.ProofVerifyError):
+        proof.verify(inst, oa.InputsAssignment.new(wrong), gens)
+    with pytest.raises(oa.ProofVerifyError):
+        proof.verify(inst, inputs, gens, b"another label")
+
+
+def test_unsatisfying_witness_yields_rejected_proof():
+    r = oa.synth_r1cs(64, 4, 2)
+    inst = oa.Instance.new(64, 64, 4, r["A"], r["B"], r["C"])
+    gens = oa.NIZKGens.new(64, 64, 4)
+    bad_vars = r["vars"].copy(); bad_vars[3, 0] ^= 1
+    v, i = oa.VarsAssignment.new(bad_vars), oa.InputsAssignment.new(r["inputs"])
+    assert not inst.is_sat(v, i)
+    proof = oa.NIZK.prove(inst, v, i, gens)
+    with pytest.raises(oa.ProofVerifyError):
+        proof.verify(inst, i, gens)

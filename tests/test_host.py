@@ -1,0 +1,180 @@
+"""CPU tests of the product's host side (no compute calls that need a GPU): the C-ABI library loads and exports every symbol
+include/otti_spartan.h declares; Instance::new validation and padding; generator derivation; zkInterface ingest; the product
+verifier against oracle-made proofs; the u64-lane transport used by the multi-GPU sum-check; loud failure without a device."""
+import hashlib
+import json
+import os
+import re
+import subprocess
+import numpy as np
+import pytest
+
+import otti_amd as oa
+import orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = json.load(open(os.path.join(ROOT, "tests", "golden", "primitives.json")))
+L = orc.L_ORDER
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "otti_spartan.h")).read()
+    names = sorted(set(re.findall(r"\b(otti_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(names) >= 35
+    for n in names:
+        assert hasattr(oa.lib, n), f"libottispartan.so does not export {n}"
+    out = subprocess.check_output(["nm", "-D", "--defined-only", oa.lib_path]).decode()
+    exported = set(re.findall(r" T (otti_[a-z0-9_]+)", out))
+    assert set(names) <= exported
+
+
+def test_library_carries_gfx950_code_object_only():
+    blob = open(oa.lib_path, "rb").read()
+    assert b"amdgcn-amd-amdhsa--gfx950" in blob
+    for other in (b"gfx942", b"gfx90a", b"gfx1100", b"sm_90", b"nvptx"):
+        assert other not in blob
+
+
+def test_generators_match_libsodium_fixture():
+    g = oa.NIZKGens.new(1 << 10, 1 << 10, 10)
+    pts = g.points(34)
+    assert [p.tobytes().hex() for p in pts] == GOLD["gens_r1cs_sat"][:34]
+    assert [p.tobytes().hex() for p in pts[:3]] == GOLD["appendix_b"]["gens_first3"]
+
+
+def test_synthetic_instance_is_reproducible_and_satisfiable():
+    r = oa.synth_r1cs(64, 10, 1)
+    assert r["num_cons"] == 64 and r["num_vars"] == 64 and r["num_inputs"] == 10
+    # Z[k] = from_bytes_wide(SHAKE256("otti-synth" || seed_le64 || k_le64, 64))
+    z0 = int.from_bytes(hashlib.shake_256(b"otti-synth" + (1).to_bytes(8, "little") + (0).to_bytes(8, "little")).digest(64), "little") % L
+    assert int.from_bytes(r["vars"][0].tobytes(), "little") == z0
+    zin = int.from_bytes(hashlib.shake_256(b"otti-synth" + (1).to_bytes(8, "little") + (65).to_bytes(8, "little")).digest(64), "little") % L
+    assert int.from_bytes(r["inputs"][0].tobytes(), "little") == zin
+    inst = oa.Instance.new(64, 64, 10, r["A"], r["B"], r["C"])
+    v, i = oa.VarsAssignment.new(r["vars"]), oa.InputsAssignment.new(r["inputs"])
+    assert inst.is_sat(v, i)
+    bad = r["vars"].copy(); bad[1, 0] ^= 1
+    assert not inst.is_sat(oa.VarsAssignment.new(bad), i)
+    assert orc.OInstance(64, 64, 10, r["A"], r["B"], r["C"]).is_sat(r["vars"], r["inputs"])
+
+
+def test_instance_new_padding_and_errors():
+    r = oa.synth_r1cs(5, 2, 4)
+    inst = oa.Instance.new(5, 5, 2, r["A"], r["B"], r["C"])
+    assert inst.dims == (8, 8, 2)
+    one = np.zeros(1, dtype=oa.ENTRY_DTYPE)
+    assert oa.Instance.new(1, 1, 0, one, one[:0], one[:0]).dims == (2, 1, 0)                  # at least two constraints
+    bad = r["A"].copy(); bad["row"][0] = 5
+    with pytest.raises(oa.R1CSError) as e:
+        oa.Instance.new(5, 5, 2, bad, r["B"], r["C"])
+    assert e.value.code == -6
+    bad = r["A"].copy(); bad["col"][0] = 5 + 1 + 2
+    with pytest.raises(oa.R1CSError) as e:
+        oa.Instance.new(5, 5, 2, bad, r["B"], r["C"])
+    assert e.value.code == -6
+    bad = r["A"].copy(); bad["val"][0] = np.frombuffer(L.to_bytes(32, "little"), dtype=np.uint8)
+    with pytest.raises(oa.R1CSError) as e:
+        oa.Instance.new(5, 5, 2, bad, r["B"], r["C"])
+    assert e.value.code == -5
+    with pytest.raises(oa.R1CSError) as e:
+        oa.VarsAssignment.new(np.frombuffer(L.to_bytes(32, "little"), dtype=np.uint8).reshape(1, 32))
+    assert e.value.code == -5
+    oa.VarsAssignment.new(np.frombuffer((L - 1).to_bytes(32, "little"), dtype=np.uint8).reshape(1, 32))
+    v, i = oa.VarsAssignment.new(r["vars"]), oa.InputsAssignment.new(r["inputs"][:1])
+    with pytest.raises(oa.R1CSError) as e:
+        inst.is_sat(v, i)
+    assert e.value.code == -3
+
+
+def test_zkif_write_load_roundtrip(tmp_path):
+    r = oa.synth_r1cs(37, 3, 6)
+    p = [str(tmp_path / n) for n in ("c.zkif", "c.inp.zkif", "c.wit.zkif")]
+    oa.zkif_write(r, *p)
+    assert open(p[0], "rb").read()[8:12] == b"zkif"
+    q = oa.zkif_load(*p)
+    assert (q["num_cons"], q["num_vars"], q["num_inputs"]) == (37, 37, 3)
+    for k in "ABC":
+        a = np.sort(r[k], order=["row", "col"]); b = np.sort(q[k], order=["row", "col"])
+        assert np.array_equal(a["row"], b["row"]) and np.array_equal(a["col"], b["col"]) and np.array_equal(a["val"], b["val"])
+    assert np.array_equal(q["vars"], r["vars"]) and np.array_equal(q["inputs"], r["inputs"])
+    # circuit alone (no assignment files) still gives the matrices
+    q2 = oa.zkif_load(p[0])
+    assert q2["num_cons"] == 37 and q2["A"].size == r["A"].size
+    # truncated / corrupted files are refused, not crashed on
+    blob = open(p[0], "rb").read()
+    open(p[0], "wb").write(blob[: len(blob) // 2])
+    with pytest.raises(oa.SpartanError) as e:
+        oa.zkif_load(*p)
+    assert e.value.code == -22
+    open(p[0], "wb").write(blob[:4] + b"\xff\xff\xff\x7f" + blob[8:])
+    with pytest.raises(oa.SpartanError):
+        oa.zkif_load(*p)
+    with pytest.raises(oa.SpartanError):
+        oa.zkif_load(str(tmp_path / "missing.zkif"))
+
+
+def test_spzk_cli_contract(tmp_path):
+    spzk = os.path.join(ROOT, "otti_amd", "spzk")
+    assert os.path.exists(spzk)
+    out = subprocess.run([spzk, "synth", "16", str(tmp_path / "t"), "2", "5"], capture_output=True, text=True)
+    assert out.returncode == 0 and os.path.exists(tmp_path / "t.wit.zkif")
+    assert subprocess.run([spzk], capture_output=True).returncode == 2
+    assert subprocess.run([spzk, "verify", str(tmp_path / "t.zkif")], capture_output=True).returncode == 2      # --nizk + three files required
+    if oa.device_count() == 0:
+        # reference argv [REF run.py:100]; with no GPU the binary must fail loudly, never fall back
+        res = subprocess.run([spzk, "verify", "--nizk", str(tmp_path / "t.zkif"), str(tmp_path / "t.inp.zkif"), str(tmp_path / "t.wit.zkif")],
+                             capture_output=True, text=True)
+        assert res.returncode != 0 and "Verification successful" not in res.stdout
+
+
+def test_product_verifier_accepts_oracle_proofs_and_rejects_tampering():
+    for n, ni in ((2, 0), (8, 3), (256, 10), (1 << 11, 10)):
+        r = oa.synth_r1cs(n, ni, 1)
+        inst = oa.Instance.new(n, n, ni, r["A"], r["B"], r["C"]); gens = oa.NIZKGens.new(n, n, ni)
+        oi, og = orc.OInstance(n, n, ni, r["A"], r["B"], r["C"]), orc.OGens(n, n, ni)
+        pf, _ = orc.nizk_prove(oi, r["vars"], r["inputs"], og, b"lbl", b"\x11" * 32)
+        inputs = oa.InputsAssignment.new(r["inputs"])
+        oa.NIZK(pf).verify(inst, inputs, gens, b"lbl")
+        with pytest.raises(oa.ProofVerifyError):
+            oa.NIZK(pf).verify(inst, inputs, gens, b"lbx")
+        for pos in (40, len(pf) // 2, len(pf) - 5):
+            bad = bytearray(pf); bad[pos] ^= 2
+            with pytest.raises(oa.ProofVerifyError):
+                oa.NIZK(bytes(bad)).verify(inst, inputs, gens, b"lbl")
+        with pytest.raises(oa.ProofVerifyError) as e:
+            oa.NIZK(pf[:-7]).verify(inst, inputs, gens, b"lbl")
+        assert e.value.code == -12
+
+
+def test_lanes_transport_of_field_sums(rng):
+    # 8 ranks' partial sums, each an Fr in Montgomery form, summed as 8 x u64 lanes and normalised once
+    parts = [orc.rand_fr(rng, 5) for _ in range(8)]
+    lanes = sum(oa.lanes_pack(p).astype(np.uint64) for p in parts)
+    got = orc.fr_to_ints(oa.lanes_unpack(lanes))
+    want = [sum(orc.fr_to_ints(p)[k] for p in parts) % L for k in range(5)]
+    assert got == want
+    # worst case: 2^32 - 1 in every limb, 8 times
+    top = np.full(8, 8 * (2 ** 32 - 1), dtype=np.uint64)
+    assert int.from_bytes(oa.lanes_unpack(top)[0].tobytes(), "little") == (8 * (2 ** 256 - 1)) % L
+
+
+@pytest.mark.skipif(oa.device_count() > 0, reason="only meaningful without a GPU")
+def test_prove_fails_loudly_without_device():
+    r = oa.synth_r1cs(8, 2, 1)
+    inst = oa.Instance.new(8, 8, 2, r["A"], r["B"], r["C"]); gens = oa.NIZKGens.new(8, 8, 2)
+    with pytest.raises(oa.NoDeviceError):
+        oa.NIZK.prove(inst, oa.VarsAssignment.new(r["vars"]), oa.InputsAssignment.new(r["inputs"]), gens)
+    with pytest.raises(oa.NoDeviceError):
+        oa.kernels.eq_evals(orc.rand_fr(np.random.default_rng(0), 3))
+
+
+def test_product_never_links_or_imports_the_oracle():
+    deps = subprocess.check_output(["ldd", oa.lib_path]).decode()
+    assert "liboracle" not in deps
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "otti_amd")):
+        if "build" in dirpath:
+            continue
+        for f in files:
+            if f.endswith((".py", ".cpp", ".h", ".hip")):
+                src = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "liboracle" not in src and "import orc" not in src and "oracle/" not in src.replace("the CPU oracle", ""), f

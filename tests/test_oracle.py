@@ -1,0 +1,191 @@
+"""CPU tests of the oracle itself: it must reproduce every known answer we hold (libsodium / hashlib fixtures in
+tests/golden/primitives.json) before anything is compared against it, and its own prove -> verify round trip must hold.
+(The reference ships no tests or golden vectors for this path: parity with upstream bytes is unpinned, see DESIGN.md.)"""
+import ctypes
+import hashlib
+import json
+import os
+import numpy as np
+import pytest
+
+import orc
+
+G = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "primitives.json")))
+L = orc.L_ORDER
+lib = orc.lib
+
+
+def buf(n=32):
+    return ctypes.create_string_buffer(n)
+
+
+def fr_of(hexstr):
+    b = buf(32); assert lib.fr_from_bytes(b, bytes.fromhex(hexstr)) == 1; return b
+
+
+def fr_hex(b):
+    o = buf(32); lib.fr_to_bytes(o, b); return o.raw.hex()
+
+
+def test_keccak_sha3_shake_against_hashlib():
+    for msg in (b"", b"abc", b"x" * 500, bytes(range(256)) * 3):
+        o = buf(32); lib.sha3_256(o, msg, ctypes.c_size_t(len(msg)))
+        assert o.raw == hashlib.sha3_256(msg).digest()
+
+    class SH(ctypes.Structure):
+        _fields_ = [("st", ctypes.c_uint64 * 25), ("pos", ctypes.c_size_t), ("sq", ctypes.c_int)]
+    s = SH(); lib.shake256_init(ctypes.byref(s)); lib.shake256_absorb(ctypes.byref(s), b"otti", ctypes.c_size_t(4))
+    o = buf(500); lib.shake256_squeeze(ctypes.byref(s), o, ctypes.c_size_t(137)); lib.shake256_squeeze(ctypes.byref(s), ctypes.byref(o, 137), ctypes.c_size_t(363))
+    assert o.raw == hashlib.shake_256(b"otti").digest(500)
+
+
+def test_strobe_and_merlin_known_answers():
+    kb = G["appendix_b"]
+    st = buf(256)
+    lib.strobe_init(st, b"Conformance Test Protocol", ctypes.c_size_t(25))
+    lib.strobe_meta_ad(st, b"ms", ctypes.c_size_t(2), 0); lib.strobe_meta_ad(st, b"g", ctypes.c_size_t(1), 1)
+    lib.strobe_ad(st, b"\x63" * 1024, ctypes.c_size_t(1024), 0)
+    lib.strobe_meta_ad(st, b"prf", ctypes.c_size_t(3), 0); p = buf(32); lib.strobe_prf(st, p, ctypes.c_size_t(32), 0)
+    assert p.raw.hex() == kb["strobe_prf1"]
+    lib.strobe_meta_ad(st, b"key", ctypes.c_size_t(3), 0); lib.strobe_key(st, p.raw, ctypes.c_size_t(32), 0)
+    lib.strobe_meta_ad(st, b"prf", ctypes.c_size_t(3), 0); lib.strobe_prf(st, p, ctypes.c_size_t(32), 0)
+    assert p.raw.hex() == kb["strobe_prf2"]
+    t = buf(256); lib.tr_init(t, b"test protocol", ctypes.c_size_t(13)); lib.tr_append(t, b"some label", b"some data", ctypes.c_size_t(9))
+    c = buf(32); lib.tr_challenge_bytes(t, b"challenge", c, ctypes.c_size_t(32))
+    assert c.raw.hex() == kb["merlin_challenge"]
+
+
+def test_scalar_field_against_python_ints():
+    for v in G["fr"]:
+        x, y, z = fr_of(v["x"]), fr_of(v["y"]), buf(32)
+        lib.fr_mul(z, x, y); assert fr_hex(z) == v["mul"]
+        lib.fr_add(z, x, y); assert fr_hex(z) == v["add"]
+        lib.fr_sub(z, x, y); assert fr_hex(z) == v["sub"]
+        lib.fr_inv(z, x); assert fr_hex(z) == v["inv"]
+        lib.fr_from_bytes_wide(z, bytes.fromhex(v["wide"])); assert fr_hex(z) == v["wide_reduced"]
+    z = buf(32); lib.fr_from_bytes_wide(z, bytes(range(64))); assert fr_hex(z) == G["appendix_b"]["wide_00_3f"]
+    assert lib.fr_from_bytes(z, L.to_bytes(32, "little")) == 0             # l itself is not canonical
+    assert lib.fr_from_bytes(z, (L - 1).to_bytes(32, "little")) == 1
+    assert lib.fr_from_bytes(z, b"\xff" * 32) == 0
+
+
+def test_ristretto_against_libsodium_vectors():
+    kb = G["appendix_b"]
+    g, enc = buf(160), buf(32)
+    assert lib.ge_decode(g, bytes.fromhex(kb["basepoint"])) == 1
+    g2 = buf(160); lib.ge_dbl(g2, g); lib.ge_encode(enc, g2); assert enc.raw.hex() == kb["basepoint_x2"]
+    h = hashlib.sha512(b"Ristretto is traditionally a short shot of espresso coffee").digest()
+    lib.ge_from_uniform_bytes(g2, h); lib.ge_encode(enc, g2); assert enc.raw.hex() == kb["espresso_map"]
+    for v in G["from_uniform_bytes"]:
+        lib.ge_from_uniform_bytes(g, bytes.fromhex(v["in"])); lib.ge_encode(enc, g); assert enc.raw.hex() == v["out"]
+        assert lib.ge_decode(g2, bytes.fromhex(v["out"])) == 1; lib.ge_encode(enc, g2); assert enc.raw.hex() == v["out"]
+    for v in G["scalarmul"]:
+        assert lib.ge_decode(g, bytes.fromhex(v["point"])) == 1
+        lib.ge_scalarmul(g2, g, fr_of(v["scalar"])); lib.ge_encode(enc, g2); assert enc.raw.hex() == v["out"]
+    for v in G["point_add"]:
+        a, b = buf(160), buf(160)
+        assert lib.ge_decode(a, bytes.fromhex(v["a"])) == 1 and lib.ge_decode(b, bytes.fromhex(v["b"])) == 1
+        lib.ge_add(g2, a, b); lib.ge_encode(enc, g2); assert enc.raw.hex() == v["out"]
+    # invalid encodings (RFC 9496 A.3): non-canonical field element, negative s
+    for bad in ("00ffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffff", "0100000000000000000000000000000000000000000000000000000000000000",
+                "edffffffffffffffffffffffffffffffffffffffffffffffffffffffffffff7f"):
+        assert lib.ge_decode(g, bytes.fromhex(bad)) == 0
+
+
+def test_generator_stream_and_pedersen_commitments():
+    og = orc.OGens(1 << 10, 1 << 10, 10)          # R = 32 generators + gens_1 + h
+    pts = og.points()
+    want = G["gens_r1cs_sat"]
+    assert [p.tobytes().hex() for p in pts] == want[: og.R + 2]
+    assert want[:3] == G["appendix_b"]["gens_first3"]
+    # Pedersen vectors: commit(xs, blind) over MultiCommitGens(n): G = stream[0..n), h = stream[n]
+    for v in G["pedersen"]:
+        n = v["n"]
+        pts_raw = (ctypes.c_char * (160 * (n + 1)))()
+        for k in range(n + 1):
+            assert lib.ge_decode(ctypes.byref(pts_raw, 160 * k), bytes.fromhex(want[k])) == 1
+        sc = (ctypes.c_char * (32 * (n + 1)))()
+        for k, s in enumerate(v["scalars"] + [v["blind"]]):
+            ctypes.memmove(ctypes.byref(sc, 32 * k), fr_of(s), 32)
+        out, enc = buf(160), buf(32)
+        lib.ge_msm(out, sc, pts_raw, ctypes.c_size_t(n + 1)); lib.ge_encode(enc, out)
+        assert enc.raw.hex() == v["out"]
+
+
+def test_pedersen_kat_from_survey():
+    # gens from label "kat-msm" (n=4 -> 5 points), x_i = SHA-256(byte i) mod l, blind = SHA-256("blind") mod l
+    base = bytes.fromhex(G["appendix_b"]["basepoint"])
+    stream = hashlib.shake_256(b"kat-msm" + base).digest(64 * 5)
+    pts = (ctypes.c_char * (160 * 5))(); sc = (ctypes.c_char * (32 * 5))()
+    for k in range(5):
+        lib.ge_from_uniform_bytes(ctypes.byref(pts, 160 * k), stream[64 * k: 64 * k + 64])
+    xs = [int.from_bytes(hashlib.sha256(bytes([i])).digest(), "little") % L for i in range(4)] + [int.from_bytes(hashlib.sha256(b"blind").digest(), "little") % L]
+    for k, x in enumerate(xs):
+        ctypes.memmove(ctypes.byref(sc, 32 * k), fr_of(x.to_bytes(32, "little").hex()), 32)
+    out, enc = buf(160), buf(32)
+    lib.ge_msm(out, sc, pts, ctypes.c_size_t(5)); lib.ge_encode(enc, out)
+    assert enc.raw.hex() == G["appendix_b"]["pedersen_kat_msm"]
+
+
+def test_eq_table_order_matches_upstream_definition(rng):
+    # evals()[1] = (1 - r0) * r1 for two variables (MSB-first index order), SURVEY App. B
+    r = orc.rand_fr(rng, 2); a, b = orc.fr_to_ints(r)
+    ev = orc.fr_to_ints(orc.eq_evals(r))
+    assert ev == [(1 - a) * (1 - b) % L, (1 - a) * b % L, a * (1 - b) % L, a * b % L]
+    r5 = orc.rand_fr(rng, 5); x = orc.fr_to_ints(r5); ev = orc.fr_to_ints(orc.eq_evals(r5))
+    for i in (0, 7, 19, 31):
+        want = 1
+        for j in range(5):
+            bit = (i >> (4 - j)) & 1
+            want = want * (x[j] if bit else 1 - x[j]) % L
+        assert ev[i] == want
+
+
+def test_kernel_restatements_against_python_ints(rng):
+    n = 16
+    A, B, C, D = (orc.rand_fr(rng, n) for _ in range(4)); r = orc.rand_fr(rng, 1)
+    a, b, c, d = (orc.fr_to_ints(x) for x in (A, B, C, D)); rr = orc.fr_to_ints(r)[0]
+    h = n // 2
+    assert orc.fr_to_ints(orc.fold_top(A, r)) == [(a[i] + rr * (a[i + h] - a[i])) % L for i in range(h)]
+    assert orc.fr_to_ints(orc.fold_bot(A, r)) == [(a[2 * i] + rr * (a[2 * i + 1] - a[2 * i])) % L for i in range(h)]
+    def at(x, i, t): return (x[i] + t * (x[i + h] - x[i])) % L
+    want = [sum(at(a, i, t) * (at(b, i, t) * at(c, i, t) - at(d, i, t)) for i in range(h)) % L for t in (0, 2, 3)]
+    assert orc.fr_to_ints(orc.sc_cubic_evals(A, B, C, D)) == want
+    assert orc.fr_to_ints(orc.sc_quad_evals(A, B)) == [sum(at(a, i, t) * at(b, i, t) for i in range(h)) % L for t in (0, 2)]
+
+
+@pytest.mark.parametrize("threads", [1, 4])
+def test_oracle_prove_verify_roundtrip_and_golden_digests(threads):
+    import otti_amd as oa
+    golden = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "proofs.json")))
+    orc.set_threads(threads)
+    try:
+        for g in golden:
+            if g["n"] > (1 << 12):
+                continue
+            r = oa.synth_r1cs(g["n"], g["num_inputs"], g["instance_seed"])
+            assert hashlib.sha256(r["vars"].tobytes() + r["inputs"].tobytes()).hexdigest() == g["witness_sha256"]
+            assert hashlib.sha256(r["A"].tobytes() + r["B"].tobytes() + r["C"].tobytes()).hexdigest() == g["matrices_sha256"]
+            oi = orc.OInstance(r["num_cons"], r["num_vars"], r["num_inputs"], r["A"], r["B"], r["C"])
+            og = orc.OGens(r["num_cons"], r["num_vars"], r["num_inputs"])
+            assert oi.is_sat(r["vars"], r["inputs"])
+            pf, _ = orc.nizk_prove(oi, r["vars"], r["inputs"], og, g["label"].encode(), bytes.fromhex(g["tape_seed"]))
+            assert len(pf) == g["proof_len"] and hashlib.sha256(pf).hexdigest() == g["proof_sha256"]
+            assert orc.nizk_verify(oi, r["inputs"], og, pf) == 0
+            bad = bytearray(pf); bad[len(bad) // 2] ^= 1
+            assert orc.nizk_verify(oi, r["inputs"], og, bytes(bad)) != 0
+            if g["num_inputs"]:
+                wrong = r["inputs"].copy(); wrong[0, 0] ^= 1
+                assert orc.nizk_verify(oi, wrong, og, pf) != 0
+    finally:
+        orc.set_threads(1)
+
+
+def test_oracle_rejects_unsatisfied_instance():
+    import otti_amd as oa
+    r = oa.synth_r1cs(32, 4, 9)
+    oi, og = orc.OInstance(32, 32, 4, r["A"], r["B"], r["C"]), orc.OGens(32, 32, 4)
+    v = r["vars"].copy(); v[5, 0] ^= 1
+    assert not oi.is_sat(v, r["inputs"])
+    pf, _ = orc.nizk_prove(oi, v, r["inputs"], og)
+    assert orc.nizk_verify(oi, r["inputs"], og, pf) != 0
