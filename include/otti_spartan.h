@@ -135,6 +135,11 @@ int32_t otti_k_sc_quad_fold_round(const uint8_t *h_A, const uint8_t *h_B, size_t
 /* DensePolynomial::commit_inner: L rows of R scalars -> L compressed points C_i = sum_j Z[iR+j] P[j] + blinds[i] P[R+1] */
 int32_t otti_k_msm_rows(otti_gens *gens, const uint8_t *h_Z, size_t L, size_t R, const uint8_t *h_blinds, uint8_t *h_out32, float *kernel_ms);
 
+/* per-kernel-class timing with HIP events recorded on the library's own stream around every launch of that class.
+   classes: msm_rows msm_finish sc_cubic sc_quad spmv eq reduce poly_bound bullet other.  enable(1) also resets the counters. */
+int32_t otti_stats_enable(int32_t on);
+int32_t otti_stats_read(const char *kernel_class, uint64_t *count, double *total_ms);
+
 /* ---- multi-GPU plumbing: sum-check partial sums travel as 8 x u32 limbs widened to u64 lanes so that a plain integer
         sum all-reduce (RCCL ncclSum/ncclUint64, or gloo in CPU tests) followed by one normalisation gives the Fr sum ---- */
 void    otti_lanes_pack(const uint8_t *fr_mont32, size_t n, uint64_t *lanes /* 8n */);

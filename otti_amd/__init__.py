@@ -9,5 +9,5 @@ from .api import (  # noqa: F401
     ENTRY_DTYPE, SpartanError, R1CSError, ProofVerifyError, NoDeviceError,
     Instance, VarsAssignment, InputsAssignment, NIZKGens, NIZK, Witness,
     synth_r1cs, zkif_load, zkif_write, device_count, lib, lib_path,
-    fr_from_ints, fr_to_ints, kernels, lanes_pack, lanes_unpack, L_ORDER,
+    fr_from_ints, fr_to_ints, kernels, lanes_pack, lanes_unpack, L_ORDER, stats_enable, stats_read, KERNEL_CLASSES,
 )

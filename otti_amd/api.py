@@ -81,6 +81,8 @@ _sig("otti_zkif_load", _i32, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, 
 _sig("otti_zkif_write", _i32, ctypes.POINTER(_R1CS), ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p)
 _sig("otti_r1cs_free", None, ctypes.POINTER(_R1CS))
 _sig("otti_synth_r1cs", _i32, _u64, _u64, _u64, ctypes.POINTER(ctypes.POINTER(_R1CS)))
+_sig("otti_stats_enable", _i32, _i32)
+_sig("otti_stats_read", _i32, ctypes.c_char_p, ctypes.POINTER(_u64), ctypes.POINTER(ctypes.c_double))
 _sig("otti_lanes_pack", None, _vp, _sz, _vp)
 _sig("otti_lanes_unpack", None, _vp, _sz, _vp)
 _fp = ctypes.POINTER(ctypes.c_float)
@@ -346,6 +348,23 @@ def fr_from_ints(xs):
 def fr_to_ints(a):
     a = _scalars(a, "fr")
     return [int.from_bytes(a[k].tobytes(), "little") * _RINV % L_ORDER for k in range(a.shape[0])]
+
+
+KERNEL_CLASSES = ("msm_rows", "msm_finish", "sc_cubic", "sc_quad", "spmv", "eq", "reduce", "poly_bound", "bullet", "other")
+
+
+def stats_enable(on=True):
+    _check(lib.otti_stats_enable(1 if on else 0))
+
+
+def stats_read():
+    """{class: (launch count, total ms)} measured with HIP events on the library's stream"""
+    out = {}
+    for k in KERNEL_CLASSES:
+        n, ms = _u64(), ctypes.c_double()
+        _check(lib.otti_stats_read(k.encode(), ctypes.byref(n), ctypes.byref(ms)))
+        out[k] = (n.value, ms.value)
+    return out
 
 
 def lanes_pack(fr_mont):

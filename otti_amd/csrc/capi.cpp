@@ -267,6 +267,18 @@ int32_t otti_k_msm_rows(otti_gens *gens, const uint8_t *Z, size_t L, size_t R, c
     });
 }
 
+// ------------------------------------------------------------------------------------------------ kernel timing (HIP events on the library stream)
+static const char *kClassNames[KC_COUNT] = {"msm_rows", "msm_finish", "sc_cubic", "sc_quad", "spmv", "eq", "reduce", "poly_bound", "bullet", "other"};
+int32_t otti_stats_enable(int32_t on) { KStats::get().on = on != 0; KStats::get().reset(); return OTTI_OK; }
+int32_t otti_stats_read(const char *kernel_class, uint64_t *count, double *total_ms) {
+    return guarded([&] {
+        KStats &s = KStats::get();
+        if (s.used) { DevCtx::get().sync(); s.flush(); }
+        for (int k = 0; k < KC_COUNT; k++) if (!strcmp(kernel_class, kClassNames[k])) { if (count) *count = s.count[k]; if (total_ms) *total_ms = s.total_ms[k]; return OTTI_OK; }
+        throw Error(OTTI_ERR_BAD_ARG, "unknown kernel class");
+    });
+}
+
 // ------------------------------------------------------------------------------------------------ u64-lane transport of Fr sums
 void otti_lanes_pack(const uint8_t *fr, size_t n, uint64_t *lanes) {
     for (size_t i = 0; i < n; i++) for (int k = 0; k < 8; k++) { uint32_t w; memcpy(&w, fr + 32 * i + 4 * k, 4); lanes[8 * i + k] = w; }

@@ -45,16 +45,33 @@ struct DevCtx {
     DevBuf<Fr> partials;                                      // [kMaxBlocks][4] per-block partial sums
     DevBuf<Fr> results;                                       // small device result slots
     Fr *h_results = nullptr;                                  // pinned mirror of `results`
-    DevBuf<Pt> msm_partial;                                   // [rows][splits]
+    DevBuf<Pt> msm_partial, msm_final;                        // [rows][chunks] partial sums, [rows] row sums
+    Pt *h_pts = nullptr; size_t pending_host_encode = 0;      // pinned: row sums of small launches, compressed on the host in sync()
     uint8_t *h_points = nullptr;                              // pinned: compressed points coming back
     DevBuf<uint8_t> d_points;
     size_t msm_partial_cap = 0, points_cap = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     static DevCtx &get();                                     // throws Error(OTTI_ERR_NO_DEVICE) when no device is usable
-    void sync() { OTTI_HIP(hipStreamSynchronize(stream)); }
+    void sync();
     void ensure_points(size_t rows, size_t splits);
 };
 constexpr int kResultSlots = 64;
+constexpr size_t kHostEncodeRows = 8;
+constexpr size_t kHostPtsCap = 512;
+
+// per-kernel-class HIP-event timing on the library's own stream (bench.py's roofline numbers come from here)
+enum KClass { KC_MSM_ROWS = 0, KC_MSM_FINISH, KC_SC_CUBIC, KC_SC_QUAD, KC_SPMV, KC_EQ, KC_REDUCE, KC_BOUND, KC_BULLET, KC_OTHER, KC_COUNT };
+struct KStats {
+    bool on = false;
+    std::vector<hipEvent_t> pool; std::vector<int> cls; size_t used = 0;
+    double total_ms[KC_COUNT] = {0}; unsigned long long count[KC_COUNT] = {0};
+    static KStats &get();
+    int begin(DevCtx &c, int k);                              // returns record index or -1
+    void end(DevCtx &c, int rec);
+    void flush();                                             // stream must be idle
+    void reset();
+};
+struct KScope { DevCtx &c; int rec; KScope(DevCtx &c_, int k) : c(c_), rec(KStats::get().begin(c_, k)) {} ~KScope() { KStats::get().end(c, rec); } };
 
 // witness resident in HBM: z = vars || 1 || inputs || 0..  (2 * num_vars Montgomery-form elements)
 struct DeviceWitness {
@@ -88,7 +105,8 @@ void dev_fetch(DevCtx &c, const Fr *src, int slot, size_t n);              // as
 // ---- K8: fixed-base MSM rows.  Row i: sum_j dense[i*stride + j] * P[j] (j < n_dense) + sum_e extra_s[i*n_extra+e] * P[extra_base[e]]
 // Compressed results land in c.h_points[32*i ..] after c.sync(); they also stay in c.d_points.
 void dev_msm_rows(DevCtx &c, const DeviceGens &g, const Fr *dense, size_t stride, size_t n_dense, size_t rows, const Fr *extra_s,
-                  const uint32_t *extra_base_host, size_t n_extra);
+                  const uint32_t *extra_base_host, size_t n_extra, bool raw_points = false);
+// raw_points: skip compression; after c.sync() the extended row sums are in c.h_pts[0..rows)
 // ---- K9: LZ[j] = sum_i Lv[i] * Z[i*R + j]
 void dev_poly_bound(DevCtx &c, const Fr *Z, size_t L, size_t R, const Fr *Lv, Fr *out, Fr *scratch /* >= 64*R */);
 // dot product of two device vectors -> h_results[slot]

@@ -77,32 +77,54 @@ HD Fr fr_dbl(const Fr &a) { return fr_add(a, a); }
 HD bool fr_eq(const Fr &a, const Fr &b) { uint32_t d = 0; for (int i = 0; i < 8; i++) d |= a.v[i] ^ b.v[i]; return d == 0; }
 HD bool fr_is_zero(const Fr &a) { uint32_t d = 0; for (int i = 0; i < 8; i++) d |= a.v[i]; return d == 0; }
 
+// ------------------------------------------------------------------------------------------------ gfx950 multiply-accumulate
+#if defined(__HIP_DEVICE_COMPILE__)
+// 96-bit column accumulator (lohi: low 64 bits, ex: carries) += x * y.  v_mad_u64_u32 leaves the carry-out of its 64-bit add in
+// VCC; v_addc_co_u32 folds it into the third word: two VALU instructions per 32x32 partial product, no 64-bit adds, no moves.
+__device__ __forceinline__ void mac96(uint64_t &lohi, uint32_t &ex, uint32_t x, uint32_t y) {
+    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32_e32 %1, vcc, 0, %1, vcc" : "+v"(lohi), "+v"(ex) : "v"(x), "v"(y) : "vcc");
+}
+// same with a wave-uniform multiplier kept in an SGPR (modulus limbs, 38)
+__device__ __forceinline__ void mac96s(uint64_t &lohi, uint32_t &ex, uint32_t x, uint32_t y_uniform) {
+    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32_e32 %1, vcc, 0, %1, vcc" : "+v"(lohi), "+v"(ex) : "v"(x), "s"(y_uniform) : "vcc");
+}
+// next column: drop the finished low word
+__device__ __forceinline__ uint32_t col_shift(uint64_t &lohi, uint32_t &ex) {
+    uint32_t out = (uint32_t)lohi;
+    lohi = (lohi >> 32) | ((uint64_t)ex << 32); ex = 0;
+    return out;
+}
+#endif
+
 // ------------------------------------------------------------------------------------------------ Fr Montgomery multiply
 // Device: CIOS over 8 u32 limbs (l has limbs 4..6 == 0 and limb 7 == 2^28, so a reduction row needs 4 real multiplies).
 // Host: the same recurrence over 4 u64 limbs.
 HD Fr fr_mul(const Fr &a, const Fr &b) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    uint32_t t[10];
+    // product scanning with the Montgomery reduction interleaved column by column (FIPS): column k collects a_i*b_(k-i) and
+    // m_i*l_(k-i); m_k makes the column's low word vanish.  l has limbs 4..6 == 0 and limb 7 == 2^28.
+    const uint32_t Lk[8] = {OTTI_L0, OTTI_L1, OTTI_L2, OTTI_L3, 0u, 0u, 0u, OTTI_L7};
+    uint32_t m[8], t[9];
+    uint64_t acc = 0; uint32_t ex = 0;
 #pragma unroll
-    for (int i = 0; i < 10; i++) t[i] = 0;
+    for (int k = 0; k < 8; k++) {
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        uint64_t c = 0;
+        for (int i = 0; i <= k; i++) mac96(acc, ex, a.v[i], b.v[k - i]);
 #pragma unroll
-        for (int j = 0; j < 8; j++) { c += (uint64_t)a.v[j] * b.v[i] + t[j]; t[j] = (uint32_t)c; c >>= 32; }
-        c += t[8]; t[8] = (uint32_t)c; t[9] = (uint32_t)(c >> 32);
-        uint32_t m = t[0] * OTTI_LINV32;
-        c = (uint64_t)m * OTTI_L0 + t[0]; c >>= 32;
-        c += (uint64_t)m * OTTI_L1 + t[1]; t[0] = (uint32_t)c; c >>= 32;
-        c += (uint64_t)m * OTTI_L2 + t[2]; t[1] = (uint32_t)c; c >>= 32;
-        c += (uint64_t)m * OTTI_L3 + t[3]; t[2] = (uint32_t)c; c >>= 32;
-        c += t[4]; t[3] = (uint32_t)c; c >>= 32;
-        c += t[5]; t[4] = (uint32_t)c; c >>= 32;
-        c += t[6]; t[5] = (uint32_t)c; c >>= 32;
-        c += ((uint64_t)m << 28) + t[7]; t[6] = (uint32_t)c; c >>= 32;
-        c += t[8]; t[7] = (uint32_t)c; c >>= 32;
-        t[8] = t[9] + (uint32_t)c;
+        for (int i = 0; i < k; i++) if (Lk[k - i] != 0u) mac96s(acc, ex, m[i], Lk[k - i]);
+        m[k] = (uint32_t)acc * OTTI_LINV32;
+        mac96s(acc, ex, m[k], OTTI_L0);
+        (void)col_shift(acc, ex);
     }
+#pragma unroll
+    for (int k = 8; k < 16; k++) {
+#pragma unroll
+        for (int i = k - 7; i < 8; i++) mac96(acc, ex, a.v[i], b.v[k - i]);
+#pragma unroll
+        for (int i = k - 7; i < 8; i++) if (Lk[k - i] != 0u) mac96s(acc, ex, m[i], Lk[k - i]);
+        t[k - 8] = col_shift(acc, ex);
+    }
+    t[8] = (uint32_t)acc;
     return fr_cond_sub_l(t, t[8]);
 #else
     typedef unsigned __int128 u128;
@@ -199,10 +221,10 @@ HD Fp fp_sub(const Fp &a, const Fp &b) {
 HD Fp fp_neg(const Fp &a) { return fp_sub(fp_zero(), a); }
 
 HD Fp fp_reduce512(const uint32_t t[16]) {
-    // r = lo + 38*hi, then fold the (<= 38) top word twice
+    // r = lo + 38*hi (two multiply-adds per limb, sums stay below 2^64), then fold the (<= 38) top word twice
     Fp r; uint64_t c = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) { c += (uint64_t)t[8 + i] * 38u + t[i]; r.v[i] = (uint32_t)c; c >>= 32; }
+    for (int i = 0; i < 8; i++) { c += (uint64_t)t[8 + i] * 38u; c += t[i]; r.v[i] = (uint32_t)c; c >>= 32; }
     c *= 38;
 #pragma unroll
     for (int i = 0; i < 8; i++) { c += r.v[i]; r.v[i] = (uint32_t)c; c >>= 32; }
@@ -212,15 +234,14 @@ HD Fp fp_reduce512(const uint32_t t[16]) {
 HD Fp fp_mul(const Fp &a, const Fp &b) {
 #if defined(__HIP_DEVICE_COMPILE__)
     uint32_t t[16];
+    uint64_t acc = 0; uint32_t ex = 0;
 #pragma unroll
-    for (int i = 0; i < 16; i++) t[i] = 0;
+    for (int k = 0; k < 15; k++) {
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        uint64_t c = 0;
-#pragma unroll
-        for (int j = 0; j < 8; j++) { c += (uint64_t)a.v[j] * b.v[i] + t[i + j]; t[i + j] = (uint32_t)c; c >>= 32; }
-        t[i + 8] = (uint32_t)c;
+        for (int i = (k < 8 ? 0 : k - 7); i <= (k < 8 ? k : 7); i++) mac96(acc, ex, a.v[i], b.v[k - i]);
+        t[k] = col_shift(acc, ex);
     }
+    t[15] = (uint32_t)acc;
     return fp_reduce512(t);
 #else
     typedef unsigned __int128 u128;

@@ -67,9 +67,31 @@ void DevCtx::ensure_points(size_t rows, size_t splits) {
     if (rows > points_cap) {
         if (h_points) (void)hipHostFree(h_points);
         OTTI_HIP(hipHostMalloc((void **)&h_points, rows * 32, hipHostMallocDefault));
-        d_points.alloc(rows * 32); points_cap = rows;
+        d_points.alloc(rows * 32); msm_final.alloc(rows); points_cap = rows;
     }
+    if (!h_pts) OTTI_HIP(hipHostMalloc((void **)&h_pts, kHostPtsCap * sizeof(Pt), hipHostMallocDefault));
 }
+
+// ------------------------------------------------------------------------------------------------ kernel timing
+KStats &KStats::get() { static KStats s; return s; }
+int KStats::begin(DevCtx &c, int k) {
+    if (!on) return -1;
+    if (pool.empty()) { pool.resize(16384); for (auto &e : pool) OTTI_HIP(hipEventCreate(&e)); cls.resize(8192); }
+    if (used + 1 > cls.size()) return -1;                     // pool exhausted until the next flush
+    int rec = (int)used++;
+    cls[rec] = k;
+    OTTI_HIP(hipEventRecord(pool[2 * rec], c.stream));
+    return rec;
+}
+void KStats::end(DevCtx &c, int rec) { if (rec >= 0) (void)hipEventRecord(pool[2 * rec + 1], c.stream); }
+void KStats::flush() {
+    for (size_t r = 0; r < used; r++) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, pool[2 * r], pool[2 * r + 1]) == hipSuccess) { total_ms[cls[r]] += ms; count[cls[r]]++; }
+    }
+    used = 0;
+}
+void KStats::reset() { used = 0; for (int k = 0; k < KC_COUNT; k++) { total_ms[k] = 0; count[k] = 0; } }
 
 // ------------------------------------------------------------------------------------------------ wave / block reductions of Fr
 __device__ __forceinline__ Fr shfl_xor_fr(const Fr &x, int mask) {
@@ -157,6 +179,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv3_heavy(DCsr3 m, const uint32_t 
 void dev_spmv3(DevCtx &c, const DeviceCsrSet &m, const Fr *x, Fr *o0, Fr *o1, Fr *o2, bool combine, const Fr coef[3]) {
     Fr z = fr_zero();
     Fr c0 = coef ? coef[0] : z, c1 = coef ? coef[1] : z, c2 = coef ? coef[2] : z;
+    KScope ks(c, KC_SPMV);
     hipLaunchKernelGGL(k_spmv3_light, grid_for(m.rows), kBlock, 0, c.stream, m.view(), m.rows, x, o0, o1, o2, (int)combine, c0, c1, c2);
     if (m.n_heavy) hipLaunchKernelGGL(k_spmv3_heavy, (int)m.n_heavy, kBlock, 0, c.stream, m.view(), m.heavy.p, x, o0, o1, o2, (int)combine, c0, c1, c2);
 }
@@ -215,6 +238,7 @@ void dev_eq_evals(DevCtx &c, const Fr *r, size_t ell, Fr *out, Fr *scratch) {
         FrArgs a; for (int i = 0; i < 13; i++) a.v[i] = i < e ? rr[i] : fr_zero();
         hipLaunchKernelGGL(k_eq_small, 1, 1024, 0, c.stream, a, e, dst, tmp);
     };
+    KScope ks(c, KC_EQ);
     if (ell <= 12) { small(r, (int)ell, out, scratch); return; }
     int lo_bits = 12, hi_bits = (int)ell - 12;
     if (hi_bits > 12) throw Error(OTTI_ERR_BAD_ARG, "eq table larger than 2^24");
@@ -292,29 +316,29 @@ __global__ __launch_bounds__(kBlock) void k_fold_bot(const Fr *Z, Fr *out, size_
     }
 }
 template <int K> static void finish_round(DevCtx &c, int nblocks, int slot) {
-    hipLaunchKernelGGL(k_reduce_partials<K>, 1, kBlock, 0, c.stream, (const Fr *)c.partials.p, nblocks, c.results.p + slot);
+    { KScope ks(c, KC_REDUCE); hipLaunchKernelGGL(k_reduce_partials<K>, 1, kBlock, 0, c.stream, (const Fr *)c.partials.p, nblocks, c.results.p + slot); }
     dev_fetch(c, c.results.p + slot, slot, K);
 }
 void dev_sc_cubic_eval(DevCtx &c, const Fr *A, const Fr *B, const Fr *C, const Fr *D, size_t len, int slot) {
     size_t half = len / 2; int g = grid_for(half);
-    hipLaunchKernelGGL(k_sc_cubic_eval, g, kBlock, 0, c.stream, A, B, C, D, half, c.partials.p);
+    { KScope ks(c, KC_SC_CUBIC); hipLaunchKernelGGL(k_sc_cubic_eval, g, kBlock, 0, c.stream, A, B, C, D, half, c.partials.p); }
     finish_round<3>(c, g, slot);
 }
 void dev_sc_cubic_fold_eval(DevCtx &c, Fr *A, Fr *B, Fr *C, Fr *D, size_t len, const Fr &r, int slot) {
     if (len < 4) throw Error(OTTI_ERR_INTERNAL, "fold_eval needs len >= 4");
     size_t q = len / 4; int g = grid_for(q);
-    hipLaunchKernelGGL(k_sc_cubic_fold_eval, g, kBlock, 0, c.stream, A, B, C, D, q, r, c.partials.p);
+    { KScope ks(c, KC_SC_CUBIC); hipLaunchKernelGGL(k_sc_cubic_fold_eval, g, kBlock, 0, c.stream, A, B, C, D, q, r, c.partials.p); }
     finish_round<3>(c, g, slot);
 }
 void dev_sc_quad_eval(DevCtx &c, const Fr *A, const Fr *B, size_t len, int slot) {
     size_t half = len / 2; int g = grid_for(half);
-    hipLaunchKernelGGL(k_sc_quad_eval, g, kBlock, 0, c.stream, A, B, half, c.partials.p);
+    { KScope ks(c, KC_SC_QUAD); hipLaunchKernelGGL(k_sc_quad_eval, g, kBlock, 0, c.stream, A, B, half, c.partials.p); }
     finish_round<2>(c, g, slot);
 }
 void dev_sc_quad_fold_eval(DevCtx &c, Fr *A, Fr *B, size_t len, const Fr &r, int slot) {
     if (len < 4) throw Error(OTTI_ERR_INTERNAL, "fold_eval needs len >= 4");
     size_t q = len / 4; int g = grid_for(q);
-    hipLaunchKernelGGL(k_sc_quad_fold_eval, g, kBlock, 0, c.stream, A, B, q, r, c.partials.p);
+    { KScope ks(c, KC_SC_QUAD); hipLaunchKernelGGL(k_sc_quad_fold_eval, g, kBlock, 0, c.stream, A, B, q, r, c.partials.p); }
     finish_round<2>(c, g, slot);
 }
 void dev_fold_top(DevCtx &c, Fr *Z, size_t len, const Fr &r) { size_t h = len / 2; if (h) hipLaunchKernelGGL(k_fold_top, grid_for(h), kBlock, 0, c.stream, Z, h, r); }
@@ -349,66 +373,143 @@ __global__ __launch_bounds__(kBlock) void k_colsum(const Fr *scratch, size_t sla
 }
 void dev_poly_bound(DevCtx &c, const Fr *Z, size_t L, size_t R, const Fr *Lv, Fr *out, Fr *scratch) {
     size_t slabs = std::min<size_t>(L, 64), rps = (L + slabs - 1) / slabs;
+    KScope ks(c, KC_BOUND);
     dim3 grid((unsigned)((R + kBlock - 1) / kBlock), (unsigned)slabs);
     hipLaunchKernelGGL(k_poly_bound_slab, grid, kBlock, 0, c.stream, Z, L, R, Lv, rps, scratch);
     hipLaunchKernelGGL(k_colsum, (unsigned)((R + kBlock - 1) / kBlock), kBlock, 0, c.stream, (const Fr *)scratch, slabs, R, out);
 }
 
 // ------------------------------------------------------------------------------------------------ K8 fixed-base MSM
-// acc += s * P[base] using the window table slice `tbl` (W windows x E entries) of that base
-__device__ __forceinline__ void msm_accumulate(Pt &acc, const Niels *tbl, const Fr &s, int c, int W, size_t E) {
-    if (fr_is_zero(s)) return;
-    Fr raw = fr_to_raw(s);
-    int carry = 0, half = 1 << (c - 1);
-    for (int w = 0; w < W; w++) {
-        int d = scalar_window(raw.v, w * c, c) + carry;
-        carry = 0;
-        if (d > half) { d -= (1 << c); carry = 1; }
-        if (d > 0) { Niels e = tbl[(size_t)w * E + (d - 1)]; acc = pt_madd(acc, e); }
-        else if (d < 0) { Niels e = tbl[(size_t)w * E + (-d - 1)]; acc = pt_msub(acc, e); }
+// One workgroup sums a chunk of one row's terms.  Phase 1 stages the chunk's scalars in LDS as s' = raw(s) + K with
+// K = sum_w 2^(c-1+cw): the signed radix-2^c digit of window w is then (window w of s') - 2^(c-1), with no carry chain between
+// windows, so any thread can take any (term, window) pair.  Phase 2: thread (term lane tl, window w) walks the terms tl, tl+lanes, ..
+// and adds the table entry |d| * 2^(cw) * P[base] (affine Niels, 96-byte gather from HBM/L2; negated in registers when d < 0) into
+// its own accumulator with one 7-multiply mixed addition per pair.  Phase 3: LDS tree over the 256 accumulators.
+constexpr int kMsmMaxChunk = 1024;             // terms per workgroup (LDS: 36 B each)
+struct MsmArgs {
+    const Niels *table; int c, W; uint32_t E; int lanes;            // lanes = 256 / W term lanes
+    const Fr *dense; size_t stride, n_dense; uint32_t chunk, nchunks;
+    const Fr *extra_s; uint32_t extra_base[8]; int n_extra;
+    uint32_t K[9];                                                  // recoding constant (288 bits)
+    Pt *partial;
+};
+__global__ __launch_bounds__(kBlock) void k_msm_rows(MsmArgs A) {
+    __shared__ uint32_t s_raw[(kMsmMaxChunk + 8) * 9];
+    __shared__ uint32_t s_base[8];
+    __shared__ Pt sm[kBlock / 2];
+    const size_t row = blockIdx.y; const uint32_t chunk_id = blockIdx.x;
+    const size_t j0 = (size_t)chunk_id * A.chunk;
+    const uint32_t n_here = (uint32_t)min((size_t)A.chunk, A.n_dense - j0);
+    const uint32_t n_ex = chunk_id == 0 ? (uint32_t)A.n_extra : 0u;
+    // ---- phase 1: recoded scalars into LDS
+    for (uint32_t t = threadIdx.x; t < n_here + n_ex; t += blockDim.x) {
+        Fr sc = t < n_here ? A.dense[row * A.stride + j0 + t] : A.extra_s[row * A.n_extra + (t - n_here)];
+        Fr raw = fr_to_raw(sc);
+        uint64_t cy = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) { cy += (uint64_t)raw.v[i] + A.K[i]; s_raw[t * 9 + i] = (uint32_t)cy; cy >>= 32; }
+        s_raw[t * 9 + 8] = (uint32_t)cy + A.K[8];
     }
-}
-struct ExtraBases { uint32_t b[8]; };
-__global__ __launch_bounds__(kBlock) void k_msm_rows(const Niels *table, int c, int W, size_t E, const Fr *dense, size_t stride, size_t n_dense,
-                                                     const Fr *extra_s, ExtraBases eb, int n_extra, int splits, Pt *partial) {
-    __shared__ Pt sm[kBlock];
-    size_t row = blockIdx.y; int split = blockIdx.x;
-    size_t chunk = (n_dense + splits - 1) / splits, j0 = split * chunk, j1 = min(n_dense, j0 + chunk);
-    size_t WE = (size_t)W * E;
-    Pt acc = pt_identity();
-    for (size_t j = j0 + threadIdx.x; j < j1; j += blockDim.x) msm_accumulate(acc, table + j * WE, dense[row * stride + j], c, W, E);
-    if (split == 0 && (int)threadIdx.x < n_extra) msm_accumulate(acc, table + (size_t)eb.b[threadIdx.x] * WE, extra_s[row * n_extra + threadIdx.x], c, W, E);
-    sm[threadIdx.x] = acc;
+    if (threadIdx.x < 8) s_base[threadIdx.x] = A.extra_base[threadIdx.x];
     __syncthreads();
-    for (int s = kBlock / 2; s >= 1; s >>= 1) {
-        if ((int)threadIdx.x < s) { acc = pt_add(acc, sm[threadIdx.x + s]); sm[threadIdx.x] = acc; }
+    // ---- phase 2: one mixed addition per (term, window) pair
+    Pt acc = pt_identity();
+    const int w = threadIdx.x % A.W, tl = threadIdx.x / A.W;
+    if (tl < A.lanes) {
+        const int pos = w * A.c, limb = pos >> 5, off = pos & 31;
+        const uint32_t mask = (1u << A.c) - 1u; const int half = 1 << (A.c - 1);
+        const size_t WE = (size_t)A.W * A.E;
+        for (uint32_t t = tl; t < n_here + n_ex; t += A.lanes) {
+            uint64_t x = s_raw[t * 9 + limb];
+            if (limb < 8) x |= (uint64_t)s_raw[t * 9 + limb + 1] << 32;
+            int d = (int)((uint32_t)(x >> off) & mask) - half;
+            if (d == 0) continue;
+            size_t base = t < n_here ? j0 + t : (size_t)s_base[t - n_here];
+            uint32_t mag = (uint32_t)(d < 0 ? -d : d);
+            Niels e = A.table[base * WE + (size_t)w * A.E + (mag - 1)];
+            if (d < 0) { Fp tmp = e.yplusx; e.yplusx = e.yminusx; e.yminusx = tmp; e.xy2d = fp_neg(e.xy2d); }
+            acc = pt_madd(acc, e);
+        }
+    }
+    // ---- phase 3: LDS tree
+    for (int sft = kBlock / 2; sft >= 1; sft >>= 1) {
+        if ((int)threadIdx.x >= sft && (int)threadIdx.x < 2 * sft) sm[threadIdx.x - sft] = acc;
+        __syncthreads();
+        if ((int)threadIdx.x < sft) acc = pt_add(acc, sm[threadIdx.x]);
         __syncthreads();
     }
-    if (threadIdx.x == 0) partial[row * splits + split] = acc;
+    if (threadIdx.x == 0) A.partial[row * A.nchunks + chunk_id] = acc;
 }
-__global__ __launch_bounds__(64) void k_msm_finish(const Pt *partial, int splits, size_t rows, uint8_t *out32) {
-    size_t row = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (row >= rows) return;
-    Pt acc = partial[row * splits];
-    for (int s = 1; s < splits; s++) acc = pt_add(acc, partial[row * splits + s]);
-    uint8_t enc[32]; pt_encode(enc, acc);
-    uint32_t *o = (uint32_t *)(out32 + 32 * row);
-    for (int i = 0; i < 8; i++) o[i] = (uint32_t)enc[4 * i] | ((uint32_t)enc[4 * i + 1] << 8) | ((uint32_t)enc[4 * i + 2] << 16) | ((uint32_t)enc[4 * i + 3] << 24);
+// one wave per row: sum the row's chunk partials into one extended point
+__global__ __launch_bounds__(64) void k_msm_finish(const Pt *partial, uint32_t nchunks, size_t rows, Pt *final_pts) {
+    __shared__ Pt sm[32];
+    const size_t row = blockIdx.x;
+    Pt acc = pt_identity();
+    for (uint32_t k = threadIdx.x; k < nchunks; k += 64) acc = pt_add(acc, partial[row * nchunks + k]);
+    for (int sft = 32; sft >= 1; sft >>= 1) {
+        if ((int)threadIdx.x >= sft && (int)threadIdx.x < 2 * sft) sm[threadIdx.x - sft] = acc;
+        __syncthreads();
+        if ((int)threadIdx.x < sft) acc = pt_add(acc, sm[threadIdx.x]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) final_pts[row] = acc;
+}
+// RFC 9496 encode, one lane per point (the inverse square root is a ~265-multiplication dependent chain: pack 64 rows per wave)
+__global__ __launch_bounds__(64) void k_encode_points(const Pt *pts, size_t n, uint8_t *out32) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint8_t enc[32]; pt_encode(enc, pts[i]);
+    uint32_t *o = (uint32_t *)(out32 + 32 * i);
+    for (int k = 0; k < 8; k++) o[k] = (uint32_t)enc[4 * k] | ((uint32_t)enc[4 * k + 1] << 8) | ((uint32_t)enc[4 * k + 2] << 16) | ((uint32_t)enc[4 * k + 3] << 24);
 }
 void dev_msm_rows(DevCtx &c, const DeviceGens &g, const Fr *dense, size_t stride, size_t n_dense, size_t rows, const Fr *extra_s,
-                  const uint32_t *extra_base, size_t n_extra) {
+                  const uint32_t *extra_base, size_t n_extra, bool raw_points) {
     if (n_extra > 8) throw Error(OTTI_ERR_INTERNAL, "msm: too many extra terms");
     if (!rows) return;
-    // enough workgroups to fill 256 CUs a few times over, but never slices shorter than one term per thread
-    size_t splits = 1;
-    while (rows * splits < 1024 && n_dense / (splits * 2) >= (size_t)kBlock) splits *= 2;
-    c.ensure_points(rows, splits);
-    ExtraBases eb; for (int i = 0; i < 8; i++) eb.b[i] = i < (int)n_extra ? extra_base[i] : 0;
-    dim3 grid((unsigned)splits, (unsigned)rows);
-    hipLaunchKernelGGL(k_msm_rows, grid, kBlock, 0, c.stream, (const Niels *)g.table.p, g.c, g.W, g.E, dense, stride, n_dense, extra_s, eb, (int)n_extra,
-                       (int)splits, c.msm_partial.p);
-    hipLaunchKernelGGL(k_msm_finish, (unsigned)((rows + 63) / 64), 64, 0, c.stream, (const Pt *)c.msm_partial.p, (int)splits, rows, c.d_points.p);
-    OTTI_HIP(hipMemcpyAsync(c.h_points, c.d_points.p, rows * 32, hipMemcpyDeviceToHost, c.stream));
+    MsmArgs A;
+    A.table = g.table.p; A.c = g.c; A.W = g.W; A.E = (uint32_t)g.E; A.lanes = kBlock / g.W;
+    A.dense = dense; A.stride = stride; A.n_dense = n_dense; A.extra_s = extra_s; A.n_extra = (int)n_extra;
+    for (int i = 0; i < 8; i++) A.extra_base[i] = i < (int)n_extra ? extra_base[i] : 0;
+    // chunking: aim for >= 1024 workgroups (4 per CU) but keep at least one term per term lane and at most kMsmMaxChunk per workgroup
+    size_t nchunks = std::max<size_t>(1, (1024 + rows - 1) / rows);
+    nchunks = std::min(nchunks, std::max<size_t>(1, n_dense / (size_t)A.lanes));
+    if (!n_dense) nchunks = 1;
+    nchunks = std::max(nchunks, (n_dense + kMsmMaxChunk - 1) / kMsmMaxChunk);
+    size_t chunk = n_dense ? (n_dense + nchunks - 1) / nchunks : 1;
+    nchunks = n_dense ? (n_dense + chunk - 1) / chunk : 1;
+    A.chunk = (uint32_t)chunk; A.nchunks = (uint32_t)nchunks;
+    for (int i = 0; i < 9; i++) A.K[i] = 0;
+    for (int w = 0; w < g.W; w++) { int bit = g.c - 1 + g.c * w; A.K[bit >> 5] |= 1u << (bit & 31); }
+    c.ensure_points(rows, nchunks);
+    A.partial = c.msm_partial.p;
+    dim3 grid((unsigned)nchunks, (unsigned)rows);
+    { KScope ks(c, KC_MSM_ROWS); hipLaunchKernelGGL(k_msm_rows, grid, kBlock, 0, c.stream, A); }
+    // rows with a single chunk need no finish pass: their partial IS the row sum
+    const Pt *finals = c.msm_partial.p;
+    if (nchunks > 1) {
+        KScope ks(c, KC_MSM_FINISH);
+        hipLaunchKernelGGL(k_msm_finish, (unsigned)rows, 64, 0, c.stream, (const Pt *)c.msm_partial.p, (uint32_t)nchunks, rows, c.msm_final.p);
+        finals = c.msm_final.p;
+    }
+    if (raw_points) {
+        if (rows > kHostPtsCap) throw Error(OTTI_ERR_INTERNAL, "msm: too many raw rows");
+        OTTI_HIP(hipMemcpyAsync(c.h_pts, finals, rows * sizeof(Pt), hipMemcpyDeviceToHost, c.stream));
+        c.pending_host_encode = 0;
+    } else if (rows > kHostEncodeRows) {
+        KScope ks(c, KC_MSM_FINISH);
+        hipLaunchKernelGGL(k_encode_points, (unsigned)((rows + 63) / 64), 64, 0, c.stream, finals, rows, c.d_points.p);
+        OTTI_HIP(hipMemcpyAsync(c.h_points, c.d_points.p, rows * 32, hipMemcpyDeviceToHost, c.stream));
+        c.pending_host_encode = 0;
+    } else {
+        // a handful of points: the dependent inverse-square-root chain runs ~30x faster on a host core than on one GPU lane
+        OTTI_HIP(hipMemcpyAsync(c.h_pts, finals, rows * sizeof(Pt), hipMemcpyDeviceToHost, c.stream));
+        c.pending_host_encode = rows;
+    }
+}
+void DevCtx::sync() {
+    OTTI_HIP(hipStreamSynchronize(stream));
+    for (size_t i = 0; i < pending_host_encode; i++) pt_encode(h_points + 32 * i, h_pts[i]);
+    pending_host_encode = 0;
 }
 
 // table build: one thread per (base, window); extended points first, then a per-thread batch inversion to affine Niels
@@ -481,6 +582,7 @@ __global__ __launch_bounds__(1024) void k_bullet_step(Fr *a, Fr *b, Fr *s, size_
     }
 }
 void dev_bullet_step(DevCtx &c, Fr *a, Fr *b, Fr *s, size_t R, size_t n_cur, bool fold_first, const Fr &u, const Fr &u_inv, Fr *rows, Fr *extra_out) {
+    KScope ks(c, KC_BULLET);
     hipLaunchKernelGGL(k_bullet_step, 1, 1024, 0, c.stream, a, b, s, R, n_cur, (int)fold_first, u, u_inv, rows, extra_out);
 }
 

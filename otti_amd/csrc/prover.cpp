@@ -39,11 +39,34 @@ DeviceWitness::DeviceWitness(const Instance &I, const std::vector<Fr> &vars_padd
 }
 
 namespace {
+// Everything a sum-check's rounds need that depends on the random tape alone, as ONE batched fixed-base MSM: for each round the
+// four points delta_j = commit(d_vec_j, r_delta_j), blinds_poly[j]*h_n, blinds_evals[j]*h_1, r_beta_j*h_1 (extended, not compressed).
+void precompute_round_points(DevCtx &c, const DeviceGens &DG, const Gens &g, const GensView &gn, SumcheckState &st, size_t ne, DevBuf<Fr> &scratch) {
+    const size_t n = st.pre.size(), nb = ne + 2;                       // bases: G_0..G_{ne-1}, h_n, h_1
+    if (4 * n > kHostPtsCap) throw Error(OTTI_ERR_INTERNAL, "too many sum-check rounds");
+    std::vector<uint32_t> bases(nb);
+    for (size_t i = 0; i < ne; i++) bases[i] = gn.G[i];
+    bases[ne] = gn.h; bases[ne + 1] = g.sc_1.h;
+    std::vector<Fr> sc(4 * n * nb, fr_zero());
+    for (size_t j = 0; j < n; j++) {
+        Fr *r0 = &sc[(4 * j + 0) * nb], *r1 = &sc[(4 * j + 1) * nb], *r2 = &sc[(4 * j + 2) * nb], *r3 = &sc[(4 * j + 3) * nb];
+        for (size_t i = 0; i < ne; i++) r0[i] = st.pre[j].d[i];
+        r0[ne] = st.pre[j].r_delta;
+        r1[ne] = st.blinds_poly[j];
+        r2[ne + 1] = st.blinds_evals[j];
+        r3[ne + 1] = st.pre[j].r_beta;
+    }
+    if (scratch.n < sc.size()) scratch.alloc(sc.size());
+    OTTI_HIP(hipMemcpyAsync(scratch.p, sc.data(), sc.size() * sizeof(Fr), hipMemcpyHostToDevice, c.stream));
+    dev_msm_rows(c, DG, nullptr, 0, 0, 4 * n, scratch.p, bases.data(), nb, true);
+    c.sync();
+    for (size_t j = 0; j < n; j++) { st.pre[j].delta = c.h_pts[4 * j]; st.pre[j].bp_h = c.h_pts[4 * j + 1]; st.pre[j].be_h = c.h_pts[4 * j + 2]; st.pre[j].rb_h = c.h_pts[4 * j + 3]; }
+}
 struct Scratch {
     DevBuf<Fr> T[4];          // eq(tau), Az, Bz, Cz  (N each)
     DevBuf<Fr> zw, ABC;       // phase-two working tables (2V each)
     DevBuf<Fr> eqs;           // eq-table scratch (3 * 4096)
-    DevBuf<Fr> blinds, Lv, Rv, LZ, a, s, rows, extras, bound_scratch;
+    DevBuf<Fr> blinds, Lv, Rv, LZ, a, s, rows, extras, bound_scratch, pre;
 };
 inline CPoint point_at(const DevCtx &c, size_t i) { CPoint p; memcpy(p.b, c.h_points + 32 * i, 32); return p; }
 }  // namespace
@@ -103,7 +126,8 @@ std::vector<uint8_t> nizk_prove_resident(Instance &I, DeviceWitness &wit, Gens &
     Fr blind_claim_postsc1;
     {
         SumcheckState st;
-        st.blinds_poly = tape.random_vector("blinds_poly", nrx); st.blinds_evals = tape.random_vector("blinds_evals", nrx);
+        sumcheck_draw_tape(st, tape, nrx, 4);
+        precompute_round_points(c, DG, g, g.sc_4, st, 4, S.pre);
         st.claim = fr_zero(); st.blind_claim = fr_zero();
         { Term t2[2] = {{g.sc_1.G[0], fr_zero()}, {g.sc_1.h, fr_zero()}}; g.commit_terms_c(st.comm_claim.b, t2, 2); }
         P.sc1.comm_polys.resize(nrx); P.sc1.comm_evals.resize(nrx); P.sc1.proofs.resize(nrx);
@@ -116,7 +140,7 @@ std::vector<uint8_t> nizk_prove_resident(Instance &I, DeviceWitness &wit, Gens &
             size_t len = N >> j;
             if (len >= 4) dev_sc_cubic_fold_eval(c, S.T[0].p, S.T[1].p, S.T[2].p, S.T[3].p, len, p1.r_j, 0);
             else for (auto &t : S.T) dev_fold_top(c, t.p, len, p1.r_j);
-            sumcheck_round_finish(P.sc1, j, p1, st, g, g.sc_4, tr, tape);       // overlaps the device fold
+            sumcheck_round_finish(P.sc1, j, p1, st, g, g.sc_4, tr);             // overlaps the device fold
         }
         blind_claim_postsc1 = st.blinds_evals[nrx - 1];
     }
@@ -159,7 +183,8 @@ std::vector<uint8_t> nizk_prove_resident(Instance &I, DeviceWitness &wit, Gens &
     Fr claims_phase2[2], blind_claim_postsc2;
     {
         SumcheckState st;
-        st.blinds_poly = tape.random_vector("blinds_poly", nry); st.blinds_evals = tape.random_vector("blinds_evals", nry);
+        sumcheck_draw_tape(st, tape, nry, 3);
+        precompute_round_points(c, DG, g, g.sc_3, st, 3, S.pre);
         st.claim = claim2; st.blind_claim = blind_claim2;
         { Term t2[2] = {{g.sc_1.G[0], claim2}, {g.sc_1.h, blind_claim2}}; g.commit_terms_c(st.comm_claim.b, t2, 2); }
         P.sc2.comm_polys.resize(nry); P.sc2.comm_evals.resize(nry); P.sc2.proofs.resize(nry);
@@ -172,7 +197,7 @@ std::vector<uint8_t> nizk_prove_resident(Instance &I, DeviceWitness &wit, Gens &
             size_t len = (2 * V) >> j;
             if (len >= 4) dev_sc_quad_fold_eval(c, S.zw.p, S.ABC.p, len, p1.r_j, 0);
             else { dev_fold_top(c, S.zw.p, len, p1.r_j); dev_fold_top(c, S.ABC.p, len, p1.r_j); }
-            sumcheck_round_finish(P.sc2, j, p1, st, g, g.sc_3, tr, tape);
+            sumcheck_round_finish(P.sc2, j, p1, st, g, g.sc_3, tr);
         }
         blind_claim_postsc2 = st.blinds_evals[nry - 1];
         dev_fetch(c, S.zw.p, 8, 1); dev_fetch(c, S.ABC.p, 9, 1);
@@ -260,6 +285,7 @@ std::vector<uint8_t> nizk_prove_resident(Instance &I, DeviceWitness &wit, Gens &
     }
     std::vector<uint8_t> out = P.serialize();
     T.ms[6] = now_ms() - t_start;
+    KStats::get().flush();                                       // stream is idle here (last c.sync() above)
     if (tm) *tm = T;
     return out;
 }

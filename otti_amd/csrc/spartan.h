@@ -96,18 +96,26 @@ KnowledgeProof knowledge_prove(CPoint &C, const Gens &g, Transcript &tr, RandomT
 EqualityProof equality_prove(const Gens &g, Transcript &tr, RandomTape &tape, const Fr &v1, const Fr &s1, const Fr &v2, const Fr &s2);
 ProductProof product_prove(CPoint &X, CPoint &Y, CPoint &Z, const Gens &g, Transcript &tr, RandomTape &tape, const Fr &x, const Fr &rX,
                            const Fr &y, const Fr &rY, const Fr &z, const Fr &rZ);
-DotProductProof dotproduct_prove(const Gens &g, const GensView &gn, Transcript &tr, RandomTape &tape, const Fr *x, size_t n,
-                                 const Fr &blind_x, const Fr *a, const Fr &y, const Fr &blind_y, const CPoint *Cx_known);
 void unipoly_from_evals(Fr *c, const Fr *e, size_t n);
 Fr unipoly_eval(const Fr *c, size_t n, const Fr &r);
 
-// one round of ZKSumcheckInstanceProof::prove_{quad,cubic_with_additive_term} after the table sums are known
-struct SumcheckState { Fr claim; CPoint comm_claim; Fr blind_claim; std::vector<Fr> blinds_poly, blinds_evals; };
+// One round of ZKSumcheckInstanceProof::prove_{quad,cubic_with_additive_term} after the table sums are known.
+// The prover's randomness (RandomTape) is a separate transcript that depends only on the seed, so everything derived from it
+// alone is drawn and committed for all rounds up front (RoundPre; one batched fixed-base MSM on the device): the per-round
+// host work on the sequential Fiat-Shamir path is then 4+1+2+1 fixed-base terms instead of 5+2+2+5+2.
+struct RoundPre {
+    Fr d[4], r_delta, r_beta;          // DotProductProof::prove draws: d_vec, r_delta, r_beta
+    Pt delta;                          // commit(d_vec, r_delta) over gens_n
+    Pt bp_h, be_h, rb_h;               // blinds_poly[j]*h_n, blinds_evals[j]*h_1, r_beta*h_1
+};
+struct SumcheckState { Fr claim; CPoint comm_claim; Fr blind_claim; std::vector<Fr> blinds_poly, blinds_evals; std::vector<RoundPre> pre; };
 struct RoundPart1 { Fr poly[4]; size_t ne; Fr r_j; };
+// draws blinds_poly, blinds_evals and every round's (d_vec, r_delta, r_beta) from the tape in upstream's order
+void sumcheck_draw_tape(SumcheckState &st, RandomTape &tape, size_t num_rounds, size_t ne);
 RoundPart1 sumcheck_round_begin(ZKSumcheckProof &pf, size_t j, const Fr *evals, size_t ne, const SumcheckState &st, const Gens &g,
                                 const GensView &gn, Transcript &tr);
 void sumcheck_round_finish(ZKSumcheckProof &pf, size_t j, const RoundPart1 &p1, SumcheckState &st, const Gens &g, const GensView &gn,
-                           Transcript &tr, RandomTape &tape);
+                           Transcript &tr);
 
 // ---------------------------------------------------------------------------------------------- verifier (lib.rs NIZK::verify)
 int nizk_verify(const Instance &inst, const std::vector<Fr> &inputs, const Gens &g, const void *tlabel, size_t tlabel_len,

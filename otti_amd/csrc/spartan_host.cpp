@@ -138,12 +138,11 @@ Pt Gens::commit_generic(const Fr *v, size_t n, const Fr &blind, const GensView &
 
 // ================================================================================================ unipoly.rs
 void unipoly_from_evals(Fr *c, const Fr *e, size_t n) {
-    Fr two_inv = fr_inv(fr_from_u64(2));
+    static const Fr two_inv = fr_inv(fr_from_u64(2)), six_inv = fr_inv(fr_from_u64(6));
     if (n == 3) {
         Fr a = fr_mul(two_inv, fr_add(fr_sub(fr_sub(e[2], e[1]), e[1]), e[0]));
         c[0] = e[0]; c[1] = fr_sub(fr_sub(e[1], e[0]), a); c[2] = a;
     } else {
-        Fr six_inv = fr_inv(fr_from_u64(6));
         Fr e1x3 = fr_add(fr_dbl(e[1]), e[1]), e2x3 = fr_add(fr_dbl(e[2]), e[2]);
         Fr a = fr_mul(six_inv, fr_sub(fr_add(fr_sub(e[3], e2x3), e1x3), e[0]));
         Fr e1x5 = fr_add(fr_dbl(fr_dbl(e[1])), e[1]), e2x4 = fr_dbl(fr_dbl(e[2]));
@@ -210,40 +209,38 @@ ProductProof product_prove(CPoint &X, CPoint &Y, CPoint &Z, const Gens &g, Trans
     return pf;
 }
 
-DotProductProof dotproduct_prove(const Gens &g, const GensView &gn, Transcript &tr, RandomTape &tape, const Fr *x, size_t n,
-                                 const Fr &blind_x, const Fr *a, const Fr &y, const Fr &blind_y, const CPoint *Cx_known) {
-    tr.append_protocol_name("dot product proof");
-    std::vector<Fr> d = tape.random_vector("d_vec", n);
-    Fr r_delta = tape.random_scalar("r_delta"), r_beta = tape.random_scalar("r_beta");
-    CPoint Cx = Cx_known ? *Cx_known : commit_vec(g, gn, x, n, blind_x);     // the round's comm_poly is this same commitment
-    tr.append_point("Cx", Cx.b);
-    CPoint Cy = commit_scalar(g, g.sc_1, y, blind_y); tr.append_point("Cy", Cy.b);
-    tr.append_scalars("a", a, n);
-    DotProductProof pf;
-    pf.delta = commit_vec(g, gn, d.data(), n, r_delta); tr.append_point("delta", pf.delta.b);
-    Fr ad = fr_zero(); for (size_t i = 0; i < n; i++) ad = fr_add(ad, fr_mul(a[i], d[i]));
-    pf.beta = commit_scalar(g, g.sc_1, ad, r_beta); tr.append_point("beta", pf.beta.b);
-    Fr c = tr.challenge_scalar("c");
-    pf.z.resize(n); for (size_t i = 0; i < n; i++) pf.z[i] = fr_add(fr_mul(c, x[i]), d[i]);
-    pf.z_delta = fr_add(fr_mul(c, blind_x), r_delta); pf.z_beta = fr_add(fr_mul(c, blind_y), r_beta);
-    return pf;
+// sumcheck.rs + nizk/mod.rs DotProductProof::prove.  NOTE on tape order: upstream draws blinds_poly and blinds_evals when the
+// sum-check starts and (d_vec, r_delta, r_beta) inside each round's DotProductProof::prove; nothing else touches the tape in
+// between, so drawing all rounds' values right after the blinds yields the same values.
+void sumcheck_draw_tape(SumcheckState &st, RandomTape &tape, size_t num_rounds, size_t ne) {
+    st.blinds_poly = tape.random_vector("blinds_poly", num_rounds);
+    st.blinds_evals = tape.random_vector("blinds_evals", num_rounds);
+    st.pre.resize(num_rounds);
+    for (auto &p : st.pre) {
+        std::vector<Fr> d = tape.random_vector("d_vec", ne);
+        for (size_t i = 0; i < ne; i++) p.d[i] = d[i];
+        p.r_delta = tape.random_scalar("r_delta"); p.r_beta = tape.random_scalar("r_beta");
+    }
 }
+static CPoint encode_sum(const Pt &a, const Pt &b) { CPoint c; pt_encode(c.b, pt_add(a, b)); return c; }
 
-// sumcheck.rs: the transcript work of one round, split at the challenge so the device can fold while the host finishes
+// the transcript work of one round, split at the challenge so the device can fold while the host finishes
 RoundPart1 sumcheck_round_begin(ZKSumcheckProof &pf, size_t j, const Fr *evals, size_t ne, const SumcheckState &st, const Gens &g,
                                 const GensView &gn, Transcript &tr) {
     RoundPart1 p; p.ne = ne;
     unipoly_from_evals(p.poly, evals, ne);
-    pf.comm_polys[j] = commit_vec(g, gn, p.poly, ne, st.blinds_poly[j]);
+    Term t[4]; for (size_t i = 0; i < ne; i++) t[i] = {gn.G[i], p.poly[i]};
+    pf.comm_polys[j] = encode_sum(g.commit_terms(t, ne), st.pre[j].bp_h);               // commit(poly, blinds_poly[j]) over gens_n
     tr.append_point("comm_poly", pf.comm_polys[j].b);
     p.r_j = tr.challenge_scalar("challenge_nextround");
     return p;
 }
 void sumcheck_round_finish(ZKSumcheckProof &pf, size_t j, const RoundPart1 &p1, SumcheckState &st, const Gens &g, const GensView &gn,
-                           Transcript &tr, RandomTape &tape) {
-    size_t ne = p1.ne;
+                           Transcript &tr) {
+    const size_t ne = p1.ne; const RoundPre &pre = st.pre[j]; (void)gn;
     Fr eval = unipoly_eval(p1.poly, ne, p1.r_j);
-    CPoint comm_eval = commit_scalar(g, g.sc_1, eval, st.blinds_evals[j]);
+    Term te = {g.sc_1.G[0], eval};
+    CPoint comm_eval = encode_sum(g.commit_terms(&te, 1), pre.be_h);                       // commit(eval, blinds_evals[j]) over gens_1
     tr.append_point("comm_claim_per_round", st.comm_claim.b);
     tr.append_point("comm_eval", comm_eval.b);
     std::vector<Fr> w = tr.challenge_vector("combine_two_claims_to_one", 2);
@@ -252,7 +249,20 @@ void sumcheck_round_finish(ZKSumcheckProof &pf, size_t j, const RoundPart1 &p1, 
     Fr blind = fr_add(fr_mul(w[0], blind_sc), fr_mul(w[1], st.blinds_evals[j]));
     Fr a[4], pw = fr_one(), two = fr_from_u64(2);
     for (size_t i = 0; i < ne; i++) { a[i] = fr_add(fr_mul(w[0], i == 0 ? two : fr_one()), fr_mul(w[1], pw)); pw = fr_mul(pw, p1.r_j); }
-    pf.proofs[j] = dotproduct_prove(g, gn, tr, tape, p1.poly, ne, st.blinds_poly[j], a, target, blind, &pf.comm_polys[j]);
+    // DotProductProof::prove(gens_1, gens_n, poly, blinds_poly[j], a, target, blind); Cx is this round's comm_poly
+    tr.append_protocol_name("dot product proof");
+    tr.append_point("Cx", pf.comm_polys[j].b);
+    CPoint Cy = commit_scalar(g, g.sc_1, target, blind); tr.append_point("Cy", Cy.b);
+    tr.append_scalars("a", a, ne);
+    DotProductProof dp;
+    pt_encode(dp.delta.b, pre.delta); tr.append_point("delta", dp.delta.b);
+    Fr ad = fr_zero(); for (size_t i = 0; i < ne; i++) ad = fr_add(ad, fr_mul(a[i], pre.d[i]));
+    Term tb = {g.sc_1.G[0], ad};
+    dp.beta = encode_sum(g.commit_terms(&tb, 1), pre.rb_h); tr.append_point("beta", dp.beta.b);
+    Fr c = tr.challenge_scalar("c");
+    dp.z.resize(ne); for (size_t i = 0; i < ne; i++) dp.z[i] = fr_add(fr_mul(c, p1.poly[i]), pre.d[i]);
+    dp.z_delta = fr_add(fr_mul(c, st.blinds_poly[j]), pre.r_delta); dp.z_beta = fr_add(fr_mul(c, blind), pre.r_beta);
+    pf.proofs[j] = dp;
     st.claim = eval; st.comm_claim = comm_eval; pf.comm_evals[j] = comm_eval;
 }
 
