@@ -138,6 +138,8 @@ int32_t otti_k_msm_rows(otti_gens *gens, const uint8_t *h_Z, size_t L, size_t R,
 /* per-kernel-class timing with HIP events recorded on the library's own stream around every launch of that class.
    classes: msm_rows msm_finish sc_cubic sc_quad spmv eq reduce poly_bound bullet other.  enable(1) also resets the counters. */
 int32_t otti_stats_enable(int32_t on);
+/* restrict timing to one class (call after enable): two event records per launch are not free on the latency-bound round loop */
+int32_t otti_stats_select(const char *kernel_class);
 int32_t otti_stats_read(const char *kernel_class, uint64_t *count, double *total_ms);
 
 /* ---- multi-GPU plumbing: sum-check partial sums travel as 8 x u32 limbs widened to u64 lanes so that a plain integer

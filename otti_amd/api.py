@@ -82,6 +82,7 @@ _sig("otti_zkif_write", _i32, ctypes.POINTER(_R1CS), ctypes.c_char_p, ctypes.c_c
 _sig("otti_r1cs_free", None, ctypes.POINTER(_R1CS))
 _sig("otti_synth_r1cs", _i32, _u64, _u64, _u64, ctypes.POINTER(ctypes.POINTER(_R1CS)))
 _sig("otti_stats_enable", _i32, _i32)
+_sig("otti_stats_select", _i32, ctypes.c_char_p)
 _sig("otti_stats_read", _i32, ctypes.c_char_p, ctypes.POINTER(_u64), ctypes.POINTER(ctypes.c_double))
 _sig("otti_lanes_pack", None, _vp, _sz, _vp)
 _sig("otti_lanes_unpack", None, _vp, _sz, _vp)
@@ -353,8 +354,10 @@ def fr_to_ints(a):
 KERNEL_CLASSES = ("msm_rows", "msm_finish", "sc_cubic", "sc_quad", "spmv", "eq", "reduce", "poly_bound", "bullet", "other")
 
 
-def stats_enable(on=True):
+def stats_enable(on=True, only=None):
     _check(lib.otti_stats_enable(1 if on else 0))
+    if on and only is not None:
+        _check(lib.otti_stats_select(only.encode()))
 
 
 def stats_read():

@@ -226,40 +226,40 @@ int32_t otti_k_fold_bot(const uint8_t *Z, size_t len, const uint8_t *r, uint8_t 
 int32_t otti_k_sc_cubic_round(const uint8_t *A, const uint8_t *B, const uint8_t *C, const uint8_t *D, size_t len, uint8_t *e3, float *ms) {
     return guarded([&] {
         DevCtx &c = DevCtx::get(); Staged a(c, A, len), b(c, B, len), cc(c, C, len), d(c, D, len);
-        KTimer t(c, ms); dev_sc_cubic_eval(c, a.d.p, b.d.p, cc.d.p, d.d.p, len, 0); t.stop();
-        c.sync(); memcpy(e3, c.h_results, 96); return OTTI_OK;
+        KTimer t(c, ms); auto tk = dev_sc_cubic_eval(c, a.d.p, b.d.p, cc.d.p, d.d.p, len, 0); t.stop();
+        c.wait_ticket(tk); memcpy(e3, c.h_results, 96); c.sync(); return OTTI_OK;
     });
 }
 int32_t otti_k_sc_cubic_fold_round(const uint8_t *A, const uint8_t *B, const uint8_t *C, const uint8_t *D, size_t len, const uint8_t *r,
                                    uint8_t *out4, uint8_t *e3, float *ms) {
     return guarded([&] {
         DevCtx &c = DevCtx::get(); Staged a(c, A, len), b(c, B, len), cc(c, C, len), d(c, D, len);
-        KTimer t(c, ms); dev_sc_cubic_fold_eval(c, a.d.p, b.d.p, cc.d.p, d.d.p, len, fr_load(r), 0); t.stop();
+        KTimer t(c, ms); auto tk = dev_sc_cubic_fold_eval(c, a.d.p, b.d.p, cc.d.p, d.d.p, len, fr_load(r), 0); t.stop();
         size_t h = len / 2;
         download(c, out4, a.d.p, h); download(c, out4 + 32 * h, b.d.p, h); download(c, out4 + 64 * h, cc.d.p, h); download(c, out4 + 96 * h, d.d.p, h);
-        c.sync(); memcpy(e3, c.h_results, 96); return OTTI_OK;
+        c.sync(); c.wait_ticket(tk); memcpy(e3, c.h_results, 96); return OTTI_OK;
     });
 }
 int32_t otti_k_sc_quad_round(const uint8_t *A, const uint8_t *B, size_t len, uint8_t *e2, float *ms) {
     return guarded([&] {
         DevCtx &c = DevCtx::get(); Staged a(c, A, len), b(c, B, len);
-        KTimer t(c, ms); dev_sc_quad_eval(c, a.d.p, b.d.p, len, 0); t.stop();
-        c.sync(); memcpy(e2, c.h_results, 64); return OTTI_OK;
+        KTimer t(c, ms); auto tk = dev_sc_quad_eval(c, a.d.p, b.d.p, len, 0); t.stop();
+        c.wait_ticket(tk); memcpy(e2, c.h_results, 64); c.sync(); return OTTI_OK;
     });
 }
 int32_t otti_k_sc_quad_fold_round(const uint8_t *A, const uint8_t *B, size_t len, const uint8_t *r, uint8_t *out2, uint8_t *e2, float *ms) {
     return guarded([&] {
         DevCtx &c = DevCtx::get(); Staged a(c, A, len), b(c, B, len);
-        KTimer t(c, ms); dev_sc_quad_fold_eval(c, a.d.p, b.d.p, len, fr_load(r), 0); t.stop();
+        KTimer t(c, ms); auto tk = dev_sc_quad_fold_eval(c, a.d.p, b.d.p, len, fr_load(r), 0); t.stop();
         size_t h = len / 2; download(c, out2, a.d.p, h); download(c, out2 + 32 * h, b.d.p, h);
-        c.sync(); memcpy(e2, c.h_results, 64); return OTTI_OK;
+        c.sync(); c.wait_ticket(tk); memcpy(e2, c.h_results, 64); return OTTI_OK;
     });
 }
 int32_t otti_k_msm_rows(otti_gens *gens, const uint8_t *Z, size_t L, size_t R, const uint8_t *blinds, uint8_t *out32, float *ms) {
     return guarded([&] {
         DevCtx &c = DevCtx::get(); Gens &g = *gens->g;
         if (R != g.R) throw Error(OTTI_ERR_BAD_ARG, "row length differs from the generator count");
-        if (!g.dev) g.dev = build_device_gens(g, getenv("OTTI_MSM_WINDOW") ? atoi(getenv("OTTI_MSM_WINDOW")) : 8);
+        if (!g.dev) g.dev = build_device_gens(g, getenv("OTTI_MSM_WINDOW") ? atoi(getenv("OTTI_MSM_WINDOW")) : 12);
         Staged z(c, Z, L * R), bl(c, blinds, L);
         uint32_t hb = g.pc_n.h;
         KTimer t(c, ms); dev_msm_rows(c, *g.dev, z.d.p, R, R, L, bl.d.p, &hb, 1); t.stop();
@@ -269,7 +269,11 @@ int32_t otti_k_msm_rows(otti_gens *gens, const uint8_t *Z, size_t L, size_t R, c
 
 // ------------------------------------------------------------------------------------------------ kernel timing (HIP events on the library stream)
 static const char *kClassNames[KC_COUNT] = {"msm_rows", "msm_finish", "sc_cubic", "sc_quad", "spmv", "eq", "reduce", "poly_bound", "bullet", "other"};
-int32_t otti_stats_enable(int32_t on) { KStats::get().on = on != 0; KStats::get().reset(); return OTTI_OK; }
+int32_t otti_stats_enable(int32_t on) { KStats::get().on = on != 0; KStats::get().mask = 0xffffffffu; KStats::get().reset(); return OTTI_OK; }
+int32_t otti_stats_select(const char *kernel_class) {
+    for (int k = 0; k < KC_COUNT; k++) if (!strcmp(kernel_class, kClassNames[k])) { KStats::get().mask = 1u << k; return OTTI_OK; }
+    return OTTI_ERR_BAD_ARG;
+}
 int32_t otti_stats_read(const char *kernel_class, uint64_t *count, double *total_ms) {
     return guarded([&] {
         KStats &s = KStats::get();

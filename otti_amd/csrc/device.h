@@ -39,12 +39,20 @@ struct DeviceGens {
     const Niels *entry0(size_t base) const { return table.p + base * (size_t)W * E; }
 };
 
+// where a sum-check kernel's last workgroup delivers the round's totals (see finish_in_kernel)
+struct Mailbox { Fr *partials; unsigned *counter; Fr *host_results; unsigned long long *host_flag; unsigned long long seq; int slot; };
+
 struct DevCtx {
     hipStream_t stream = nullptr;
     int device = 0, num_cu = 256;
     DevBuf<Fr> partials;                                      // [kMaxBlocks][4] per-block partial sums
     DevBuf<Fr> results;                                       // small device result slots
     Fr *h_results = nullptr;                                  // pinned mirror of `results`
+    Fr *d_results_alias = nullptr;                            // device address of h_results (zero-copy stores)
+    unsigned long long *h_flag = nullptr, *d_flag_alias = nullptr, seq = 0;   // host-visible completion flag of the latest mailbox launch
+    DevBuf<unsigned> d_counter;                               // arrival counter of the publishing workgroups
+    Mailbox next_mailbox(int slot);
+    void wait_ticket(unsigned long long ticket);              // spin until the launch with that sequence number has delivered
     DevBuf<Pt> msm_partial, msm_final;                        // [rows][chunks] partial sums, [rows] row sums
     Pt *h_pts = nullptr; size_t pending_host_encode = 0;      // pinned: row sums of small launches, compressed on the host in sync()
     uint8_t *h_points = nullptr;                              // pinned: compressed points coming back
@@ -62,7 +70,7 @@ constexpr size_t kHostPtsCap = 512;
 // per-kernel-class HIP-event timing on the library's own stream (bench.py's roofline numbers come from here)
 enum KClass { KC_MSM_ROWS = 0, KC_MSM_FINISH, KC_SC_CUBIC, KC_SC_QUAD, KC_SPMV, KC_EQ, KC_REDUCE, KC_BOUND, KC_BULLET, KC_OTHER, KC_COUNT };
 struct KStats {
-    bool on = false;
+    bool on = false; unsigned mask = 0xffffffffu;            // bit k set: kernel class k is timed
     std::vector<hipEvent_t> pool; std::vector<int> cls; size_t used = 0;
     double total_ms[KC_COUNT] = {0}; unsigned long long count[KC_COUNT] = {0};
     static KStats &get();
@@ -94,11 +102,12 @@ void dev_fill_zero(DevCtx &c, Fr *p, size_t n);
 void dev_spmv3(DevCtx &c, const DeviceCsrSet &m, const Fr *x, Fr *out0, Fr *out1, Fr *out2, bool combine, const Fr coef[3]);
 // ---- K2: eq tables.  r is a HOST array (challenges come from the transcript)
 void dev_eq_evals(DevCtx &c, const Fr *r_host, size_t ell, Fr *out, Fr *scratch /* >= 2 * 2^min(ell,12) */);
-// ---- K3/K4/K5/K7: sum-check rounds.  Results land in c.h_results[slot .. slot+k) after c.sync()
-void dev_sc_cubic_eval(DevCtx &c, const Fr *A, const Fr *B, const Fr *C, const Fr *D, size_t len, int slot);
-void dev_sc_cubic_fold_eval(DevCtx &c, Fr *A, Fr *B, Fr *C, Fr *D, size_t len, const Fr &r, int slot);   // len >= 4; folds to len/2, sums over the folded tables
-void dev_sc_quad_eval(DevCtx &c, const Fr *A, const Fr *B, size_t len, int slot);
-void dev_sc_quad_fold_eval(DevCtx &c, Fr *A, Fr *B, size_t len, const Fr &r, int slot);
+// ---- K3/K4/K5/K7: sum-check rounds.  Results land in c.h_results[slot .. slot+k)
+// each returns a ticket: c.wait_ticket(ticket) returns once h_results[slot..] hold that launch's sums (no stream synchronise)
+unsigned long long dev_sc_cubic_eval(DevCtx &c, const Fr *A, const Fr *B, const Fr *C, const Fr *D, size_t len, int slot);
+unsigned long long dev_sc_cubic_fold_eval(DevCtx &c, Fr *A, Fr *B, Fr *C, Fr *D, size_t len, const Fr &r, int slot);   // len >= 4; folds to len/2, sums over the folded tables
+unsigned long long dev_sc_quad_eval(DevCtx &c, const Fr *A, const Fr *B, size_t len, int slot);
+unsigned long long dev_sc_quad_fold_eval(DevCtx &c, Fr *A, Fr *B, size_t len, const Fr &r, int slot);
 void dev_fold_top(DevCtx &c, Fr *Z, size_t len, const Fr &r);
 void dev_fold_bot(DevCtx &c, const Fr *Z, Fr *out, size_t len, const Fr &r);
 void dev_fetch(DevCtx &c, const Fr *src, int slot, size_t n);              // async copy of n elements into h_results[slot..]

@@ -12,9 +12,11 @@
 //   k_poly_bound_*       K9 DensePolynomial::bound
 //   k_bullet_step        K10 nizk/bullet.rs BulletReductionProof::prove scalar bookkeeping
 #include "device.h"
+#include "pool.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include <algorithm>
+#include <chrono>
 #include <mutex>
 
 namespace otti {
@@ -56,6 +58,12 @@ DevCtx &DevCtx::get() {
         c->partials.alloc((size_t)kMaxBlocks * 4);
         c->results.alloc(kResultSlots);
         OTTI_HIP(hipHostMalloc((void **)&c->h_results, kResultSlots * sizeof(Fr), hipHostMallocDefault));
+        OTTI_HIP(hipHostGetDevicePointer((void **)&c->d_results_alias, c->h_results, 0));
+        OTTI_HIP(hipHostMalloc((void **)&c->h_flag, 64, hipHostMallocDefault));
+        *c->h_flag = 0;
+        OTTI_HIP(hipHostGetDevicePointer((void **)&c->d_flag_alias, c->h_flag, 0));
+        c->d_counter.alloc(1);
+        OTTI_HIP(hipMemset(c->d_counter.p, 0, sizeof(unsigned)));
         OTTI_HIP(hipEventCreate(&c->ev0)); OTTI_HIP(hipEventCreate(&c->ev1));
         ctx = c;
         return *ctx;
@@ -75,7 +83,7 @@ void DevCtx::ensure_points(size_t rows, size_t splits) {
 // ------------------------------------------------------------------------------------------------ kernel timing
 KStats &KStats::get() { static KStats s; return s; }
 int KStats::begin(DevCtx &c, int k) {
-    if (!on) return -1;
+    if (!on || !((mask >> k) & 1u)) return -1;
     if (pool.empty()) { pool.resize(16384); for (auto &e : pool) OTTI_HIP(hipEventCreate(&e)); cls.resize(8192); }
     if (used + 1 > cls.size()) return -1;                     // pool exhausted until the next flush
     int rec = (int)used++;
@@ -277,33 +285,63 @@ template <int K> __device__ __forceinline__ void store_partials(Fr (&acc)[K], Fr
     block_reduce<K>(acc);
     if (threadIdx.x == 0) for (int k = 0; k < K; k++) partials[(size_t)blockIdx.x * K + k] = acc[k];
 }
-__global__ __launch_bounds__(kBlock) void k_sc_cubic_eval(const Fr *A, const Fr *B, const Fr *C, const Fr *D, size_t half, Fr *partials) {
+// Round sums without a second launch or a stream synchronise: every workgroup publishes its partial sums, the last one to arrive
+// (agent-scope counter; release/acquire per the gfx950 inter-workgroup recipe) adds them up, writes the K totals straight into
+// pinned host memory and then stores the launch's sequence number into a host-visible flag the prover thread is spinning on.
+template <int K> __device__ __forceinline__ void finish_in_kernel(Fr (&acc)[K], const Mailbox &mb) {
+    __shared__ int s_last;
+    block_reduce<K>(acc);
+    if (gridDim.x > 1) {
+        if (threadIdx.x == 0) {
+            for (int k = 0; k < K; k++) mb.partials[(size_t)blockIdx.x * K + k] = acc[k];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            unsigned old = __hip_atomic_fetch_add(mb.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = (old == gridDim.x - 1) ? 1 : 0;
+        }
+        __syncthreads();
+        if (!s_last) return;
+        if (threadIdx.x == 0) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        __syncthreads();
+        for (int k = 0; k < K; k++) acc[k] = fr_zero();
+        for (unsigned b = threadIdx.x; b < gridDim.x; b += blockDim.x)
+            for (int k = 0; k < K; k++) acc[k] = fr_add(acc[k], mb.partials[(size_t)b * K + k]);
+        block_reduce<K>(acc);
+    }
+    if (threadIdx.x == 0) {
+        for (int k = 0; k < K; k++) mb.host_results[mb.slot + k] = acc[k];
+        if (gridDim.x > 1) __hip_atomic_store(mb.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence_system();
+        __hip_atomic_store(mb.host_flag, mb.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_sc_cubic_eval(const Fr *A, const Fr *B, const Fr *C, const Fr *D, size_t half, Mailbox mb) {
     Fr acc[3] = {fr_zero(), fr_zero(), fr_zero()};
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x)
         cubic_accum(acc, load_pair(A, i, half), load_pair(B, i, half), load_pair(C, i, half), load_pair(D, i, half));
-    store_partials<3>(acc, partials);
+    finish_in_kernel<3>(acc, mb);
 }
-__global__ __launch_bounds__(kBlock) void k_sc_cubic_fold_eval(Fr *A, Fr *B, Fr *C, Fr *D, size_t q, Fr r, Fr *partials) {
+__global__ __launch_bounds__(kBlock) void k_sc_cubic_fold_eval(Fr *A, Fr *B, Fr *C, Fr *D, size_t q, Fr r, Mailbox mb) {
     Fr acc[3] = {fr_zero(), fr_zero(), fr_zero()};
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < q; i += (size_t)gridDim.x * blockDim.x) {
         Pair a = fold_pair(A, i, q, r), b = fold_pair(B, i, q, r), c = fold_pair(C, i, q, r), d = fold_pair(D, i, q, r);
         cubic_accum(acc, a, b, c, d);
     }
-    store_partials<3>(acc, partials);
+    finish_in_kernel<3>(acc, mb);
 }
-__global__ __launch_bounds__(kBlock) void k_sc_quad_eval(const Fr *A, const Fr *B, size_t half, Fr *partials) {
+__global__ __launch_bounds__(kBlock) void k_sc_quad_eval(const Fr *A, const Fr *B, size_t half, Mailbox mb) {
     Fr acc[2] = {fr_zero(), fr_zero()};
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x)
         quad_accum(acc, load_pair(A, i, half), load_pair(B, i, half));
-    store_partials<2>(acc, partials);
+    finish_in_kernel<2>(acc, mb);
 }
-__global__ __launch_bounds__(kBlock) void k_sc_quad_fold_eval(Fr *A, Fr *B, size_t q, Fr r, Fr *partials) {
+__global__ __launch_bounds__(kBlock) void k_sc_quad_fold_eval(Fr *A, Fr *B, size_t q, Fr r, Mailbox mb) {
     Fr acc[2] = {fr_zero(), fr_zero()};
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < q; i += (size_t)gridDim.x * blockDim.x) {
         Pair a = fold_pair(A, i, q, r), b = fold_pair(B, i, q, r);
         quad_accum(acc, a, b);
     }
-    store_partials<2>(acc, partials);
+    finish_in_kernel<2>(acc, mb);
 }
 __global__ __launch_bounds__(kBlock) void k_fold_top(Fr *Z, size_t half, Fr r) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x) {
@@ -319,27 +357,46 @@ template <int K> static void finish_round(DevCtx &c, int nblocks, int slot) {
     { KScope ks(c, KC_REDUCE); hipLaunchKernelGGL(k_reduce_partials<K>, 1, kBlock, 0, c.stream, (const Fr *)c.partials.p, nblocks, c.results.p + slot); }
     dev_fetch(c, c.results.p + slot, slot, K);
 }
-void dev_sc_cubic_eval(DevCtx &c, const Fr *A, const Fr *B, const Fr *C, const Fr *D, size_t len, int slot) {
-    size_t half = len / 2; int g = grid_for(half);
-    { KScope ks(c, KC_SC_CUBIC); hipLaunchKernelGGL(k_sc_cubic_eval, g, kBlock, 0, c.stream, A, B, C, D, half, c.partials.p); }
-    finish_round<3>(c, g, slot);
+Mailbox DevCtx::next_mailbox(int slot) {
+    Mailbox mb; mb.partials = partials.p; mb.counter = d_counter.p; mb.host_results = d_results_alias; mb.host_flag = d_flag_alias;
+    mb.seq = ++seq; mb.slot = slot; return mb;
 }
-void dev_sc_cubic_fold_eval(DevCtx &c, Fr *A, Fr *B, Fr *C, Fr *D, size_t len, const Fr &r, int slot) {
+void DevCtx::wait_ticket(unsigned long long ticket) {
+    volatile unsigned long long *f = h_flag;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0;; spins++) {
+        if (*f >= ticket) return;
+#if defined(__x86_64__)
+        _mm_pause();
+#endif
+        if ((spins & 0xffff) == 0xffff && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) {
+            OTTI_HIP(hipStreamSynchronize(stream));          // surfaces a device fault as an error instead of spinning forever
+            if (*f >= ticket) return;
+            throw Error(OTTI_ERR_INTERNAL, "sum-check round result never arrived");
+        }
+    }
+}
+unsigned long long dev_sc_cubic_eval(DevCtx &c, const Fr *A, const Fr *B, const Fr *C, const Fr *D, size_t len, int slot) {
+    size_t half = len / 2; int g = grid_for(half); Mailbox mb = c.next_mailbox(slot);
+    KScope ks(c, KC_SC_CUBIC); hipLaunchKernelGGL(k_sc_cubic_eval, g, kBlock, 0, c.stream, A, B, C, D, half, mb);
+    return mb.seq;
+}
+unsigned long long dev_sc_cubic_fold_eval(DevCtx &c, Fr *A, Fr *B, Fr *C, Fr *D, size_t len, const Fr &r, int slot) {
     if (len < 4) throw Error(OTTI_ERR_INTERNAL, "fold_eval needs len >= 4");
-    size_t q = len / 4; int g = grid_for(q);
-    { KScope ks(c, KC_SC_CUBIC); hipLaunchKernelGGL(k_sc_cubic_fold_eval, g, kBlock, 0, c.stream, A, B, C, D, q, r, c.partials.p); }
-    finish_round<3>(c, g, slot);
+    size_t q = len / 4; int g = grid_for(q); Mailbox mb = c.next_mailbox(slot);
+    KScope ks(c, KC_SC_CUBIC); hipLaunchKernelGGL(k_sc_cubic_fold_eval, g, kBlock, 0, c.stream, A, B, C, D, q, r, mb);
+    return mb.seq;
 }
-void dev_sc_quad_eval(DevCtx &c, const Fr *A, const Fr *B, size_t len, int slot) {
-    size_t half = len / 2; int g = grid_for(half);
-    { KScope ks(c, KC_SC_QUAD); hipLaunchKernelGGL(k_sc_quad_eval, g, kBlock, 0, c.stream, A, B, half, c.partials.p); }
-    finish_round<2>(c, g, slot);
+unsigned long long dev_sc_quad_eval(DevCtx &c, const Fr *A, const Fr *B, size_t len, int slot) {
+    size_t half = len / 2; int g = grid_for(half); Mailbox mb = c.next_mailbox(slot);
+    KScope ks(c, KC_SC_QUAD); hipLaunchKernelGGL(k_sc_quad_eval, g, kBlock, 0, c.stream, A, B, half, mb);
+    return mb.seq;
 }
-void dev_sc_quad_fold_eval(DevCtx &c, Fr *A, Fr *B, size_t len, const Fr &r, int slot) {
+unsigned long long dev_sc_quad_fold_eval(DevCtx &c, Fr *A, Fr *B, size_t len, const Fr &r, int slot) {
     if (len < 4) throw Error(OTTI_ERR_INTERNAL, "fold_eval needs len >= 4");
-    size_t q = len / 4; int g = grid_for(q);
-    { KScope ks(c, KC_SC_QUAD); hipLaunchKernelGGL(k_sc_quad_fold_eval, g, kBlock, 0, c.stream, A, B, q, r, c.partials.p); }
-    finish_round<2>(c, g, slot);
+    size_t q = len / 4; int g = grid_for(q); Mailbox mb = c.next_mailbox(slot);
+    KScope ks(c, KC_SC_QUAD); hipLaunchKernelGGL(k_sc_quad_fold_eval, g, kBlock, 0, c.stream, A, B, q, r, mb);
+    return mb.seq;
 }
 void dev_fold_top(DevCtx &c, Fr *Z, size_t len, const Fr &r) { size_t h = len / 2; if (h) hipLaunchKernelGGL(k_fold_top, grid_for(h), kBlock, 0, c.stream, Z, h, r); }
 void dev_fold_bot(DevCtx &c, const Fr *Z, Fr *out, size_t len, const Fr &r) { size_t h = len / 2; if (h) hipLaunchKernelGGL(k_fold_bot, grid_for(h), kBlock, 0, c.stream, Z, out, h, r); }
@@ -508,7 +565,13 @@ void dev_msm_rows(DevCtx &c, const DeviceGens &g, const Fr *dense, size_t stride
 }
 void DevCtx::sync() {
     OTTI_HIP(hipStreamSynchronize(stream));
-    for (size_t i = 0; i < pending_host_encode; i++) pt_encode(h_points + 32 * i, h_pts[i]);
+    if (pending_host_encode >= 2) {
+        SpinPool &pool = SpinPool::get(); const int nt = std::min<int>(pool.workers() + 1, (int)pending_host_encode);
+        const size_t n = pending_host_encode;
+        std::vector<std::function<void()>> tasks(nt);
+        for (int t = 0; t < nt; t++) tasks[t] = [this, t, nt, n] { for (size_t i = t; i < n; i += nt) pt_encode(h_points + 32 * i, h_pts[i]); };
+        pool.parallel(tasks.data(), nt);
+    } else if (pending_host_encode == 1) pt_encode(h_points, h_pts[0]);
     pending_host_encode = 0;
 }
 

@@ -7,7 +7,9 @@
 // 2-3 field elements (96 B) through a pinned buffer; the host hashes, derives the challenge, and launches the next
 // fused fold+evaluate kernel before finishing the round's O(1) sigma-protocol work, so the two overlap.
 #include "device.h"
+#include "pool.h"
 #include <chrono>
+#include <mutex>
 
 namespace otti {
 
@@ -15,8 +17,8 @@ static double now_ms() { return std::chrono::duration<double, std::milli>(std::c
 
 static int device_window_bits() {
     const char *e = getenv("OTTI_MSM_WINDOW");
-    int c = e ? atoi(e) : 8;
-    if (c < 4 || c > 16) c = 8;
+    int c = e ? atoi(e) : 12;
+    if (c < 4 || c > 16) c = 12;
     return c;
 }
 
@@ -61,19 +63,38 @@ void precompute_round_points(DevCtx &c, const DeviceGens &DG, const Gens &g, con
     dev_msm_rows(c, DG, nullptr, 0, 0, 4 * n, scratch.p, bases.data(), nb, true);
     c.sync();
     for (size_t j = 0; j < n; j++) { st.pre[j].delta = c.h_pts[4 * j]; st.pre[j].bp_h = c.h_pts[4 * j + 1]; st.pre[j].be_h = c.h_pts[4 * j + 2]; st.pre[j].rb_h = c.h_pts[4 * j + 3]; }
+    // compress the deltas now, off the per-round path, striped over the helper threads
+    SpinPool &pool = SpinPool::get(); const int nt = pool.workers() + 1;
+    std::vector<std::function<void()>> tasks(nt);
+    for (int t = 0; t < nt; t++) tasks[t] = [&, t] { for (size_t j = t; j < n; j += nt) pt_encode(st.pre[j].delta_c.b, st.pre[j].delta); };
+    pool.parallel(tasks.data(), nt);
 }
+// HBM working set of one proof; kept across proofs of the same shape (hipMalloc/hipFree of ~0.5 GB costs more than a sum-check)
 struct Scratch {
+    size_t N = 0, V = 0;
     DevBuf<Fr> T[4];          // eq(tau), Az, Bz, Cz  (N each)
     DevBuf<Fr> zw, ABC;       // phase-two working tables (2V each)
     DevBuf<Fr> eqs;           // eq-table scratch (3 * 4096)
     DevBuf<Fr> blinds, Lv, Rv, LZ, a, s, rows, extras, bound_scratch, pre;
+    void reserve(size_t n, size_t v, size_t Lsz, size_t Rsz, size_t lgR) {
+        if (n == N && v == V) return;
+        for (auto &t : T) t.alloc(n);
+        zw.alloc(2 * v); ABC.alloc(2 * v); eqs.alloc(3 * 4096);
+        blinds.alloc(Lsz); Lv.alloc(Lsz); Rv.alloc(Rsz); LZ.alloc(Rsz); a.alloc(Rsz); s.alloc(Rsz); rows.alloc(2 * Rsz);
+        extras.alloc(4 * (lgR + 1)); bound_scratch.alloc(64 * Rsz);
+        N = n; V = v;
+    }
 };
+Scratch &workspace() { static Scratch s; return s; }
 inline CPoint point_at(const DevCtx &c, size_t i) { CPoint p; memcpy(p.b, c.h_points + 32 * i, 32); return p; }
 }  // namespace
 
 std::vector<uint8_t> nizk_prove_resident(Instance &I, DeviceWitness &wit, Gens &g, const void *tlabel, size_t tlabel_len, const uint8_t *seed32,
                                          ProveTimings *tm) {
+    static std::mutex prove_mu;                                   // one stream, one workspace: proofs of a process run one at a time
+    std::lock_guard<std::mutex> lock(prove_mu);
     DevCtx &c = DevCtx::get();
+    SpinPool::Session pool_session;                               // helper threads spin for the duration of this proof
     ensure_device_objects(I, g);
     const DeviceInstance &DI = *I.dev; const DeviceGens &DG = *g.dev;
     const size_t N = I.num_cons, V = I.num_vars, nrx = ilog2(N), nry = ilog2(2 * V);
@@ -82,12 +103,9 @@ std::vector<uint8_t> nizk_prove_resident(Instance &I, DeviceWitness &wit, Gens &
     if (wit.inputs.size() != I.num_inputs) throw Error(OTTI_ERR_INVALID_NUM_INPUTS, "wrong number of inputs");
 
     double t_start = now_ms(), t0; ProveTimings T{};
-    Scratch S;
-    for (auto &t : S.T) t.alloc(N);
-    S.zw.alloc(2 * V); S.ABC.alloc(2 * V); S.eqs.alloc(3 * 4096);
-    S.blinds.alloc(Lsz); S.Lv.alloc(Lsz); S.Rv.alloc(Rsz); S.LZ.alloc(Rsz); S.a.alloc(Rsz); S.s.alloc(Rsz); S.rows.alloc(2 * Rsz);
     const size_t lgR = ilog2(Rsz);
-    S.extras.alloc(4 * (lgR + 1)); S.bound_scratch.alloc(64 * Rsz);
+    Scratch &S = workspace();
+    S.reserve(N, V, Lsz, Rsz, lgR);
     const Fr *d_vars = wit.z.p;
 
     Transcript tr(tlabel, tlabel_len);
@@ -131,17 +149,23 @@ std::vector<uint8_t> nizk_prove_resident(Instance &I, DeviceWitness &wit, Gens &
         st.claim = fr_zero(); st.blind_claim = fr_zero();
         { Term t2[2] = {{g.sc_1.G[0], fr_zero()}, {g.sc_1.h, fr_zero()}}; g.commit_terms_c(st.comm_claim.b, t2, 2); }
         P.sc1.comm_polys.resize(nrx); P.sc1.comm_evals.resize(nrx); P.sc1.proofs.resize(nrx);
-        dev_sc_cubic_eval(c, S.T[0].p, S.T[1].p, S.T[2].p, S.T[3].p, N, 0);
+        unsigned long long ticket = dev_sc_cubic_eval(c, S.T[0].p, S.T[1].p, S.T[2].p, S.T[3].p, N, 0);
+        double tw = 0, tb = 0, tl = 0, tf = 0, ta;
         for (size_t j = 0; j < nrx; j++) {
-            c.sync();
+            ta = now_ms(); c.wait_ticket(ticket); tw += now_ms() - ta;
             Fr ev[4] = {c.h_results[0], fr_sub(st.claim, c.h_results[0]), c.h_results[1], c.h_results[2]};
+            ta = now_ms();
             RoundPart1 p1 = sumcheck_round_begin(P.sc1, j, ev, 4, st, g, g.sc_4, tr);
+            tb += now_ms() - ta; ta = now_ms();
             P.rx[j] = p1.r_j;
             size_t len = N >> j;
-            if (len >= 4) dev_sc_cubic_fold_eval(c, S.T[0].p, S.T[1].p, S.T[2].p, S.T[3].p, len, p1.r_j, 0);
+            if (len >= 4) ticket = dev_sc_cubic_fold_eval(c, S.T[0].p, S.T[1].p, S.T[2].p, S.T[3].p, len, p1.r_j, 0);
             else for (auto &t : S.T) dev_fold_top(c, t.p, len, p1.r_j);
+            tl += now_ms() - ta; ta = now_ms();
             sumcheck_round_finish(P.sc1, j, p1, st, g, g.sc_4, tr);             // overlaps the device fold
+            tf += now_ms() - ta;
         }
+        if (getenv("OTTI_TRACE")) fprintf(stderr, "[otti] phase1 rounds=%zu wait %.3f begin %.3f launch %.3f finish %.3f ms\n", nrx, tw, tb, tl, tf);
         blind_claim_postsc1 = st.blinds_evals[nrx - 1];
     }
     for (int k = 0; k < 4; k++) dev_fetch(c, S.T[k].p, 8 + k, 1);
@@ -188,14 +212,14 @@ std::vector<uint8_t> nizk_prove_resident(Instance &I, DeviceWitness &wit, Gens &
         st.claim = claim2; st.blind_claim = blind_claim2;
         { Term t2[2] = {{g.sc_1.G[0], claim2}, {g.sc_1.h, blind_claim2}}; g.commit_terms_c(st.comm_claim.b, t2, 2); }
         P.sc2.comm_polys.resize(nry); P.sc2.comm_evals.resize(nry); P.sc2.proofs.resize(nry);
-        dev_sc_quad_eval(c, S.zw.p, S.ABC.p, 2 * V, 0);
+        unsigned long long ticket = dev_sc_quad_eval(c, S.zw.p, S.ABC.p, 2 * V, 0);
         for (size_t j = 0; j < nry; j++) {
-            c.sync();
+            c.wait_ticket(ticket);
             Fr ev[3] = {c.h_results[0], fr_sub(st.claim, c.h_results[0]), c.h_results[1]};
             RoundPart1 p1 = sumcheck_round_begin(P.sc2, j, ev, 3, st, g, g.sc_3, tr);
             P.ry[j] = p1.r_j;
             size_t len = (2 * V) >> j;
-            if (len >= 4) dev_sc_quad_fold_eval(c, S.zw.p, S.ABC.p, len, p1.r_j, 0);
+            if (len >= 4) ticket = dev_sc_quad_fold_eval(c, S.zw.p, S.ABC.p, len, p1.r_j, 0);
             else { dev_fold_top(c, S.zw.p, len, p1.r_j); dev_fold_top(c, S.ABC.p, len, p1.r_j); }
             sumcheck_round_finish(P.sc2, j, p1, st, g, g.sc_3, tr);
         }

@@ -105,7 +105,7 @@ Fr unipoly_eval(const Fr *c, size_t n, const Fr &r);
 // host work on the sequential Fiat-Shamir path is then 4+1+2+1 fixed-base terms instead of 5+2+2+5+2.
 struct RoundPre {
     Fr d[4], r_delta, r_beta;          // DotProductProof::prove draws: d_vec, r_delta, r_beta
-    Pt delta;                          // commit(d_vec, r_delta) over gens_n
+    Pt delta; CPoint delta_c;          // commit(d_vec, r_delta) over gens_n, and its compressed form
     Pt bp_h, be_h, rb_h;               // blinds_poly[j]*h_n, blinds_evals[j]*h_1, r_beta*h_1
 };
 struct SumcheckState { Fr claim; CPoint comm_claim; Fr blind_claim; std::vector<Fr> blinds_poly, blinds_evals; std::vector<RoundPre> pre; };

@@ -1,6 +1,7 @@
 // Host-side objects of the proving path: instance building, generator derivation, proof (de)serialisation, sigma protocols,
 // verifier, synthetic instances.  See spartan.h for what each piece replaces upstream.
 #include "spartan.h"
+#include "pool.h"
 #include <algorithm>
 #include <numeric>
 
@@ -229,8 +230,13 @@ RoundPart1 sumcheck_round_begin(ZKSumcheckProof &pf, size_t j, const Fr *evals, 
                                 const GensView &gn, Transcript &tr) {
     RoundPart1 p; p.ne = ne;
     unipoly_from_evals(p.poly, evals, ne);
-    Term t[4]; for (size_t i = 0; i < ne; i++) t[i] = {gn.G[i], p.poly[i]};
-    pf.comm_polys[j] = encode_sum(g.commit_terms(t, ne), st.pre[j].bp_h);               // commit(poly, blinds_poly[j]) over gens_n
+    // commit(poly, blinds_poly[j]) over gens_n: one fixed-base term per coefficient, spread over the helper threads
+    Pt part[4]; std::function<void()> tasks[4];
+    for (size_t i = 0; i < ne; i++) tasks[i] = [&, i] { Term t = {gn.G[i], p.poly[i]}; part[i] = g.commit_terms(&t, 1); };
+    SpinPool::get().parallel(tasks, (int)ne);
+    Pt sum = st.pre[j].bp_h;
+    for (size_t i = 0; i < ne; i++) sum = pt_add(sum, part[i]);
+    pt_encode(pf.comm_polys[j].b, sum);
     tr.append_point("comm_poly", pf.comm_polys[j].b);
     p.r_j = tr.challenge_scalar("challenge_nextround");
     return p;
@@ -249,16 +255,28 @@ void sumcheck_round_finish(ZKSumcheckProof &pf, size_t j, const RoundPart1 &p1, 
     Fr blind = fr_add(fr_mul(w[0], blind_sc), fr_mul(w[1], st.blinds_evals[j]));
     Fr a[4], pw = fr_one(), two = fr_from_u64(2);
     for (size_t i = 0; i < ne; i++) { a[i] = fr_add(fr_mul(w[0], i == 0 ? two : fr_one()), fr_mul(w[1], pw)); pw = fr_mul(pw, p1.r_j); }
-    // DotProductProof::prove(gens_1, gens_n, poly, blinds_poly[j], a, target, blind); Cx is this round's comm_poly
+    Fr ad = fr_zero(); for (size_t i = 0; i < ne; i++) ad = fr_add(ad, fr_mul(a[i], pre.d[i]));
+    // DotProductProof::prove(gens_1, gens_n, poly, blinds_poly[j], a, target, blind); Cx is this round's comm_poly.
+    // Cy = commit(target, blind) and beta = commit(<a,d>, r_beta) are independent: three concurrent pieces.
+    DotProductProof dp; Pt cy_g, cy_h; CPoint Cy;
+    std::function<void()> tasks[3] = {
+        [&] { Term t = {g.sc_1.G[0], target}; cy_g = g.commit_terms(&t, 1); },
+        [&] { Term t = {g.sc_1.h, blind}; cy_h = g.commit_terms(&t, 1); },
+        [&] { Term t = {g.sc_1.G[0], ad}; dp.beta = encode_sum(g.commit_terms(&t, 1), pre.rb_h); }};
+    SpinPool &pool = SpinPool::get();
+    int nw = pool.workers();
+    if (nw >= 2) {
+        pool.submit(0, tasks[1]); pool.submit(1, tasks[2]);
+        tasks[0](); pool.wait(0);
+        Cy = encode_sum(cy_g, cy_h);                                                      // overlaps the helper's beta compression
+        pool.wait(1);
+    } else { pool.parallel(tasks, 3); Cy = encode_sum(cy_g, cy_h); }
     tr.append_protocol_name("dot product proof");
     tr.append_point("Cx", pf.comm_polys[j].b);
-    CPoint Cy = commit_scalar(g, g.sc_1, target, blind); tr.append_point("Cy", Cy.b);
+    tr.append_point("Cy", Cy.b);
     tr.append_scalars("a", a, ne);
-    DotProductProof dp;
-    pt_encode(dp.delta.b, pre.delta); tr.append_point("delta", dp.delta.b);
-    Fr ad = fr_zero(); for (size_t i = 0; i < ne; i++) ad = fr_add(ad, fr_mul(a[i], pre.d[i]));
-    Term tb = {g.sc_1.G[0], ad};
-    dp.beta = encode_sum(g.commit_terms(&tb, 1), pre.rb_h); tr.append_point("beta", dp.beta.b);
+    dp.delta = pre.delta_c; tr.append_point("delta", dp.delta.b);
+    tr.append_point("beta", dp.beta.b);
     Fr c = tr.challenge_scalar("c");
     dp.z.resize(ne); for (size_t i = 0; i < ne; i++) dp.z[i] = fr_add(fr_mul(c, p1.poly[i]), pre.d[i]);
     dp.z_delta = fr_add(fr_mul(c, st.blinds_poly[j]), pre.r_delta); dp.z_beta = fr_add(fr_mul(c, blind), pre.r_beta);
