@@ -166,7 +166,8 @@ def main():
 
     cpu_baseline = None
     if not args.no_cpu_baseline:
-        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        cores = int(os.environ.get("OTTI_CPU_THREADS", min(avail, 16)))       # a 1-GPU box's CPU share is 16 cores
         clg = args.cpu_log2 if args.cpu_log2 is not None else lg
         cr = r if (clg == lg and rank == 0) else oa.synth_r1cs(1 << clg, ni, 1)
         ci, cg = orc.OInstance(cr["num_cons"], cr["num_vars"], cr["num_inputs"], cr["A"], cr["B"], cr["C"]), orc.OGens(cr["num_cons"], cr["num_vars"], cr["num_inputs"])
