@@ -213,3 +213,86 @@ def test_unsatisfying_witness_yields_rejected_proof():
     proof = oa.NIZK.prove(inst, v, i, gens)
     with pytest.raises(oa.ProofVerifyError):
         proof.verify(inst, i, gens)
+
+
+# ------------------------------------------------------------------------------------------------ compiler-like instance, CLI
+def _compiler_like_r1cs(rng, nc, nv, ni):
+    """satisfiable R1CS with 1..8 non-zeros per row, small coefficients, a heavily used constant column and one very long row"""
+    L = orc.L_ORDER
+    size_z = nv + 1 + ni
+    z = [int(rng.integers(0, 2 ** 63)) if rng.random() < 0.9 else int.from_bytes(rng.bytes(40), "little") % L for _ in range(size_z)]
+    z[nv] = 1
+    ents = {k: [] for k in "ABC"}
+
+    def lin(row, k_max, force_const):
+        cols = set(int(c) for c in rng.integers(0, size_z, size=int(rng.integers(1, k_max + 1))))
+        if force_const:
+            cols.add(nv)
+        terms = [(c, int(rng.integers(1, 1000)) if rng.random() < 0.8 else L - int(rng.integers(1, 1000))) for c in sorted(cols)]
+        return terms, sum(v * z[c] for c, v in terms) % L
+
+    for row in range(nc):
+        ta, a = lin(row, 300 if row == 3 else 8, rng.random() < 0.5)
+        tb, b = lin(row, 8, rng.random() < 0.5)
+        tc, c = lin(row, 6, False)
+        # fix C with one extra term on a non-zero variable so that <C,z> = a*b
+        fix = next(cc for cc in range(size_z) if z[cc] % L and cc not in dict(tc))
+        tc.append((fix, (a * b - c) * pow(z[fix], -1, L) % L))
+        for name, terms in (("A", ta), ("B", tb), ("C", tc)):
+            ents[name] += [(row, col, v) for col, v in terms]
+    mats = []
+    for name in "ABC":
+        e = np.zeros(len(ents[name]), dtype=oa.ENTRY_DTYPE)
+        e["row"] = [t[0] for t in ents[name]]; e["col"] = [t[1] for t in ents[name]]
+        e["val"] = np.array([np.frombuffer(t[2].to_bytes(32, "little"), dtype=np.uint8) for t in ents[name]])
+        mats.append(e)
+    to32 = lambda xs: np.array([np.frombuffer((x % L).to_bytes(32, "little"), dtype=np.uint8) for x in xs]).reshape(-1, 32)
+    return mats, to32(z[:nv]), to32(z[nv + 1:])
+
+
+def test_compiler_like_instance_with_heavy_rows_and_columns(rng):
+    nc, nv, ni = 700, 500, 6
+    (A, B, C), vars32, inputs32 = _compiler_like_r1cs(rng, nc, nv, ni)
+    inst = oa.Instance.new(nc, nv, ni, A, B, C); gens = oa.NIZKGens.new(nc, nv, ni)
+    v, i = oa.VarsAssignment.new(vars32), oa.InputsAssignment.new(inputs32)
+    assert inst.is_sat(v, i)
+    proof = oa.NIZK.prove(inst, v, i, gens, b"circ", b"\x33" * 32)
+    proof.verify(inst, i, gens, b"circ")
+    oi, og = orc.OInstance(nc, nv, ni, A, B, C), orc.OGens(nc, nv, ni)
+    oproof, _ = orc.nizk_prove(oi, vars32, inputs32, og, b"circ", b"\x33" * 32)
+    assert proof.bytes == oproof
+
+
+def test_spzk_cli_end_to_end(tmp_path):
+    import os
+    import subprocess
+    spzk = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "otti_amd", "spzk")
+    pre = str(tmp_path / "syn")
+    assert subprocess.run([spzk, "synth", "300", pre, "7", "4"], capture_output=True).returncode == 0
+    # the reference's argv [REF run.py:100], plus the additive reproducibility options
+    res = subprocess.run([spzk, "verify", "--nizk", pre + ".zkif", pre + ".inp.zkif", pre + ".wit.zkif", "--seed", "2a" * 32, "--proof-out", pre + ".proof"],
+                         capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    assert "Verification successful" in res.stdout and "prove_sc_phase_one" in res.stdout
+    r = oa.zkif_load(pre + ".zkif", pre + ".inp.zkif", pre + ".wit.zkif")
+    oi = orc.OInstance(r["num_cons"], r["num_vars"], r["num_inputs"], r["A"], r["B"], r["C"])
+    og = orc.OGens(r["num_cons"], r["num_vars"], r["num_inputs"])
+    oproof, _ = orc.nizk_prove(oi, r["vars"], r["inputs"], og, b"nizk_example", b"\x2a" * 32)
+    assert open(pre + ".proof", "rb").read() == oproof
+    # a corrupted witness must make the process fail (run.py checks the exit status on the LP path)
+    wit = bytearray(open(pre + ".wit.zkif", "rb").read()); wit[-40] ^= 1
+    open(pre + ".wit.zkif", "wb").write(bytes(wit))
+    res = subprocess.run([spzk, "verify", "--nizk", pre + ".zkif", pre + ".inp.zkif", pre + ".wit.zkif"], capture_output=True, text=True)
+    assert res.returncode != 0 and "Verification successful" not in res.stdout
+
+
+def test_golden_proof_digests_on_gpu():
+    import json
+    import os
+    golden = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "proofs.json")))
+    for g in golden:
+        r = oa.synth_r1cs(g["n"], g["num_inputs"], g["instance_seed"])
+        inst = oa.Instance.new(r["num_cons"], r["num_vars"], r["num_inputs"], r["A"], r["B"], r["C"])
+        gens = oa.NIZKGens.new(r["num_cons"], r["num_vars"], r["num_inputs"])
+        p = oa.NIZK.prove(inst, oa.VarsAssignment.new(r["vars"]), oa.InputsAssignment.new(r["inputs"]), gens, g["label"].encode(), bytes.fromhex(g["tape_seed"]))
+        assert len(p.bytes) == g["proof_len"] and hashlib.sha256(p.bytes).hexdigest() == g["proof_sha256"], g["n"]
