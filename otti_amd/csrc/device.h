@@ -53,6 +53,7 @@ struct DevCtx {
     DevBuf<unsigned> d_counter;                               // arrival counter of the publishing workgroups
     Mailbox next_mailbox(int slot);
     void wait_ticket(unsigned long long ticket);              // spin until the launch with that sequence number has delivered
+    DevBuf<Pt> msm_keep;                                      // row sums parked on the device (MSM_KEEP)
     DevBuf<Pt> msm_partial, msm_final;                        // [rows][chunks] partial sums, [rows] row sums
     Pt *h_pts = nullptr; size_t pending_host_encode = 0;      // pinned: row sums of small launches, compressed on the host in sync()
     uint8_t *h_points = nullptr;                              // pinned: compressed points coming back
@@ -113,9 +114,12 @@ void dev_fold_bot(DevCtx &c, const Fr *Z, Fr *out, size_t len, const Fr &r);
 void dev_fetch(DevCtx &c, const Fr *src, int slot, size_t n);              // async copy of n elements into h_results[slot..]
 // ---- K8: fixed-base MSM rows.  Row i: sum_j dense[i*stride + j] * P[j] (j < n_dense) + sum_e extra_s[i*n_extra+e] * P[extra_base[e]]
 // Compressed results land in c.h_points[32*i ..] after c.sync(); they also stay in c.d_points.
+enum { MSM_COMPRESSED = 0, MSM_RAW = 1, MSM_KEEP = 2 };
 void dev_msm_rows(DevCtx &c, const DeviceGens &g, const Fr *dense, size_t stride, size_t n_dense, size_t rows, const Fr *extra_s,
-                  const uint32_t *extra_base_host, size_t n_extra, bool raw_points = false);
-// raw_points: skip compression; after c.sync() the extended row sums are in c.h_pts[0..rows)
+                  const uint32_t *extra_base_host, size_t n_extra, int mode = MSM_COMPRESSED, const Pt *addend = nullptr);
+// MSM_RAW: skip compression; after c.sync() the extended row sums are in c.h_pts[0..rows).
+// MSM_KEEP: no output; the row sums stay on the device in c.msm_keep (to be passed as `addend` of a later launch, which then
+// compresses (row sum + addend)).  Lets the host draw the blinds while the device already sums the witness terms.
 // ---- K9: LZ[j] = sum_i Lv[i] * Z[i*R + j]
 void dev_poly_bound(DevCtx &c, const Fr *Z, size_t L, size_t R, const Fr *Lv, Fr *out, Fr *scratch /* >= 64*R */);
 // dot product of two device vectors -> h_results[slot]

@@ -1,6 +1,7 @@
 // See hash.h.  FIPS 202 Keccak-f[1600]; STROBE-128 per merlin's strobe.rs subset; Merlin v1.0 framing.
 #include "hash.h"
 #include <stdexcept>
+#include <string>
 #include <stdio.h>
 
 namespace otti {
@@ -101,6 +102,19 @@ RandomTape::RandomTape(const uint8_t seed32[32]) : t_("proof", 5) {
         fclose(f);
     }
     t_.append_scalar("init_randomness", fr_from_bytes_wide(w));
+}
+
+Fr RandomTape::random_scalar(const char *label) {
+    if (head_ < queue_.size()) {
+        if (strcmp(queue_[head_].first, label) != 0) throw std::logic_error(std::string("RandomTape: prefetched label '") + queue_[head_].first + "' but '" + label + "' was asked for");
+        return queue_[head_++].second;
+    }
+    return t_.challenge_scalar(label);
+}
+void RandomTape::prefetch(const std::vector<std::pair<const char *, size_t>> &schedule) {
+    if (head_ != queue_.size()) throw std::logic_error("RandomTape: prefetch with unread values pending");
+    queue_.clear(); head_ = 0;
+    for (auto &e : schedule) for (size_t i = 0; i < e.second; i++) queue_.emplace_back(e.first, t_.challenge_scalar(e.first));
 }
 
 }  // namespace otti

@@ -7,6 +7,7 @@
 #include <string.h>
 #include <string>
 #include <vector>
+#include <utility>
 #include "field.h"
 
 namespace otti {
@@ -56,10 +57,15 @@ private:
 class RandomTape {
 public:
     explicit RandomTape(const uint8_t seed32[32]);
-    Fr random_scalar(const char *label) { return t_.challenge_scalar(label); }
-    std::vector<Fr> random_vector(const char *label, size_t n) { return t_.challenge_vector(label, n); }
+    Fr random_scalar(const char *label);
+    std::vector<Fr> random_vector(const char *label, size_t n) { std::vector<Fr> v(n); for (auto &x : v) x = random_scalar(label); return v; }
+    // The tape is a transcript of its own: its outputs depend only on the seed and on the sequence of labels asked for.  The prover
+    // knows that sequence in advance, so it draws everything in one go (while the device is busy with the witness commitment);
+    // later random_scalar calls pop the queue and check that the label is the scheduled one.
+    void prefetch(const std::vector<std::pair<const char *, size_t>> &schedule);
 private:
     Transcript t_;
+    std::vector<std::pair<const char *, Fr>> queue_; size_t head_ = 0;
 };
 
 }  // namespace otti

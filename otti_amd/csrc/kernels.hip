@@ -12,6 +12,7 @@
 //   k_poly_bound_*       K9 DensePolynomial::bound
 //   k_bullet_step        K10 nizk/bullet.rs BulletReductionProof::prove scalar bookkeeping
 #include "device.h"
+#include "fp10.h"
 #include "pool.h"
 #include <stdio.h>
 #include <stdlib.h>
@@ -451,9 +452,12 @@ struct MsmArgs {
     Pt *partial;
 };
 __global__ __launch_bounds__(kBlock) void k_msm_rows(MsmArgs A) {
-    __shared__ uint32_t s_raw[(kMsmMaxChunk + 8) * 9];
+    // the recoded scalars (phases 1-2) and the reduction tree (phase 3) never live at the same time: one LDS region for both
+    constexpr size_t kRawBytes = (kMsmMaxChunk + 8) * 9 * sizeof(uint32_t), kTreeBytes = (kBlock / 2) * sizeof(P10);
+    __shared__ __attribute__((aligned(16))) unsigned char s_mem[kRawBytes > kTreeBytes ? kRawBytes : kTreeBytes];
     __shared__ uint32_t s_base[8];
-    __shared__ Pt sm[kBlock / 2];
+    uint32_t *s_raw = reinterpret_cast<uint32_t *>(s_mem);
+    P10 *sm = reinterpret_cast<P10 *>(s_mem);
     const size_t row = blockIdx.y; const uint32_t chunk_id = blockIdx.x;
     const size_t j0 = (size_t)chunk_id * A.chunk;
     const uint32_t n_here = (uint32_t)min((size_t)A.chunk, A.n_dense - j0);
@@ -469,8 +473,8 @@ __global__ __launch_bounds__(kBlock) void k_msm_rows(MsmArgs A) {
     }
     if (threadIdx.x < 8) s_base[threadIdx.x] = A.extra_base[threadIdx.x];
     __syncthreads();
-    // ---- phase 2: one mixed addition per (term, window) pair
-    Pt acc = pt_identity();
+    // ---- phase 2: one mixed addition per (term, window) pair, in 26/25-bit limbs (fp10.h)
+    P10 acc = p10_identity();
     const int w = threadIdx.x % A.W, tl = threadIdx.x / A.W;
     if (tl < A.lanes) {
         const int pos = w * A.c, limb = pos >> 5, off = pos & 31;
@@ -483,44 +487,50 @@ __global__ __launch_bounds__(kBlock) void k_msm_rows(MsmArgs A) {
             if (d == 0) continue;
             size_t base = t < n_here ? j0 + t : (size_t)s_base[t - n_here];
             uint32_t mag = (uint32_t)(d < 0 ? -d : d);
-            Niels e = A.table[base * WE + (size_t)w * A.E + (mag - 1)];
-            if (d < 0) { Fp tmp = e.yplusx; e.yplusx = e.yminusx; e.yminusx = tmp; e.xy2d = fp_neg(e.xy2d); }
-            acc = pt_madd(acc, e);
+            N10 e = n10_unpack(A.table[base * WE + (size_t)w * A.E + (mag - 1)]);
+            if (d < 0) e = n10_negate(e);
+            acc = p10_madd(acc, e);
         }
     }
-    // ---- phase 3: LDS tree
+    // ---- phase 3: LDS tree (reuses the scalar region: everyone must be done reading it)
+    __syncthreads();
+    const F10 d2 = f10_const(fp_2D());
     for (int sft = kBlock / 2; sft >= 1; sft >>= 1) {
         if ((int)threadIdx.x >= sft && (int)threadIdx.x < 2 * sft) sm[threadIdx.x - sft] = acc;
         __syncthreads();
-        if ((int)threadIdx.x < sft) acc = pt_add(acc, sm[threadIdx.x]);
+        if ((int)threadIdx.x < sft) acc = p10_add(acc, sm[threadIdx.x], d2);
         __syncthreads();
     }
-    if (threadIdx.x == 0) A.partial[row * A.nchunks + chunk_id] = acc;
+    if (threadIdx.x == 0) A.partial[row * A.nchunks + chunk_id] = p10_pack(acc);
 }
 // one wave per row: sum the row's chunk partials into one extended point
 __global__ __launch_bounds__(64) void k_msm_finish(const Pt *partial, uint32_t nchunks, size_t rows, Pt *final_pts) {
-    __shared__ Pt sm[32];
+    __shared__ P10 sm[32];
     const size_t row = blockIdx.x;
-    Pt acc = pt_identity();
-    for (uint32_t k = threadIdx.x; k < nchunks; k += 64) acc = pt_add(acc, partial[row * nchunks + k]);
+    const F10 d2 = f10_const(fp_2D());
+    P10 acc = p10_identity();
+    for (uint32_t k = threadIdx.x; k < nchunks; k += 64) acc = p10_add(acc, p10_unpack(partial[row * nchunks + k]), d2);
     for (int sft = 32; sft >= 1; sft >>= 1) {
         if ((int)threadIdx.x >= sft && (int)threadIdx.x < 2 * sft) sm[threadIdx.x - sft] = acc;
         __syncthreads();
-        if ((int)threadIdx.x < sft) acc = pt_add(acc, sm[threadIdx.x]);
+        if ((int)threadIdx.x < sft) acc = p10_add(acc, sm[threadIdx.x], d2);
         __syncthreads();
     }
-    if (threadIdx.x == 0) final_pts[row] = acc;
+    if (threadIdx.x == 0) final_pts[row] = p10_pack(acc);
 }
 // RFC 9496 encode, one lane per point (the inverse square root is a ~265-multiplication dependent chain: pack 64 rows per wave)
-__global__ __launch_bounds__(64) void k_encode_points(const Pt *pts, size_t n, uint8_t *out32) {
+__global__ __launch_bounds__(64) void k_encode_points(const Pt *pts, const Pt *addend, size_t n, uint8_t *out32) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
-    uint8_t enc[32]; pt_encode(enc, pts[i]);
+    P10 p = p10_unpack(pts[i]);
+    if (addend) p = p10_add(p, p10_unpack(addend[i]), f10_const(fp_2D()));
+    uint8_t enc[32]; p10_encode(enc, p);
     uint32_t *o = (uint32_t *)(out32 + 32 * i);
     for (int k = 0; k < 8; k++) o[k] = (uint32_t)enc[4 * k] | ((uint32_t)enc[4 * k + 1] << 8) | ((uint32_t)enc[4 * k + 2] << 16) | ((uint32_t)enc[4 * k + 3] << 24);
 }
 void dev_msm_rows(DevCtx &c, const DeviceGens &g, const Fr *dense, size_t stride, size_t n_dense, size_t rows, const Fr *extra_s,
-                  const uint32_t *extra_base, size_t n_extra, bool raw_points) {
+                  const uint32_t *extra_base, size_t n_extra, int mode, const Pt *addend) {
+    const bool raw_points = mode == MSM_RAW;
     if (n_extra > 8) throw Error(OTTI_ERR_INTERNAL, "msm: too many extra terms");
     if (!rows) return;
     MsmArgs A;
@@ -548,13 +558,17 @@ void dev_msm_rows(DevCtx &c, const DeviceGens &g, const Fr *dense, size_t stride
         hipLaunchKernelGGL(k_msm_finish, (unsigned)rows, 64, 0, c.stream, (const Pt *)c.msm_partial.p, (uint32_t)nchunks, rows, c.msm_final.p);
         finals = c.msm_final.p;
     }
-    if (raw_points) {
+    if (mode == MSM_KEEP) {
+        if (c.msm_keep.n < rows) c.msm_keep.alloc(rows);
+        OTTI_HIP(hipMemcpyAsync(c.msm_keep.p, finals, rows * sizeof(Pt), hipMemcpyDeviceToDevice, c.stream));
+        c.pending_host_encode = 0;
+    } else if (raw_points) {
         if (rows > kHostPtsCap) throw Error(OTTI_ERR_INTERNAL, "msm: too many raw rows");
         OTTI_HIP(hipMemcpyAsync(c.h_pts, finals, rows * sizeof(Pt), hipMemcpyDeviceToHost, c.stream));
         c.pending_host_encode = 0;
-    } else if (rows > kHostEncodeRows) {
+    } else if (rows > kHostEncodeRows || addend) {
         KScope ks(c, KC_MSM_FINISH);
-        hipLaunchKernelGGL(k_encode_points, (unsigned)((rows + 63) / 64), 64, 0, c.stream, finals, rows, c.d_points.p);
+        hipLaunchKernelGGL(k_encode_points, (unsigned)((rows + 63) / 64), 64, 0, c.stream, finals, addend, rows, c.d_points.p);
         OTTI_HIP(hipMemcpyAsync(c.h_points, c.d_points.p, rows * 32, hipMemcpyDeviceToHost, c.stream));
         c.pending_host_encode = 0;
     } else {

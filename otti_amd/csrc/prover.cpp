@@ -60,7 +60,7 @@ void precompute_round_points(DevCtx &c, const DeviceGens &DG, const Gens &g, con
     }
     if (scratch.n < sc.size()) scratch.alloc(sc.size());
     OTTI_HIP(hipMemcpyAsync(scratch.p, sc.data(), sc.size() * sizeof(Fr), hipMemcpyHostToDevice, c.stream));
-    dev_msm_rows(c, DG, nullptr, 0, 0, 4 * n, scratch.p, bases.data(), nb, true);
+    dev_msm_rows(c, DG, nullptr, 0, 0, 4 * n, scratch.p, bases.data(), nb, MSM_RAW);
     c.sync();
     for (size_t j = 0; j < n; j++) { st.pre[j].delta = c.h_pts[4 * j]; st.pre[j].bp_h = c.h_pts[4 * j + 1]; st.pre[j].be_h = c.h_pts[4 * j + 2]; st.pre[j].rb_h = c.h_pts[4 * j + 3]; }
     // compress the deltas now, off the per-round path, striped over the helper threads
@@ -114,13 +114,29 @@ std::vector<uint8_t> nizk_prove_resident(Instance &I, DeviceWitness &wit, Gens &
     tr.append_protocol_name("Spartan NIZK proof");
     tr.append_protocol_name("R1CS proof");
 
-    // ---- polycommit: DensePolynomial::commit (K8)
+    // ---- polycommit: DensePolynomial::commit (K8).  The witness terms of every row are summed first (no host input needed);
+    // meanwhile the host draws the whole random tape (its label sequence is known in advance); the blind terms are added last.
     t0 = now_ms();
+    dev_msm_rows(c, DG, d_vars, Rsz, Rsz, Lsz, nullptr, nullptr, 0, MSM_KEEP);
+    {
+        std::vector<std::pair<const char *, size_t>> sched;
+        auto sumcheck_sched = [&](size_t rounds, size_t ne) {
+            sched.push_back({"blinds_poly", rounds}); sched.push_back({"blinds_evals", rounds});
+            for (size_t j = 0; j < rounds; j++) { sched.push_back({"d_vec", ne}); sched.push_back({"r_delta", 1}); sched.push_back({"r_beta", 1}); }
+        };
+        sched.push_back({"poly_blinds", Lsz});
+        sumcheck_sched(nrx, 4);
+        for (const char *l : {"Az_blind", "Bz_blind", "Cz_blind", "prod_Az_Bz_blind", "t1", "t2", "b1", "b2", "b3", "b4", "b5", "r"}) sched.push_back({l, 1});
+        sumcheck_sched(nry, 3);
+        sched.push_back({"blind_eval", 1}); sched.push_back({"d", 1}); sched.push_back({"r_delta", 2});
+        sched.push_back({"blinds_vec_1", 2 * lgR}); sched.push_back({"blinds_vec_2", 2 * lgR}); sched.push_back({"r", 1});
+        tape.prefetch(sched);
+    }
     std::vector<Fr> blinds_vars = tape.random_vector("poly_blinds", Lsz);
     OTTI_HIP(hipMemcpyAsync(S.blinds.p, blinds_vars.data(), Lsz * sizeof(Fr), hipMemcpyHostToDevice, c.stream));
     {
         uint32_t hbase = g.pc_n.h;
-        dev_msm_rows(c, DG, d_vars, Rsz, Rsz, Lsz, S.blinds.p, &hbase, 1);
+        dev_msm_rows(c, DG, nullptr, 0, 0, Lsz, S.blinds.p, &hbase, 1, MSM_COMPRESSED, c.msm_keep.p);
         c.sync();
         P.comm_vars.resize(Lsz);
         for (size_t i = 0; i < Lsz; i++) P.comm_vars[i] = point_at(c, i);

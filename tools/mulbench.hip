@@ -5,6 +5,7 @@
 #include <vector>
 #include "field.h"
 #include "point.h"
+#include "fp10.h"
 using namespace otti;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
@@ -16,6 +17,10 @@ template <int MODE> __global__ void k_chain(Fp *io, int iters) {
     if (MODE == 2) for (int k = 0; k < iters; k++) a = fp_add(fp_sub(a, b), a);
     if (MODE == 3) { Pt p; p.X = a; p.Y = b; p.Z = fp_one(); p.T = fp_mul(a, b); Pt q = p; for (int k = 0; k < iters; k++) p = pt_add(p, q); a = p.X; }
     if (MODE == 4) { Pt p; p.X = a; p.Y = b; p.Z = fp_one(); p.T = fp_mul(a, b); Niels n; n.yplusx = a; n.yminusx = b; n.xy2d = p.T; for (int k = 0; k < iters; k++) p = pt_madd(p, n); a = p.X; }
+    if (MODE == 5) { F10 x = f10_unpack(a), y = f10_unpack(b); for (int k = 0; k < iters; k++) x = f10_mul(x, y); a = f10_pack(x); }
+    if (MODE == 6) { F10 x = f10_unpack(a); for (int k = 0; k < iters; k++) x = f10_sqr(x); a = f10_pack(x); }
+    if (MODE == 7) { P10 p; p.X = f10_unpack(a); p.Y = f10_unpack(b); p.Z = f10_one(); p.T = f10_mul(p.X, p.Y); N10 n; n.yplusx = p.X; n.yminusx = p.Y; n.xy2d = p.T; for (int k = 0; k < iters; k++) p = p10_madd(p, n); a = f10_pack(p.X); }
+    if (MODE == 8) { P10 p; p.X = f10_unpack(a); p.Y = f10_unpack(b); p.Z = f10_one(); p.T = f10_mul(p.X, p.Y); P10 q = p; F10 d2 = f10_const(fp_2D()); for (int k = 0; k < iters; k++) p = p10_add(p, q, d2); a = f10_pack(p.X); }
     io[2 * i] = a;
 }
 template <int MODE> static int run(const char *name, int blocks, int threads, int iters, double ops_per_iter) {
@@ -37,6 +42,14 @@ int main() {
     run<2>("fp_add+sub latency", 1, 64, 2000, 2);
     run<3>("pt_add latency (1 wave)", 1, 64, 500, 1);
     run<4>("pt_madd latency (1 wave)", 1, 64, 500, 1);
+    run<5>("f10_mul latency (1 wave)", 1, 64, 2000, 1);
+    run<6>("f10_sqr latency (1 wave)", 1, 64, 2000, 1);
+    run<7>("p10_madd latency (1 wave)", 1, 64, 500, 1);
+    run<8>("p10_add latency (1 wave)", 1, 64, 500, 1);
+    run<5>("f10_mul throughput", 256 * 8, 256, 500, 1);
+    run<6>("f10_sqr throughput", 256 * 8, 256, 500, 1);
+    run<7>("p10_madd throughput", 256 * 4, 256, 200, 1);
+    run<8>("p10_add throughput", 256 * 4, 256, 200, 1);
     run<0>("fp_mul throughput", 256 * 8, 256, 500, 1);
     run<1>("fr_mul throughput", 256 * 8, 256, 500, 1);
     run<4>("pt_madd throughput", 256 * 4, 256, 200, 1);
