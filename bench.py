@@ -46,7 +46,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     os.environ.setdefault("OTTI_DEVICE", str(local_rank))
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("OTTI_FORCE_DIST"):      # OTTI_FORCE_DIST: exercise the RCCL path on a one-GPU box
         import torch
         import torch.distributed as dist_mod
         dist = dist_mod

@@ -62,6 +62,9 @@ struct DevCtx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     static DevCtx &get();                                     // throws Error(OTTI_ERR_NO_DEVICE) when no device is usable
     void sync();
+    void wait_points(unsigned long long ticket);              // results of a dev_msm_rows launch: flag wait when fused, else stream sync
+    void encode_pending();
+    Pt *d_pts_alias = nullptr; DevBuf<unsigned> d_counter2;
     void ensure_points(size_t rows, size_t splits);
 };
 constexpr int kResultSlots = 64;
@@ -115,8 +118,9 @@ void dev_fetch(DevCtx &c, const Fr *src, int slot, size_t n);              // as
 // ---- K8: fixed-base MSM rows.  Row i: sum_j dense[i*stride + j] * P[j] (j < n_dense) + sum_e extra_s[i*n_extra+e] * P[extra_base[e]]
 // Compressed results land in c.h_points[32*i ..] after c.sync(); they also stay in c.d_points.
 enum { MSM_COMPRESSED = 0, MSM_RAW = 1, MSM_KEEP = 2 };
-void dev_msm_rows(DevCtx &c, const DeviceGens &g, const Fr *dense, size_t stride, size_t n_dense, size_t rows, const Fr *extra_s,
-                  const uint32_t *extra_base_host, size_t n_extra, int mode = MSM_COMPRESSED, const Pt *addend = nullptr);
+// returns a ticket: c.wait_points(ticket) returns once the compressed points are in c.h_points (ticket 0 = plain stream sync)
+unsigned long long dev_msm_rows(DevCtx &c, const DeviceGens &g, const Fr *dense, size_t stride, size_t n_dense, size_t rows, const Fr *extra_s,
+                                const uint32_t *extra_base_host, size_t n_extra, int mode = MSM_COMPRESSED, const Pt *addend = nullptr);
 // MSM_RAW: skip compression; after c.sync() the extended row sums are in c.h_pts[0..rows).
 // MSM_KEEP: no output; the row sums stay on the device in c.msm_keep (to be passed as `addend` of a later launch, which then
 // compresses (row sum + addend)).  Lets the host draw the blinds while the device already sums the witness terms.

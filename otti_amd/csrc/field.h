@@ -56,13 +56,91 @@ HD Fr fr_cond_sub_l(const uint32_t a[8], uint32_t top) {
     for (int i = 0; i < 8; i++) r.v[i] = use_t ? t[i] : a[i];
     return r;
 }
+#if defined(__HIP_DEVICE_COMPILE__)
+// gfx950: explicit carry chains (v_add_co/v_addc_co, v_subrev_co/v_subbrev_co with the modulus limbs as literals).  The portable
+// u64 formulation below compiles to 64-bit adds, shifts and moves on this target (~100 instructions per modular add instead of 24).
+__device__ __forceinline__ void fr_dev_cond_sub_l(Fr &r, const uint32_t s[8]) {
+    uint32_t t0, t1, t2, t3, t4, t5, t6, t7;
+    // (a literal and VCC in one VOP2 would exceed gfx9's one-constant-bus-read limit: the modulus limbs sit in VGPRs)
+    const uint32_t l0 = OTTI_L0, l1 = OTTI_L1, l2 = OTTI_L2, l3 = OTTI_L3, l7 = OTTI_L7;
+    asm("v_sub_co_u32_e32 %8, vcc, %16, %24\n\t"
+        "v_subb_co_u32_e32 %9, vcc, %17, %25, vcc\n\t"
+        "v_subb_co_u32_e32 %10, vcc, %18, %26, vcc\n\t"
+        "v_subb_co_u32_e32 %11, vcc, %19, %27, vcc\n\t"
+        "v_subbrev_co_u32_e32 %12, vcc, 0, %20, vcc\n\t"
+        "v_subbrev_co_u32_e32 %13, vcc, 0, %21, vcc\n\t"
+        "v_subbrev_co_u32_e32 %14, vcc, 0, %22, vcc\n\t"
+        "v_subb_co_u32_e32 %15, vcc, %23, %28, vcc\n\t"
+        "v_cndmask_b32_e32 %0, %8, %16, vcc\n\t"
+        "v_cndmask_b32_e32 %1, %9, %17, vcc\n\t"
+        "v_cndmask_b32_e32 %2, %10, %18, vcc\n\t"
+        "v_cndmask_b32_e32 %3, %11, %19, vcc\n\t"
+        "v_cndmask_b32_e32 %4, %12, %20, vcc\n\t"
+        "v_cndmask_b32_e32 %5, %13, %21, vcc\n\t"
+        "v_cndmask_b32_e32 %6, %14, %22, vcc\n\t"
+        "v_cndmask_b32_e32 %7, %15, %23, vcc"
+        : "=&v"(r.v[0]), "=&v"(r.v[1]), "=&v"(r.v[2]), "=&v"(r.v[3]), "=&v"(r.v[4]), "=&v"(r.v[5]), "=&v"(r.v[6]), "=&v"(r.v[7]),
+          "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7)
+        : "v"(s[0]), "v"(s[1]), "v"(s[2]), "v"(s[3]), "v"(s[4]), "v"(s[5]), "v"(s[6]), "v"(s[7]),
+          "v"(l0), "v"(l1), "v"(l2), "v"(l3), "v"(l7)
+        : "vcc");
+}
+#endif
 HD Fr fr_add(const Fr &a, const Fr &b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t s[8]; Fr r;
+    asm("v_add_co_u32_e32 %0, vcc, %8, %16\n\t"
+        "v_addc_co_u32_e32 %1, vcc, %9, %17, vcc\n\t"
+        "v_addc_co_u32_e32 %2, vcc, %10, %18, vcc\n\t"
+        "v_addc_co_u32_e32 %3, vcc, %11, %19, vcc\n\t"
+        "v_addc_co_u32_e32 %4, vcc, %12, %20, vcc\n\t"
+        "v_addc_co_u32_e32 %5, vcc, %13, %21, vcc\n\t"
+        "v_addc_co_u32_e32 %6, vcc, %14, %22, vcc\n\t"
+        "v_addc_co_u32_e32 %7, vcc, %15, %23, vcc"
+        : "=&v"(s[0]), "=&v"(s[1]), "=&v"(s[2]), "=&v"(s[3]), "=&v"(s[4]), "=&v"(s[5]), "=&v"(s[6]), "=&v"(s[7])
+        : "v"(a.v[0]), "v"(a.v[1]), "v"(a.v[2]), "v"(a.v[3]), "v"(a.v[4]), "v"(a.v[5]), "v"(a.v[6]), "v"(a.v[7]),
+          "v"(b.v[0]), "v"(b.v[1]), "v"(b.v[2]), "v"(b.v[3]), "v"(b.v[4]), "v"(b.v[5]), "v"(b.v[6]), "v"(b.v[7])
+        : "vcc");
+    fr_dev_cond_sub_l(r, s);                  // a,b < l < 2^253: no carry out of 256 bits; subtract l iff s >= l
+    return r;
+#else
     uint32_t s[8]; uint64_t c = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) { c += (uint64_t)a.v[i] + b.v[i]; s[i] = (uint32_t)c; c >>= 32; }
     return fr_cond_sub_l(s, 0);               // a,b < l < 2^253: no carry out of 256 bits
+#endif
 }
 HD Fr fr_sub(const Fr &a, const Fr &b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t d[8], m; Fr r;
+    asm("v_sub_co_u32_e32 %0, vcc, %9, %17\n\t"
+        "v_subb_co_u32_e32 %1, vcc, %10, %18, vcc\n\t"
+        "v_subb_co_u32_e32 %2, vcc, %11, %19, vcc\n\t"
+        "v_subb_co_u32_e32 %3, vcc, %12, %20, vcc\n\t"
+        "v_subb_co_u32_e32 %4, vcc, %13, %21, vcc\n\t"
+        "v_subb_co_u32_e32 %5, vcc, %14, %22, vcc\n\t"
+        "v_subb_co_u32_e32 %6, vcc, %15, %23, vcc\n\t"
+        "v_subb_co_u32_e32 %7, vcc, %16, %24, vcc\n\t"
+        "v_cndmask_b32_e64 %8, 0, -1, vcc"
+        : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(d[6]), "=&v"(d[7]), "=&v"(m)
+        : "v"(a.v[0]), "v"(a.v[1]), "v"(a.v[2]), "v"(a.v[3]), "v"(a.v[4]), "v"(a.v[5]), "v"(a.v[6]), "v"(a.v[7]),
+          "v"(b.v[0]), "v"(b.v[1]), "v"(b.v[2]), "v"(b.v[3]), "v"(b.v[4]), "v"(b.v[5]), "v"(b.v[6]), "v"(b.v[7])
+        : "vcc");
+    uint32_t l0 = OTTI_L0 & m, l1 = OTTI_L1 & m, l2 = OTTI_L2 & m, l3 = OTTI_L3 & m, l7 = OTTI_L7 & m;
+    asm("v_add_co_u32_e32 %0, vcc, %8, %16\n\t"
+        "v_addc_co_u32_e32 %1, vcc, %9, %17, vcc\n\t"
+        "v_addc_co_u32_e32 %2, vcc, %10, %18, vcc\n\t"
+        "v_addc_co_u32_e32 %3, vcc, %11, %19, vcc\n\t"
+        "v_addc_co_u32_e32 %4, vcc, 0, %12, vcc\n\t"
+        "v_addc_co_u32_e32 %5, vcc, 0, %13, vcc\n\t"
+        "v_addc_co_u32_e32 %6, vcc, 0, %14, vcc\n\t"
+        "v_addc_co_u32_e32 %7, vcc, %20, %15, vcc"
+        : "=&v"(r.v[0]), "=&v"(r.v[1]), "=&v"(r.v[2]), "=&v"(r.v[3]), "=&v"(r.v[4]), "=&v"(r.v[5]), "=&v"(r.v[6]), "=&v"(r.v[7])
+        : "v"(d[0]), "v"(d[1]), "v"(d[2]), "v"(d[3]), "v"(d[4]), "v"(d[5]), "v"(d[6]), "v"(d[7]),
+          "v"(l0), "v"(l1), "v"(l2), "v"(l3), "v"(l7)
+        : "vcc");
+    return r;
+#else
     uint32_t s[8]; uint64_t br = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) { uint64_t d = (uint64_t)a.v[i] - b.v[i] - br; s[i] = (uint32_t)d; br = (d >> 32) & 1; }
@@ -71,6 +149,7 @@ HD Fr fr_sub(const Fr &a, const Fr &b) {
 #pragma unroll
     for (int i = 0; i < 8; i++) { c += (uint64_t)s[i] + (fr_L(i) & m); r.v[i] = (uint32_t)c; c >>= 32; }
     return r;
+#endif
 }
 HD Fr fr_neg(const Fr &a) { return fr_sub(fr_zero(), a); }
 HD Fr fr_dbl(const Fr &a) { return fr_add(a, a); }
@@ -102,30 +181,10 @@ __device__ __forceinline__ uint32_t col_shift(uint64_t &lohi, uint32_t &ex) {
 HD Fr fr_mul(const Fr &a, const Fr &b) {
 #if defined(__HIP_DEVICE_COMPILE__)
     // product scanning with the Montgomery reduction interleaved column by column (FIPS): column k collects a_i*b_(k-i) and
-    // m_i*l_(k-i); m_k makes the column's low word vanish.  l has limbs 4..6 == 0 and limb 7 == 2^28.
-    const uint32_t Lk[8] = {OTTI_L0, OTTI_L1, OTTI_L2, OTTI_L3, 0u, 0u, 0u, OTTI_L7};
-    uint32_t m[8], t[9];
-    uint64_t acc = 0; uint32_t ex = 0;
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-#pragma unroll
-        for (int i = 0; i <= k; i++) mac96(acc, ex, a.v[i], b.v[k - i]);
-#pragma unroll
-        for (int i = 0; i < k; i++) if (Lk[k - i] != 0u) mac96s(acc, ex, m[i], Lk[k - i]);
-        m[k] = (uint32_t)acc * OTTI_LINV32;
-        mac96s(acc, ex, m[k], OTTI_L0);
-        (void)col_shift(acc, ex);
-    }
-#pragma unroll
-    for (int k = 8; k < 16; k++) {
-#pragma unroll
-        for (int i = k - 7; i < 8; i++) mac96(acc, ex, a.v[i], b.v[k - i]);
-#pragma unroll
-        for (int i = k - 7; i < 8; i++) if (Lk[k - i] != 0u) mac96s(acc, ex, m[i], Lk[k - i]);
-        t[k - 8] = col_shift(acc, ex);
-    }
-    t[8] = (uint32_t)acc;
-    return fr_cond_sub_l(t, t[8]);
+    // m_i*l_(k-i); m_k makes the column's low word vanish.  l has limbs 4..6 == 0.  Body generated by gen_fr_mul.py.
+#include "fr_mul_gfx950.inc"
+    // a, b < l: the Montgomery product is < 2l < 2^254, so t[8] == 0 and one conditional subtraction finishes
+    Fr r; fr_dev_cond_sub_l(r, t); return r;
 #else
     typedef unsigned __int128 u128;
     static const uint64_t L[4] = {0x5812631a5cf5d3edULL, 0x14def9dea2f79cd6ULL, 0, 0x1000000000000000ULL};

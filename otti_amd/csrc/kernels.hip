@@ -78,7 +78,11 @@ void DevCtx::ensure_points(size_t rows, size_t splits) {
         OTTI_HIP(hipHostMalloc((void **)&h_points, rows * 32, hipHostMallocDefault));
         d_points.alloc(rows * 32); msm_final.alloc(rows); points_cap = rows;
     }
-    if (!h_pts) OTTI_HIP(hipHostMalloc((void **)&h_pts, kHostPtsCap * sizeof(Pt), hipHostMallocDefault));
+    if (!h_pts) {
+        OTTI_HIP(hipHostMalloc((void **)&h_pts, kHostPtsCap * sizeof(Pt), hipHostMallocDefault));
+        OTTI_HIP(hipHostGetDevicePointer((void **)&d_pts_alias, h_pts, 0));
+        d_counter2.alloc(1); OTTI_HIP(hipMemset(d_counter2.p, 0, sizeof(unsigned)));
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ kernel timing
@@ -101,6 +105,37 @@ void KStats::flush() {
     used = 0;
 }
 void KStats::reset() { used = 0; for (int k = 0; k < KC_COUNT; k++) { total_ms[k] = 0; count[k] = 0; } }
+
+// ------------------------------------------------------------------------------------------------ inter-workgroup hand-off
+// Publishing a workgroup's partial result to the LAST workgroup of the same launch.  A per-workgroup agent release fence
+// (buffer_wbl2) serialises on the XCD's L2 and cost ~100 us over a 2048-workgroup grid; instead every handed-off byte is written
+// with write-through (sc1) stores and read with sc1 loads (8-byte relaxed agent-scope atomics lower to exactly those), the storing
+// lane drains its stores (s_waitcnt vmcnt(0)) before its agent-scope counter add, and the last arriver's other waves read only
+// after a workgroup barrier behind the lane whose add returned last (MI355X guide, "valid forms", sc1 row).
+__device__ __forceinline__ void store_words_sc1(void *dst, const uint32_t *w, int nwords) {
+    unsigned long long *p = reinterpret_cast<unsigned long long *>(dst);
+    for (int i = 0; i < nwords / 2; i++)
+        __hip_atomic_store(p + i, (unsigned long long)w[2 * i] | ((unsigned long long)w[2 * i + 1] << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void load_words_sc1(uint32_t *w, const void *src, int nwords) {
+    const unsigned long long *p = reinterpret_cast<const unsigned long long *>(src);
+    for (int i = 0; i < nwords / 2; i++) {
+        unsigned long long v = __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        w[2 * i] = (uint32_t)v; w[2 * i + 1] = (uint32_t)(v >> 32);
+    }
+}
+// true in every thread of exactly one workgroup: the last one to call it in this launch (counter is left at zero for the next launch)
+__device__ __forceinline__ bool arrive_and_check_last(unsigned *counter, unsigned total) {
+    __shared__ int s_is_last;
+    if (threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this lane's sc1 stores have left
+        unsigned old = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_is_last = (old == total - 1) ? 1 : 0;
+        if (s_is_last) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    return s_is_last != 0;
+}
 
 // ------------------------------------------------------------------------------------------------ wave / block reductions of Fr
 __device__ __forceinline__ Fr shfl_xor_fr(const Fr &x, int mask) {
@@ -290,56 +325,69 @@ template <int K> __device__ __forceinline__ void store_partials(Fr (&acc)[K], Fr
 // (agent-scope counter; release/acquire per the gfx950 inter-workgroup recipe) adds them up, writes the K totals straight into
 // pinned host memory and then stores the launch's sequence number into a host-visible flag the prover thread is spinning on.
 template <int K> __device__ __forceinline__ void finish_in_kernel(Fr (&acc)[K], const Mailbox &mb) {
-    __shared__ int s_last;
     block_reduce<K>(acc);
     if (gridDim.x > 1) {
-        if (threadIdx.x == 0) {
-            for (int k = 0; k < K; k++) mb.partials[(size_t)blockIdx.x * K + k] = acc[k];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            unsigned old = __hip_atomic_fetch_add(mb.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_last = (old == gridDim.x - 1) ? 1 : 0;
-        }
-        __syncthreads();
-        if (!s_last) return;
-        if (threadIdx.x == 0) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-        __syncthreads();
+        if (threadIdx.x == 0) for (int k = 0; k < K; k++) store_words_sc1(&mb.partials[(size_t)blockIdx.x * K + k], acc[k].v, 8);
+        if (!arrive_and_check_last(mb.counter, gridDim.x)) return;
         for (int k = 0; k < K; k++) acc[k] = fr_zero();
         for (unsigned b = threadIdx.x; b < gridDim.x; b += blockDim.x)
-            for (int k = 0; k < K; k++) acc[k] = fr_add(acc[k], mb.partials[(size_t)b * K + k]);
+            for (int k = 0; k < K; k++) { Fr t; load_words_sc1(t.v, &mb.partials[(size_t)b * K + k], 8); acc[k] = fr_add(acc[k], t); }
         block_reduce<K>(acc);
     }
     if (threadIdx.x == 0) {
         for (int k = 0; k < K; k++) mb.host_results[mb.slot + k] = acc[k];
-        if (gridDim.x > 1) __hip_atomic_store(mb.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __threadfence_system();
         __hip_atomic_store(mb.host_flag, mb.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
+// All of an item's loads are issued before any arithmetic so that their HBM latency is paid once per item, not once per table.
 __global__ __launch_bounds__(kBlock) void k_sc_cubic_eval(const Fr *A, const Fr *B, const Fr *C, const Fr *D, size_t half, Mailbox mb) {
     Fr acc[3] = {fr_zero(), fr_zero(), fr_zero()};
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x)
-        cubic_accum(acc, load_pair(A, i, half), load_pair(B, i, half), load_pair(C, i, half), load_pair(D, i, half));
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x) {
+        Pair a, b, c, d;
+        a.lo = A[i]; a.hi = A[i + half]; b.lo = B[i]; b.hi = B[i + half]; c.lo = C[i]; c.hi = C[i + half]; d.lo = D[i]; d.hi = D[i + half];
+        __builtin_amdgcn_sched_barrier(0);                    // keep the scheduler from sinking the loads next to their uses
+        cubic_accum(acc, a, b, c, d);
+    }
     finish_in_kernel<3>(acc, mb);
+}
+__device__ __forceinline__ Pair fold_regs(const Fr &x0, const Fr &x1, const Fr &x2, const Fr &x3, const Fr &r) {
+    Pair p; p.lo = fr_add(x0, fr_mul(r, fr_sub(x2, x0))); p.hi = fr_add(x1, fr_mul(r, fr_sub(x3, x1))); return p;
 }
 __global__ __launch_bounds__(kBlock) void k_sc_cubic_fold_eval(Fr *A, Fr *B, Fr *C, Fr *D, size_t q, Fr r, Mailbox mb) {
     Fr acc[3] = {fr_zero(), fr_zero(), fr_zero()};
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < q; i += (size_t)gridDim.x * blockDim.x) {
-        Pair a = fold_pair(A, i, q, r), b = fold_pair(B, i, q, r), c = fold_pair(C, i, q, r), d = fold_pair(D, i, q, r);
+        Fr a0 = A[i], a1 = A[i + q], a2 = A[i + 2 * q], a3 = A[i + 3 * q];
+        Fr b0 = B[i], b1 = B[i + q], b2 = B[i + 2 * q], b3 = B[i + 3 * q];
+        Fr c0 = C[i], c1 = C[i + q], c2 = C[i + 2 * q], c3 = C[i + 3 * q];
+        Fr d0 = D[i], d1 = D[i + q], d2 = D[i + 2 * q], d3 = D[i + 3 * q];
+        __builtin_amdgcn_sched_barrier(0);
+        Pair a = fold_regs(a0, a1, a2, a3, r); A[i] = a.lo; A[i + q] = a.hi;
+        Pair b = fold_regs(b0, b1, b2, b3, r); B[i] = b.lo; B[i + q] = b.hi;
+        Pair c = fold_regs(c0, c1, c2, c3, r); C[i] = c.lo; C[i + q] = c.hi;
+        Pair d = fold_regs(d0, d1, d2, d3, r); D[i] = d.lo; D[i + q] = d.hi;
         cubic_accum(acc, a, b, c, d);
     }
     finish_in_kernel<3>(acc, mb);
 }
 __global__ __launch_bounds__(kBlock) void k_sc_quad_eval(const Fr *A, const Fr *B, size_t half, Mailbox mb) {
     Fr acc[2] = {fr_zero(), fr_zero()};
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x)
-        quad_accum(acc, load_pair(A, i, half), load_pair(B, i, half));
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x) {
+        Pair a, b;
+        a.lo = A[i]; a.hi = A[i + half]; b.lo = B[i]; b.hi = B[i + half];
+        __builtin_amdgcn_sched_barrier(0);
+        quad_accum(acc, a, b);
+    }
     finish_in_kernel<2>(acc, mb);
 }
 __global__ __launch_bounds__(kBlock) void k_sc_quad_fold_eval(Fr *A, Fr *B, size_t q, Fr r, Mailbox mb) {
     Fr acc[2] = {fr_zero(), fr_zero()};
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < q; i += (size_t)gridDim.x * blockDim.x) {
-        Pair a = fold_pair(A, i, q, r), b = fold_pair(B, i, q, r);
+        Fr a0 = A[i], a1 = A[i + q], a2 = A[i + 2 * q], a3 = A[i + 3 * q];
+        Fr b0 = B[i], b1 = B[i + q], b2 = B[i + 2 * q], b3 = B[i + 3 * q];
+        __builtin_amdgcn_sched_barrier(0);
+        Pair a = fold_regs(a0, a1, a2, a3, r); A[i] = a.lo; A[i + q] = a.hi;
+        Pair b = fold_regs(b0, b1, b2, b3, r); B[i] = b.lo; B[i + q] = b.hi;
         quad_accum(acc, a, b);
     }
     finish_in_kernel<2>(acc, mb);
@@ -450,6 +498,9 @@ struct MsmArgs {
     const Fr *extra_s; uint32_t extra_base[8]; int n_extra;
     uint32_t K[9];                                                  // recoding constant (288 bits)
     Pt *partial;
+    // fused finish (rows <= 2, 1 < nchunks <= 128): the last workgroup to arrive sums every row's partials and mails the extended
+    // row sums to pinned host memory, then raises the host flag — no finish launch, no copy, no stream synchronise
+    int fuse; uint32_t rows; unsigned *counter; Pt *host_pts; unsigned long long *host_flag; unsigned long long seq;
 };
 __global__ __launch_bounds__(kBlock) void k_msm_rows(MsmArgs A) {
     // the recoded scalars (phases 1-2) and the reduction tree (phase 3) never live at the same time: one LDS region for both
@@ -501,7 +552,26 @@ __global__ __launch_bounds__(kBlock) void k_msm_rows(MsmArgs A) {
         if ((int)threadIdx.x < sft) acc = p10_add(acc, sm[threadIdx.x], d2);
         __syncthreads();
     }
-    if (threadIdx.x == 0) A.partial[row * A.nchunks + chunk_id] = p10_pack(acc);
+    if (!A.fuse) { if (threadIdx.x == 0) A.partial[row * A.nchunks + chunk_id] = p10_pack(acc); return; }
+    if (threadIdx.x == 0) { Pt pk = p10_pack(acc); store_words_sc1(&A.partial[row * A.nchunks + chunk_id], pk.X.v, 32); }
+    if (!arrive_and_check_last(A.counter, gridDim.x * gridDim.y)) return;
+    {   // 128 threads per row: one partial each, 7-level tree
+        const uint32_t r = threadIdx.x >> 7, idx = threadIdx.x & 127;
+        P10 sum = p10_identity();
+        if (r < A.rows && idx < A.nchunks) { Pt pk; load_words_sc1(pk.X.v, &A.partial[(size_t)r * A.nchunks + idx], 32); sum = p10_unpack(pk); }
+        for (int sft = 64; sft >= 1; sft >>= 1) {
+            if ((int)idx >= sft && (int)idx < 2 * sft) sm[r * 64 + idx - sft] = sum;
+            __syncthreads();
+            if ((int)idx < sft) sum = p10_add(sum, sm[r * 64 + idx], d2);
+            __syncthreads();
+        }
+        if (idx == 0 && r < A.rows) { A.host_pts[r] = p10_pack(sum); __threadfence_system(); }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence_system();
+            __hip_atomic_store(A.host_flag, A.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 // one wave per row: sum the row's chunk partials into one extended point
 __global__ __launch_bounds__(64) void k_msm_finish(const Pt *partial, uint32_t nchunks, size_t rows, Pt *final_pts) {
@@ -528,11 +598,11 @@ __global__ __launch_bounds__(64) void k_encode_points(const Pt *pts, const Pt *a
     uint32_t *o = (uint32_t *)(out32 + 32 * i);
     for (int k = 0; k < 8; k++) o[k] = (uint32_t)enc[4 * k] | ((uint32_t)enc[4 * k + 1] << 8) | ((uint32_t)enc[4 * k + 2] << 16) | ((uint32_t)enc[4 * k + 3] << 24);
 }
-void dev_msm_rows(DevCtx &c, const DeviceGens &g, const Fr *dense, size_t stride, size_t n_dense, size_t rows, const Fr *extra_s,
-                  const uint32_t *extra_base, size_t n_extra, int mode, const Pt *addend) {
+unsigned long long dev_msm_rows(DevCtx &c, const DeviceGens &g, const Fr *dense, size_t stride, size_t n_dense, size_t rows, const Fr *extra_s,
+                                const uint32_t *extra_base, size_t n_extra, int mode, const Pt *addend) {
     const bool raw_points = mode == MSM_RAW;
     if (n_extra > 8) throw Error(OTTI_ERR_INTERNAL, "msm: too many extra terms");
-    if (!rows) return;
+    if (!rows) return 0;
     MsmArgs A;
     A.table = g.table.p; A.c = g.c; A.W = g.W; A.E = (uint32_t)g.E; A.lanes = kBlock / g.W;
     A.dense = dense; A.stride = stride; A.n_dense = n_dense; A.extra_s = extra_s; A.n_extra = (int)n_extra;
@@ -549,8 +619,11 @@ void dev_msm_rows(DevCtx &c, const DeviceGens &g, const Fr *dense, size_t stride
     for (int w = 0; w < g.W; w++) { int bit = g.c - 1 + g.c * w; A.K[bit >> 5] |= 1u << (bit & 31); }
     c.ensure_points(rows, nchunks);
     A.partial = c.msm_partial.p;
+    A.fuse = (mode == MSM_COMPRESSED && !addend && rows <= 2 && nchunks > 1 && nchunks <= 128) ? 1 : 0;
+    A.rows = (uint32_t)rows; A.counter = c.d_counter2.p; A.host_pts = c.d_pts_alias; A.host_flag = c.d_flag_alias; A.seq = A.fuse ? ++c.seq : 0;
     dim3 grid((unsigned)nchunks, (unsigned)rows);
     { KScope ks(c, KC_MSM_ROWS); hipLaunchKernelGGL(k_msm_rows, grid, kBlock, 0, c.stream, A); }
+    if (A.fuse) { c.pending_host_encode = rows; return A.seq; }
     // rows with a single chunk need no finish pass: their partial IS the row sum
     const Pt *finals = c.msm_partial.p;
     if (nchunks > 1) {
@@ -576,9 +649,18 @@ void dev_msm_rows(DevCtx &c, const DeviceGens &g, const Fr *dense, size_t stride
         OTTI_HIP(hipMemcpyAsync(c.h_pts, finals, rows * sizeof(Pt), hipMemcpyDeviceToHost, c.stream));
         c.pending_host_encode = rows;
     }
+    return 0;
+}
+void DevCtx::wait_points(unsigned long long ticket) {
+    if (!ticket) { sync(); return; }
+    wait_ticket(ticket);
+    encode_pending();
 }
 void DevCtx::sync() {
     OTTI_HIP(hipStreamSynchronize(stream));
+    encode_pending();
+}
+void DevCtx::encode_pending() {
     if (pending_host_encode >= 2) {
         SpinPool &pool = SpinPool::get(); const int nt = std::min<int>(pool.workers() + 1, (int)pending_host_encode);
         const size_t n = pending_host_encode;

@@ -265,12 +265,13 @@ std::vector<uint8_t> nizk_prove_resident(Instance &I, DeviceWitness &wit, Gens &
         tr.append_protocol_name("dot product proof (log)");
         Fr d = tape.random_scalar("d"), r_delta = tape.random_scalar("r_delta"), r_beta = tape.random_scalar("r_delta");   // sic: upstream reuses the label
         std::vector<Fr> bv1 = tape.random_vector("blinds_vec_1", 2 * lgR), bv2 = tape.random_vector("blinds_vec_2", 2 * lgR);
+        unsigned long long tk_cx = 0;
         {   // Cx = commit(LZ, LZ_blind) over gens_n
             OTTI_HIP(hipMemcpyAsync(S.extras.p, &LZ_blind, sizeof(Fr), hipMemcpyHostToDevice, c.stream));
             uint32_t hb = g.pc_n.h;
-            dev_msm_rows(c, DG, S.LZ.p, Rsz, Rsz, 1, S.extras.p, &hb, 1);
+            tk_cx = dev_msm_rows(c, DG, S.LZ.p, Rsz, Rsz, 1, S.extras.p, &hb, 1);
         }
-        c.sync();
+        c.wait_points(tk_cx);
         const Fr eval_vars_at_ry = c.h_results[12];
         CPoint Cx = point_at(c, 0);
         tr.append_point("Cx", Cx.b);
@@ -288,8 +289,8 @@ std::vector<uint8_t> nizk_prove_resident(Instance &I, DeviceWitness &wit, Gens &
         dev_bullet_step(c, S.a.p, bvec, S.s.p, Rsz, n, false, fr_zero(), fr_zero(), S.rows.p, S.extras.p);
         const uint32_t qh[2] = {g.pc_1.G[0], g.pc_n.h};
         while (n != 1) {
-            dev_msm_rows(c, DG, S.rows.p, Rsz, Rsz, 2, S.extras.p + 4 * round, qh, 2);
-            c.sync();
+            unsigned long long tk = dev_msm_rows(c, DG, S.rows.p, Rsz, Rsz, 2, S.extras.p + 4 * round, qh, 2);
+            c.wait_points(tk);
             CPoint Lp = point_at(c, 0), Rp = point_at(c, 1);
             tr.append_point("L", Lp.b); tr.append_point("R", Rp.b);
             P.polyeval.L_vec.push_back(Lp); P.polyeval.R_vec.push_back(Rp);
@@ -302,8 +303,9 @@ std::vector<uint8_t> nizk_prove_resident(Instance &I, DeviceWitness &wit, Gens &
         // delta = d * g_hat + r_delta * h with g_hat = sum_j s[j] P[j]
         dev_scale(c, S.s.p, d, S.rows.p, Rsz);
         OTTI_HIP(hipMemcpyAsync(S.extras.p, &r_delta, sizeof(Fr), hipMemcpyHostToDevice, c.stream));
-        { uint32_t hb = g.pc_1.h; dev_msm_rows(c, DG, S.rows.p, Rsz, Rsz, 1, S.extras.p, &hb, 1); }
-        c.sync();
+        unsigned long long tk_delta;
+        { uint32_t hb = g.pc_1.h; tk_delta = dev_msm_rows(c, DG, S.rows.p, Rsz, Rsz, 1, S.extras.p, &hb, 1); }
+        c.wait_points(tk_delta);
         const Fr x_hat = c.h_results[13], a_hat = c.h_results[14];
         P.polyeval.delta = point_at(c, 0);
         tr.append_point("delta", P.polyeval.delta.b);
@@ -325,7 +327,8 @@ std::vector<uint8_t> nizk_prove_resident(Instance &I, DeviceWitness &wit, Gens &
     }
     std::vector<uint8_t> out = P.serialize();
     T.ms[6] = now_ms() - t_start;
-    KStats::get().flush();                                       // stream is idle here (last c.sync() above)
+    OTTI_HIP(hipStreamSynchronize(c.stream));                    // already drained: every result above was waited for
+    KStats::get().flush();
     if (tm) *tm = T;
     return out;
 }
