@@ -357,12 +357,14 @@ __device__ __forceinline__ Pair fold_regs(const Fr &x0, const Fr &x1, const Fr &
 __global__ __launch_bounds__(kBlock) void k_sc_cubic_fold_eval(Fr *A, Fr *B, Fr *C, Fr *D, size_t q, Fr r, Mailbox mb) {
     Fr acc[3] = {fr_zero(), fr_zero(), fr_zero()};
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < q; i += (size_t)gridDim.x * blockDim.x) {
+        // two load groups of eight elements: all sixteen in flight at once would need the whole register file (one wave per SIMD)
         Fr a0 = A[i], a1 = A[i + q], a2 = A[i + 2 * q], a3 = A[i + 3 * q];
         Fr b0 = B[i], b1 = B[i + q], b2 = B[i + 2 * q], b3 = B[i + 3 * q];
+        __builtin_amdgcn_sched_barrier(0);
+        Pair a = fold_regs(a0, a1, a2, a3, r); A[i] = a.lo; A[i + q] = a.hi;
         Fr c0 = C[i], c1 = C[i + q], c2 = C[i + 2 * q], c3 = C[i + 3 * q];
         Fr d0 = D[i], d1 = D[i + q], d2 = D[i + 2 * q], d3 = D[i + 3 * q];
         __builtin_amdgcn_sched_barrier(0);
-        Pair a = fold_regs(a0, a1, a2, a3, r); A[i] = a.lo; A[i + q] = a.hi;
         Pair b = fold_regs(b0, b1, b2, b3, r); B[i] = b.lo; B[i + q] = b.hi;
         Pair c = fold_regs(c0, c1, c2, c3, r); C[i] = c.lo; C[i + q] = c.hi;
         Pair d = fold_regs(d0, d1, d2, d3, r); D[i] = d.lo; D[i + q] = d.hi;
