@@ -24,6 +24,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (guide: MI355X_MICROARCH.md); ~6300 achievable
 F = 32                          # bytes per field element
+MADD_PEAK_G = 24.07             # measured: 10-limb mixed point additions per second (x1e9), tools/mulbench.hip on MI355X
 
 
 def algorithmic_bytes(N, V, nnz):
@@ -139,12 +140,9 @@ def main():
     if cnt:
         avg_ms = tot_ms / cnt
         if dom == "msm_rows":
-            # launches per proof: 1 commit (V scalars) + polyeval rows (Cx: R, bullet: 2R per round, delta: R); algorithmic bytes =
-            # the scalars each launch must read once (SURVEY 8d "commit 32V"); window-table gathers are not compulsory traffic
-            lgR = Rsz.bit_length() - 1
-            scalars_per_proof = V + Rsz + 2 * Rsz * lgR + Rsz
-            launches_per_proof = 1 + 1 + lgR + 1
-            bytes_per_launch = F * scalars_per_proof / launches_per_proof
+            # the witness commitment: one launch per proof reads V scalars once (SURVEY 8d "commit 32*V"); the window-table gathers
+            # (96 B per mixed addition) are not compulsory traffic and are not counted
+            bytes_per_launch = F * V
         elif dom == "sc_cubic":
             bytes_per_launch = 512 * N / max(1, (N.bit_length() - 1))          # phase one 512*N over log2(N) launches
         elif dom == "sc_quad":
@@ -154,13 +152,25 @@ def main():
         else:
             bytes_per_launch = algorithmic_bytes(N, V, nnz) / max(1, cnt / steps)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        try:   # HBM traffic of the dominant kernel's largest launch, from a separate rocprofv3 --pmc pass (profiles/, see its note)
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
+            kname = {"msm_rows": "k_msm_rows", "sc_cubic": "k_sc_cubic_fold_eval", "sc_quad": "k_sc_quad_fold_eval", "spmv": "k_spmv3_light"}.get(dom)
+            if kname and lg == 20 and int(os.environ.get("OTTI_MSM_WINDOW", "12")) == 12:
+                traffic = pm["kernels"][kname]["traffic_bytes_corrected"]
+        except Exception:
+            traffic = None
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": None, "launches": cnt, "avg_launch_ms": round(avg_ms, 4),
+                    "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic, "launches": cnt, "avg_launch_ms": round(avg_ms, 4),
                     "algorithmic_bytes_per_launch": int(bytes_per_launch)}
         if dom == "msm_rows":
-            W = 253 // int(os.environ.get("OTTI_MSM_WINDOW", "12")) + 1
-            adds_per_launch = scalars_per_proof * W / launches_per_proof
-            roofline["alu"] = {"point_adds_per_s": round(adds_per_launch / (avg_ms * 1e-3), 1), "note": "integer-ALU-bound kernel (7 Fp mul per mixed add); see DESIGN.md"}
+            cbits = int(os.environ.get("OTTI_MSM_WINDOW", "12"))
+            W = 253 // cbits + 1
+            adds = V * W                                   # one mixed addition (7 multiplications in GF(2^255-19)) per scalar and window
+            rate = adds / (avg_ms * 1e-3)
+            roofline["alu"] = {"bound": "integer ALU (v_mad_u64_u32)", "achieved": round(rate / 1e9, 3), "peak": MADD_PEAK_G, "unit": "G mixed additions/s",
+                               "frac": round(rate / 1e9 / MADD_PEAK_G, 4),
+                               "note": "peak = tools/mulbench.hip p10_madd throughput on this chip, all CUs busy, operands in registers"}
     whole = algorithmic_bytes(N, V, nnz)
     proof_gbps = whole / (ms_per_step * 1e-3) / 1e9
 

@@ -136,7 +136,7 @@ int32_t otti_k_sc_quad_fold_round(const uint8_t *h_A, const uint8_t *h_B, size_t
 int32_t otti_k_msm_rows(otti_gens *gens, const uint8_t *h_Z, size_t L, size_t R, const uint8_t *h_blinds, uint8_t *h_out32, float *kernel_ms);
 
 /* per-kernel-class timing with HIP events recorded on the library's own stream around every launch of that class.
-   classes: msm_rows msm_finish sc_cubic sc_quad spmv eq reduce poly_bound bullet other.  enable(1) also resets the counters. */
+   classes: msm_rows (>= 2^16 scalars per launch: the witness commitment) msm_small msm_finish sc_cubic sc_quad spmv eq reduce poly_bound bullet other.  enable(1) also resets the counters. */
 int32_t otti_stats_enable(int32_t on);
 /* restrict timing to one class (call after enable): two event records per launch are not free on the latency-bound round loop */
 int32_t otti_stats_select(const char *kernel_class);

@@ -351,7 +351,7 @@ def fr_to_ints(a):
     return [int.from_bytes(a[k].tobytes(), "little") * _RINV % L_ORDER for k in range(a.shape[0])]
 
 
-KERNEL_CLASSES = ("msm_rows", "msm_finish", "sc_cubic", "sc_quad", "spmv", "eq", "reduce", "poly_bound", "bullet", "other")
+KERNEL_CLASSES = ("msm_rows", "msm_small", "msm_finish", "sc_cubic", "sc_quad", "spmv", "eq", "reduce", "poly_bound", "bullet", "other")
 
 
 def stats_enable(on=True, only=None):

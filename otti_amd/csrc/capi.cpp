@@ -268,7 +268,7 @@ int32_t otti_k_msm_rows(otti_gens *gens, const uint8_t *Z, size_t L, size_t R, c
 }
 
 // ------------------------------------------------------------------------------------------------ kernel timing (HIP events on the library stream)
-static const char *kClassNames[KC_COUNT] = {"msm_rows", "msm_finish", "sc_cubic", "sc_quad", "spmv", "eq", "reduce", "poly_bound", "bullet", "other"};
+static const char *kClassNames[KC_COUNT] = {"msm_rows", "msm_small", "msm_finish", "sc_cubic", "sc_quad", "spmv", "eq", "reduce", "poly_bound", "bullet", "other"};
 int32_t otti_stats_enable(int32_t on) { KStats::get().on = on != 0; KStats::get().mask = 0xffffffffu; KStats::get().reset(); return OTTI_OK; }
 int32_t otti_stats_select(const char *kernel_class) {
     for (int k = 0; k < KC_COUNT; k++) if (!strcmp(kernel_class, kClassNames[k])) { KStats::get().mask = 1u << k; return OTTI_OK; }

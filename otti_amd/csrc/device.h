@@ -72,7 +72,7 @@ constexpr size_t kHostEncodeRows = 8;
 constexpr size_t kHostPtsCap = 512;
 
 // per-kernel-class HIP-event timing on the library's own stream (bench.py's roofline numbers come from here)
-enum KClass { KC_MSM_ROWS = 0, KC_MSM_FINISH, KC_SC_CUBIC, KC_SC_QUAD, KC_SPMV, KC_EQ, KC_REDUCE, KC_BOUND, KC_BULLET, KC_OTHER, KC_COUNT };
+enum KClass { KC_MSM_ROWS = 0, KC_MSM_SMALL, KC_MSM_FINISH, KC_SC_CUBIC, KC_SC_QUAD, KC_SPMV, KC_EQ, KC_REDUCE, KC_BOUND, KC_BULLET, KC_OTHER, KC_COUNT };
 struct KStats {
     bool on = false; unsigned mask = 0xffffffffu;            // bit k set: kernel class k is timed
     std::vector<hipEvent_t> pool; std::vector<int> cls; size_t used = 0;

@@ -624,7 +624,7 @@ unsigned long long dev_msm_rows(DevCtx &c, const DeviceGens &g, const Fr *dense,
     A.fuse = (mode == MSM_COMPRESSED && !addend && rows <= 2 && nchunks > 1 && nchunks <= 128) ? 1 : 0;
     A.rows = (uint32_t)rows; A.counter = c.d_counter2.p; A.host_pts = c.d_pts_alias; A.host_flag = c.d_flag_alias; A.seq = A.fuse ? ++c.seq : 0;
     dim3 grid((unsigned)nchunks, (unsigned)rows);
-    { KScope ks(c, KC_MSM_ROWS); hipLaunchKernelGGL(k_msm_rows, grid, kBlock, 0, c.stream, A); }
+    { KScope ks(c, rows * n_dense >= ((size_t)1 << 16) ? KC_MSM_ROWS : KC_MSM_SMALL); hipLaunchKernelGGL(k_msm_rows, grid, kBlock, 0, c.stream, A); }
     if (A.fuse) { c.pending_host_encode = rows; return A.seq; }
     // rows with a single chunk need no finish pass: their partial IS the row sum
     const Pt *finals = c.msm_partial.p;
