@@ -28,7 +28,9 @@ struct DCsr3 { const uint32_t *ptr[3]; const uint32_t *idx[3]; const Fr *val[3];
 struct DeviceCsrSet {
     DevBuf<uint32_t> ptr[3], idx[3]; DevBuf<Fr> val[3];
     DevBuf<uint32_t> heavy;                                   // ids of rows whose longest list exceeds kHeavyRow
-    size_t rows = 0, n_heavy = 0;
+    DevBuf<uint32_t> seg_row, seg_no, seg_begin;              // their segments (row id, segment number), and each long row's first segment
+    DevBuf<Fr> seg_partial;                                   // 3 partial sums per segment
+    size_t rows = 0, n_heavy = 0, n_seg = 0;
     DCsr3 view() const { DCsr3 v; for (int k = 0; k < 3; k++) { v.ptr[k] = ptr[k].p; v.idx[k] = idx[k].p; v.val[k] = val[k].p; } return v; }
 };
 struct DeviceInstance { DeviceCsrSet by_row, by_col; size_t nnz = 0; };

@@ -206,32 +206,51 @@ __global__ __launch_bounds__(kBlock) void k_spmv3_light(DCsr3 m, size_t rows, co
         else { o0[r] = a0; o1[r] = a1; o2[r] = a2; }
     }
 }
-__global__ __launch_bounds__(kBlock) void k_spmv3_heavy(DCsr3 m, const uint32_t *heavy, const Fr *x, Fr *o0, Fr *o1, Fr *o2, int combine, Fr c0, Fr c1, Fr c2) {
-    size_t r = heavy[blockIdx.x];
+// Long lists (a linear combination over thousands of variables; the constant-1 column of a compiled circuit, which can hold O(N)
+// entries in the transposed copy) are cut into segments of kHeavySeg entries: one workgroup per segment writes the three raw partial
+// sums, then one thread per long list adds its segments up and applies the combination.
+constexpr uint32_t kHeavySeg = 2048;
+__global__ __launch_bounds__(kBlock) void k_spmv3_heavy_seg(DCsr3 m, const uint32_t *seg_row, const uint32_t *seg_no, const Fr *x, Fr *partial) {
+    const size_t r = seg_row[blockIdx.x]; const uint32_t sn = seg_no[blockIdx.x];
     Fr acc[3];
     for (int k = 0; k < 3; k++) {
         acc[k] = fr_zero();
-        uint32_t p0 = m.ptr[k][r], p1 = m.ptr[k][r + 1];
-        for (uint32_t p = p0 + threadIdx.x; p < p1; p += blockDim.x) acc[k] = fr_add(acc[k], fr_mul(m.val[k][p], x[m.idx[k][p]]));
+        const uint32_t p0 = m.ptr[k][r], p1 = m.ptr[k][r + 1];
+        const uint64_t lo = (uint64_t)p0 + (uint64_t)sn * kHeavySeg;
+        if (lo >= p1) continue;
+        const uint32_t hi = (uint32_t)min((uint64_t)p1, lo + kHeavySeg);
+        for (uint32_t p = (uint32_t)lo + threadIdx.x; p < hi; p += blockDim.x) acc[k] = fr_add(acc[k], fr_mul(m.val[k][p], x[m.idx[k][p]]));
     }
     block_reduce<3>(acc);
-    if (threadIdx.x == 0) {
-        if (combine) o0[r] = fr_add(fr_add(fr_mul(c0, acc[0]), fr_mul(c1, acc[1])), fr_mul(c2, acc[2]));
-        else { o0[r] = acc[0]; o1[r] = acc[1]; o2[r] = acc[2]; }
-    }
+    if (threadIdx.x == 0) for (int k = 0; k < 3; k++) partial[(size_t)blockIdx.x * 3 + k] = acc[k];
+}
+__global__ __launch_bounds__(64) void k_spmv3_heavy_combine(const uint32_t *heavy, const uint32_t *seg_begin, size_t n_heavy, const Fr *partial, Fr *o0, Fr *o1, Fr *o2,
+                                                            int combine, Fr c0, Fr c1, Fr c2) {
+    size_t h = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (h >= n_heavy) return;
+    Fr acc[3] = {fr_zero(), fr_zero(), fr_zero()};
+    for (uint32_t s = seg_begin[h]; s < seg_begin[h + 1]; s++)
+        for (int k = 0; k < 3; k++) acc[k] = fr_add(acc[k], partial[(size_t)s * 3 + k]);
+    const size_t r = heavy[h];
+    if (combine) o0[r] = fr_add(fr_add(fr_mul(c0, acc[0]), fr_mul(c1, acc[1])), fr_mul(c2, acc[2]));
+    else { o0[r] = acc[0]; o1[r] = acc[1]; o2[r] = acc[2]; }
 }
 void dev_spmv3(DevCtx &c, const DeviceCsrSet &m, const Fr *x, Fr *o0, Fr *o1, Fr *o2, bool combine, const Fr coef[3]) {
     Fr z = fr_zero();
     Fr c0 = coef ? coef[0] : z, c1 = coef ? coef[1] : z, c2 = coef ? coef[2] : z;
     KScope ks(c, KC_SPMV);
     hipLaunchKernelGGL(k_spmv3_light, grid_for(m.rows), kBlock, 0, c.stream, m.view(), m.rows, x, o0, o1, o2, (int)combine, c0, c1, c2);
-    if (m.n_heavy) hipLaunchKernelGGL(k_spmv3_heavy, (int)m.n_heavy, kBlock, 0, c.stream, m.view(), m.heavy.p, x, o0, o1, o2, (int)combine, c0, c1, c2);
+    if (m.n_heavy) {
+        hipLaunchKernelGGL(k_spmv3_heavy_seg, (unsigned)m.n_seg, kBlock, 0, c.stream, m.view(), (const uint32_t *)m.seg_row.p, (const uint32_t *)m.seg_no.p, x, m.seg_partial.p);
+        hipLaunchKernelGGL(k_spmv3_heavy_combine, (unsigned)((m.n_heavy + 63) / 64), 64, 0, c.stream, (const uint32_t *)m.heavy.p, (const uint32_t *)m.seg_begin.p, m.n_heavy,
+                           (const Fr *)m.seg_partial.p, o0, o1, o2, (int)combine, c0, c1, c2);
+    }
 }
 
 static void upload_csr_set(DeviceCsrSet &d, const SparseMat M[3], bool by_col) {
     size_t rows = by_col ? M[0].by_col.rows : M[0].by_row.rows;
     d.rows = rows;
-    std::vector<uint32_t> heavy;
+    std::vector<uint32_t> heavy, seg_row, seg_no, seg_begin;
     for (int k = 0; k < 3; k++) {
         const Csr &s = by_col ? M[k].by_col : M[k].by_row;
         d.ptr[k].alloc(s.ptr.size()); d.idx[k].alloc(std::max<size_t>(1, s.idx.size())); d.val[k].alloc(std::max<size_t>(1, s.val.size()));
@@ -244,10 +263,18 @@ static void upload_csr_set(DeviceCsrSet &d, const SparseMat M[3], bool by_col) {
     for (size_t r = 0; r < rows; r++) {
         uint32_t mx = 0;
         for (int k = 0; k < 3; k++) { const Csr &s = by_col ? M[k].by_col : M[k].by_row; mx = std::max(mx, s.ptr[r + 1] - s.ptr[r]); }
-        if (mx > (uint32_t)kHeavyRow) heavy.push_back((uint32_t)r);
+        if (mx > (uint32_t)kHeavyRow) {
+            heavy.push_back((uint32_t)r); seg_begin.push_back((uint32_t)seg_row.size());
+            for (uint32_t sn = 0; sn * kHeavySeg < mx; sn++) { seg_row.push_back((uint32_t)r); seg_no.push_back(sn); }
+        }
     }
-    d.n_heavy = heavy.size();
-    if (!heavy.empty()) { d.heavy.alloc(heavy.size()); OTTI_HIP(hipMemcpy(d.heavy.p, heavy.data(), heavy.size() * 4, hipMemcpyHostToDevice)); }
+    seg_begin.push_back((uint32_t)seg_row.size());
+    d.n_heavy = heavy.size(); d.n_seg = seg_row.size();
+    if (!heavy.empty()) {
+        auto up = [](DevBuf<uint32_t> &b, const std::vector<uint32_t> &v) { b.alloc(v.size()); OTTI_HIP(hipMemcpy(b.p, v.data(), v.size() * 4, hipMemcpyHostToDevice)); };
+        up(d.heavy, heavy); up(d.seg_row, seg_row); up(d.seg_no, seg_no); up(d.seg_begin, seg_begin);
+        d.seg_partial.alloc(3 * seg_row.size());
+    }
 }
 std::shared_ptr<DeviceInstance> upload_instance(const Instance &I) {
     DevCtx::get();

@@ -296,3 +296,25 @@ def test_golden_proof_digests_on_gpu():
         gens = oa.NIZKGens.new(r["num_cons"], r["num_vars"], r["num_inputs"])
         p = oa.NIZK.prove(inst, oa.VarsAssignment.new(r["vars"]), oa.InputsAssignment.new(r["inputs"]), gens, g["label"].encode(), bytes.fromhex(g["tape_seed"]))
         assert len(p.bytes) == g["proof_len"] and hashlib.sha256(p.bytes).hexdigest() == g["proof_sha256"], g["n"]
+
+
+def test_very_long_row_and_column_are_segmented(rng):
+    # the constant-1 column appears in every row of A (8192 entries in the transposed copy: 4 segments), and row 7 of B spans 5000 columns
+    nc = nv = 1 << 13; ni = 3
+    A, B, C = _random_instance(rng, nc, nv, ni, 2)
+    extra = np.zeros(nc, dtype=oa.ENTRY_DTYPE); extra["row"] = np.arange(nc); extra["col"] = nv
+    extra["val"] = rng.integers(0, 256, size=(nc, 32), dtype=np.uint8); extra["val"][:, 31] &= 0x0f
+    A = np.concatenate([A, extra])
+    longrow = np.zeros(5000, dtype=oa.ENTRY_DTYPE); longrow["row"] = 7; longrow["col"] = rng.permutation(nv)[:5000]
+    longrow["val"] = rng.integers(0, 256, size=(5000, 32), dtype=np.uint8); longrow["val"][:, 31] &= 0x0f
+    B = np.concatenate([B, longrow])
+    inst, oinst = oa.Instance.new(nc, nv, ni, A, B, C), orc.OInstance(nc, nv, ni, A, B, C)
+    z = orc.rand_fr(rng, 2 * nv)
+    ga, gb, gc, _ = K.multiply_vec(inst, z)
+    oa_, ob_, oc_ = orc.multiply_vec(oinst, z)
+    assert eq(ga, oa_) and eq(gb, ob_) and eq(gc, oc_)
+    eqrx, coef = orc.rand_fr(rng, nc), orc.rand_fr(rng, 3)
+    got, _ = K.eval_table_sparse(inst, eqrx, coef)
+    eA, eB, eC = (orc.fr_to_ints(x) for x in orc.eval_table_sparse(oinst, eqrx))
+    c = orc.fr_to_ints(coef)
+    assert orc.fr_to_ints(got) == [(c[0] * a + c[1] * b + c[2] * d) % orc.L_ORDER for a, b, d in zip(eA, eB, eC)]
