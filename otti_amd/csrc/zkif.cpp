@@ -81,10 +81,10 @@ std::vector<uint8_t> read_file(const char *path) {
 
 struct Messages {
     bool have_header = false; VarList instance; uint64_t free_variable_id = 0; std::vector<uint8_t> field_maximum;
-    std::vector<std::array<VarList, 3>> constraints;
     VarList witness; bool have_witness = false;
 };
-void parse_messages(const std::vector<uint8_t> &file, Messages &m) {
+// walks the size-prefixed messages of one file; fn(type, message table, buffer)
+template <class F> void for_each_message(const std::vector<uint8_t> &file, F &&fn) {
     size_t off = 0;
     while (off + 4 <= file.size()) {
         uint32_t sz = (uint32_t)file[off] | ((uint32_t)file[off + 1] << 8) | ((uint32_t)file[off + 2] << 16) | ((uint32_t)file[off + 3] << 24);
@@ -92,29 +92,27 @@ void parse_messages(const std::vector<uint8_t> &file, Messages &m) {
         Buf b{file.data() + off + 4, sz};
         if (memcmp(b.p + 4, "zkif", 4) != 0) throw Error(OTTI_ERR_IO, "zkif: missing file identifier");
         Table root; root.b = &b; root.pos = b.u32(0); root.present = true; b.chk(root.pos, 4);
-        uint8_t type = root.u8f(0, 0);
-        Table msg = root.sub(1);
+        fn(root.u8f(0, 0), root.sub(1), b);
+        off += 4 + sz;
+    }
+    if (off != file.size()) throw Error(OTTI_ERR_IO, "zkif: trailing bytes");
+}
+// pass 1: headers and witness only (ConstraintSystem messages are skipped by their size prefix)
+void parse_headers(const std::vector<uint8_t> &file, Messages &m) {
+    for_each_message(file, [&](uint8_t type, const Table &msg, const Buf &b) {
         if (type == 1) {                       // CircuitHeader
             VarList iv = read_variables(msg.sub(0));
             if (!m.have_header || iv.has_vals) m.instance = iv;           // the .inp.zkif header carries the values
             m.free_variable_id = std::max(m.free_variable_id, msg.u64f(1, 0));
             size_t s, n; if (msg.vec(2, s, n)) { b.chk(s, n); m.field_maximum.assign(b.p + s, b.p + s + n); }
             m.have_header = true;
-        } else if (type == 2) {                // ConstraintSystem
-            size_t s, n; msg.vec(0, s, n); b.chk(s, n * 4);
-            for (size_t i = 0; i < n; i++) {
-                Table bc; bc.b = &b; bc.pos = s + 4 * i + b.u32(s + 4 * i); bc.present = true; b.chk(bc.pos, 4);
-                m.constraints.push_back({read_variables(bc.sub(0)), read_variables(bc.sub(1)), read_variables(bc.sub(2))});
-            }
         } else if (type == 3) {                // Witness
             VarList w = read_variables(msg.sub(0));
             m.witness.ids.insert(m.witness.ids.end(), w.ids.begin(), w.ids.end());
             m.witness.vals.insert(m.witness.vals.end(), w.vals.begin(), w.vals.end());
             m.have_witness = true;
-        }                                      // Command and unknown messages are skipped
-        off += 4 + sz;
-    }
-    if (off != file.size()) throw Error(OTTI_ERR_IO, "zkif: trailing bytes");
+        }                                      // ConstraintSystem / Command / unknown: not here
+    });
 }
 
 // ---- forward-laid-out FlatBuffers writer (every uoffset points forward; vtables sit right before their tables)
@@ -177,14 +175,28 @@ void write_header(FILE *f, const std::vector<uint64_t> &inst_ids, const std::vec
 }
 }  // namespace
 
-// column of a zkInterface variable id in Spartan's z = [vars | 1 | inputs]
+// column of a zkInterface variable id in Spartan's z = [vars | 1 | inputs]; ids are dense in [0, free_variable_id), so a flat table
 struct IdMap {
-    std::map<uint64_t, size_t> inst, wit; size_t num_vars = 0, num_inputs = 0;
+    std::vector<uint32_t> col_of;             // 0xffffffff = undeclared
+    size_t num_vars = 0, num_inputs = 0;
     size_t col(uint64_t id) const {
-        if (id == 0) return num_vars;
-        auto i = inst.find(id); if (i != inst.end()) return num_vars + 1 + i->second;
-        auto w = wit.find(id); if (w != wit.end()) return w->second;
-        throw Error(OTTI_ERR_INVALID_INDEX, "zkif: constraint references an undeclared variable id");
+        if (id >= col_of.size() || col_of[id] == 0xffffffffu) throw Error(OTTI_ERR_INVALID_INDEX, "zkif: constraint references an undeclared variable id");
+        return col_of[id];
+    }
+    // witness position of an id (its column while it is below num_vars), or SIZE_MAX
+    size_t wit_pos(uint64_t id) const { if (id >= col_of.size()) return SIZE_MAX; uint32_t c = col_of[id]; return c < num_vars ? c : SIZE_MAX; }
+    void build(const std::vector<uint64_t> &instance_ids, uint64_t free_id) {
+        if (free_id > ((uint64_t)1 << 31)) throw Error(OTTI_ERR_BAD_ARG, "zkif: more than 2^31 variable ids");
+        for (auto id : instance_ids) if (id == 0 || id >= free_id) throw Error(OTTI_ERR_INVALID_INDEX, "zkif: instance variable id out of range");
+        num_inputs = instance_ids.size();
+        std::vector<uint8_t> is_inst((size_t)free_id, 0);
+        for (auto id : instance_ids) { if (is_inst[id]) throw Error(OTTI_ERR_IO, "zkif: duplicate instance variable id"); is_inst[id] = 1; }
+        num_vars = free_id > 0 ? (size_t)free_id - 1 - num_inputs : 0;
+        col_of.assign((size_t)std::max<uint64_t>(free_id, 1), 0xffffffffu);
+        col_of[0] = (uint32_t)num_vars;                                     // id 0 is the constant one
+        for (size_t i = 0; i < instance_ids.size(); i++) col_of[instance_ids[i]] = (uint32_t)(num_vars + 1 + i);
+        uint32_t k = 0;
+        for (uint64_t id = 1; id < free_id; id++) if (!is_inst[id]) col_of[id] = k++;
     }
 };
 
@@ -212,11 +224,32 @@ otti_r1cs *otti_r1cs_from(size_t nc, size_t nv, size_t ni, const std::vector<ott
     return r;
 }
 
+// one linear combination (a Variables table) straight into matrix entries of `row`; no intermediate per-constraint objects, so a
+// 2^24-constraint file costs its own size plus the entry arrays
+static void append_lc(std::vector<otti_entry> &out, const Table &vars, uint64_t row, const IdMap &map) {
+    if (!vars.present) return;
+    size_t is, in; vars.vec(0, is, in);
+    if (!in) return;
+    vars.b->chk(is, in * 8);
+    size_t vs, vn;
+    if (!vars.vec(1, vs, vn) || vn == 0 || vn % in) throw Error(OTTI_ERR_IO, "zkif: linear combination without (well-formed) coefficients");
+    const size_t w = vn / in; vars.b->chk(vs, vn);
+    for (size_t i = 0; i < in; i++) {
+        otti_entry e; e.row = row; e.col = map.col(vars.b->u64(is + 8 * i)); memset(e.val, 0, 32);
+        for (size_t k = 0; k < w; k++) {
+            uint8_t byte = vars.b->p[vs + i * w + k];
+            if (k < 32) e.val[k] = byte; else if (byte) throw Error(OTTI_ERR_INVALID_SCALAR, "zkif: coefficient wider than 32 bytes");
+        }
+        out.push_back(e);
+    }
+}
+
 otti_r1cs *zkif_load_impl(const char *circuit_path, const char *inputs_path, const char *witness_path) {
     Messages m;
-    parse_messages(read_file(circuit_path), m);
-    if (inputs_path) parse_messages(read_file(inputs_path), m);
-    if (witness_path) parse_messages(read_file(witness_path), m);
+    std::vector<uint8_t> circuit = read_file(circuit_path);
+    parse_headers(circuit, m);
+    if (inputs_path) parse_headers(read_file(inputs_path), m);
+    if (witness_path) parse_headers(read_file(witness_path), m);
     if (!m.have_header) throw Error(OTTI_ERR_IO, "zkif: no CircuitHeader message");
     if (!m.field_maximum.empty()) {
         static const uint8_t lm1[32] = {0xec, 0xd3, 0xf5, 0x5c, 0x1a, 0x63, 0x12, 0x58, 0xd6, 0x9c, 0xf7, 0xa2, 0xde, 0xf9, 0xde, 0x14,
@@ -225,25 +258,21 @@ otti_r1cs *zkif_load_impl(const char *circuit_path, const char *inputs_path, con
         std::vector<uint8_t> want(lm1, lm1 + 32); while (!want.empty() && want.back() == 0) want.pop_back();
         if (fm != want) throw Error(OTTI_ERR_IO, "zkif: field_maximum is not l-1 for the curve25519 scalar field");
     }
-    IdMap map;
-    for (size_t i = 0; i < m.instance.ids.size(); i++) map.inst[m.instance.ids[i]] = i;
-    map.num_inputs = m.instance.ids.size();
     // witness variables: every id in [1, free_variable_id) that is not an instance variable, in increasing order
-    uint64_t free_id = m.free_variable_id;
+    uint64_t free_id = std::max<uint64_t>(m.free_variable_id, 1);
     for (auto id : m.witness.ids) free_id = std::max(free_id, id + 1);
-    size_t k = 0;
-    for (uint64_t id = 1; id < free_id; id++) if (!map.inst.count(id)) map.wit[id] = k++;
-    map.num_vars = k;
-    std::vector<otti_entry> M[3];
-    for (size_t row = 0; row < m.constraints.size(); row++)
-        for (int t = 0; t < 3; t++) {
-            const VarList &lc = m.constraints[row][t];
-            if (!lc.ids.empty() && !lc.has_vals) throw Error(OTTI_ERR_IO, "zkif: linear combination without coefficients");
-            for (size_t i = 0; i < lc.ids.size(); i++) {
-                otti_entry e; e.row = row; e.col = map.col(lc.ids[i]); memcpy(e.val, lc.vals[i].data(), 32);
-                M[t].push_back(e);
-            }
+    for (auto id : m.instance.ids) free_id = std::max(free_id, id + 1);
+    IdMap map; map.build(m.instance.ids, free_id);
+    // pass 2: constraints of the circuit file, message by message
+    std::vector<otti_entry> M[3]; uint64_t row = 0;
+    for_each_message(circuit, [&](uint8_t type, const Table &msg, const Buf &b) {
+        if (type != 2) return;
+        size_t s, n; msg.vec(0, s, n); b.chk(s, n * 4);
+        for (size_t i = 0; i < n; i++, row++) {
+            Table bc; bc.b = &b; bc.pos = s + 4 * i + b.u32(s + 4 * i); bc.present = true; b.chk(bc.pos, 4);
+            for (int t = 0; t < 3; t++) append_lc(M[t], bc.sub(t), row, map);
         }
+    });
     std::vector<uint8_t> vars(32 * map.num_vars, 0), inputs(32 * map.num_inputs, 0);
     if (m.instance.has_vals) for (size_t i = 0; i < map.num_inputs; i++) memcpy(&inputs[32 * i], m.instance.vals[i].data(), 32);
     else if (map.num_inputs && inputs_path) throw Error(OTTI_ERR_IO, "zkif: inputs file carries no instance values");
@@ -251,13 +280,13 @@ otti_r1cs *zkif_load_impl(const char *circuit_path, const char *inputs_path, con
         if (m.witness.ids.size() != m.witness.vals.size()) throw Error(OTTI_ERR_IO, "zkif: witness without values");
         std::vector<bool> seen(map.num_vars, false);
         for (size_t i = 0; i < m.witness.ids.size(); i++) {
-            auto it = map.wit.find(m.witness.ids[i]);
-            if (it == map.wit.end()) throw Error(OTTI_ERR_INVALID_INDEX, "zkif: witness assigns an instance or unknown variable");
-            memcpy(&vars[32 * it->second], m.witness.vals[i].data(), 32); seen[it->second] = true;
+            size_t pos = m.witness.ids[i] == 0 ? SIZE_MAX : map.wit_pos(m.witness.ids[i]);
+            if (pos == SIZE_MAX) throw Error(OTTI_ERR_INVALID_INDEX, "zkif: witness assigns an instance or unknown variable");
+            memcpy(&vars[32 * pos], m.witness.vals[i].data(), 32); seen[pos] = true;
         }
-        for (bool s : seen) if (!s) throw Error(OTTI_ERR_IO, "zkif: witness does not assign every variable");
+        for (bool sn : seen) if (!sn) throw Error(OTTI_ERR_IO, "zkif: witness does not assign every variable");
     }
-    return otti_r1cs_from(m.constraints.size(), map.num_vars, map.num_inputs, M[0], M[1], M[2], vars, inputs);
+    return otti_r1cs_from(row, map.num_vars, map.num_inputs, M[0], M[1], M[2], vars, inputs);
 }
 
 void zkif_write_impl(const otti_r1cs *r, const char *circuit_path, const char *inputs_path, const char *witness_path) {
