@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log2-constraints", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist", choices=("uniform", "compiler"), default="uniform", help="synthetic instance distribution (SURVEY 8d); the metric is quoted on 'uniform'")
     ap.add_argument("--cpu-log2", type=int, default=None, help="size of the CPU-baseline sample (default: same workload)")
     args = ap.parse_args()
 
@@ -62,7 +63,8 @@ def main():
 
     lg = args.log2_constraints
     n, ni, label, seed = 1 << lg, 10, b"nizk_example", b"\x2a" * 32
-    r = oa.synth_r1cs(n, ni, 1 + rank)                     # each rank its own instance
+    gen = oa.synth_r1cs if args.dist == "uniform" else oa.synth_r1cs_compiler_like
+    r = gen(n, ni, 1 + rank)                               # each rank its own instance
     inst = oa.Instance.new(r["num_cons"], r["num_vars"], r["num_inputs"], r["A"], r["B"], r["C"])
     gens = oa.NIZKGens.new(r["num_cons"], r["num_vars"], r["num_inputs"])
     vars_, inputs = oa.VarsAssignment.new(r["vars"]), oa.InputsAssignment.new(r["inputs"])
@@ -181,7 +183,7 @@ def main():
         avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
         cores = int(os.environ.get("OTTI_CPU_THREADS", min(avail, 16)))       # a 1-GPU box's CPU share is 16 cores
         clg = args.cpu_log2 if args.cpu_log2 is not None else lg
-        cr = r if (clg == lg and rank == 0) else oa.synth_r1cs(1 << clg, ni, 1)
+        cr = r if (clg == lg and rank == 0) else gen(1 << clg, ni, 1)
         ci, cg = orc.OInstance(cr["num_cons"], cr["num_vars"], cr["num_inputs"], cr["A"], cr["B"], cr["C"]), orc.OGens(cr["num_cons"], cr["num_vars"], cr["num_inputs"])
         orc.set_threads(cores)
         orc.nizk_prove(orc.OInstance(256, 256, ni, *[oa.synth_r1cs(256, ni, 1)[k] for k in "ABC"]), oa.synth_r1cs(256, ni, 1)["vars"],
@@ -199,8 +201,10 @@ def main():
         "metric": "R1CS constraints/sec proved (Spartan NIZK) at 2^%d" % lg, "value": round(value, 1), "unit": "constraints/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "u256 (GF(l) / GF(2^255-19), 8 x u32 limbs)", "data": "synthetic",
-        "config": {"workload": f"synthetic satisfiable R1CS, 2^{lg} constraints = variables, 10 inputs, 1 nnz/row/matrix, uniform GF(l) witness "
-                               "(SURVEY 8d); one NIZK::prove per step, witness/instance/generators resident in HBM",
+        "config": {"workload": (f"synthetic satisfiable R1CS, 2^{lg} constraints = variables, 10 inputs, 1 nnz/row/matrix, uniform GF(l) witness "
+                                if args.dist == "uniform" else
+                                f"synthetic compiler-like R1CS, 2^{lg} constraints = variables, 10 inputs, 1..8 nnz/row/matrix, 90% of the witness < 2^64, heavy constant column ")
+                               + "(SURVEY 8d); one NIZK::prove per step, witness/instance/generators resident in HBM",
                    "parallelism": "1 proof per GPU" if world > 1 else "single GPU", "msm_window_bits": int(os.environ.get("OTTI_MSM_WINDOW", "12"))},
         "roofline": roofline,
         "cpu_baseline": cpu_baseline,

@@ -106,6 +106,9 @@ int32_t otti_zkif_write(const otti_r1cs *r, const char *circuit_path, const char
 void    otti_r1cs_free(otti_r1cs *r);
 /* synthetic satisfiable R1CS: num_cons = num_vars = n, one non-zero per row per matrix */
 int32_t otti_synth_r1cs(uint64_t n, uint64_t num_inputs, uint64_t seed, otti_r1cs **out);
+/* second distribution of SURVEY 8d ("compiler-like"): 90 % of the witness < 2^64, 1..8 non-zeros per row, small signed coefficients,
+   a heavily used constant column, one 300-entry row */
+int32_t otti_synth_r1cs_compiler_like(uint64_t n, uint64_t num_inputs, uint64_t seed, otti_r1cs **out);
 
 /* ---- kernel-level entry points (tests / bench).  h_* = host pointers; elements are 32-byte Montgomery-form Fr.
         Each call stages inputs to HBM, runs the named kernel(s) on the library's stream, and copies results back;

@@ -81,6 +81,7 @@ _sig("otti_zkif_load", _i32, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, 
 _sig("otti_zkif_write", _i32, ctypes.POINTER(_R1CS), ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p)
 _sig("otti_r1cs_free", None, ctypes.POINTER(_R1CS))
 _sig("otti_synth_r1cs", _i32, _u64, _u64, _u64, ctypes.POINTER(ctypes.POINTER(_R1CS)))
+_sig("otti_synth_r1cs_compiler_like", _i32, _u64, _u64, _u64, ctypes.POINTER(ctypes.POINTER(_R1CS)))
 _sig("otti_stats_enable", _i32, _i32)
 _sig("otti_stats_select", _i32, ctypes.c_char_p)
 _sig("otti_stats_read", _i32, ctypes.c_char_p, ctypes.POINTER(_u64), ctypes.POINTER(ctypes.c_double))
@@ -320,6 +321,13 @@ def synth_r1cs(n, num_inputs=10, seed=1):
     """Synthetic satisfiable R1CS of SURVEY.md 8(d): num_cons = num_vars = n, one non-zero per row per matrix."""
     rp = ctypes.POINTER(_R1CS)()
     _check(lib.otti_synth_r1cs(n, num_inputs, seed, ctypes.byref(rp)))
+    return _r1cs_to_py(rp)
+
+
+def synth_r1cs_compiler_like(n, num_inputs=10, seed=1):
+    """Second distribution of SURVEY.md 8(d): compiler-like R1CS (small witness values, ragged rows, heavy constant column)."""
+    rp = ctypes.POINTER(_R1CS)()
+    _check(lib.otti_synth_r1cs_compiler_like(n, num_inputs, seed, ctypes.byref(rp)))
     return _r1cs_to_py(rp)
 
 

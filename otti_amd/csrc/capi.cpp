@@ -155,6 +155,15 @@ int32_t otti_synth_r1cs(uint64_t n, uint64_t ni, uint64_t seed, otti_r1cs **out)
     });
 }
 
+int32_t otti_synth_r1cs_compiler_like(uint64_t n, uint64_t ni, uint64_t seed, otti_r1cs **out) {
+    return guarded([&] {
+        if (!out || n < 8) throw Error(OTTI_ERR_BAD_ARG, "bad argument");
+        std::vector<otti_entry> A, B, C; std::vector<uint8_t> vars, inputs;
+        synth_r1cs_compiler_like(n, ni, seed, A, B, C, vars, inputs);
+        *out = otti_r1cs_from(n, n, ni, A, B, C, vars, inputs); return OTTI_OK;
+    });
+}
+
 // ------------------------------------------------------------------------------------------------ kernel-level entry points
 namespace {
 struct Staged {                      // host Montgomery bytes -> device buffer

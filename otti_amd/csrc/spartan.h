@@ -130,4 +130,7 @@ std::vector<uint8_t> nizk_prove_gpu(Instance &inst, const std::vector<Fr> &vars_
 void synth_r1cs(size_t n, size_t num_inputs, uint64_t seed, std::vector<otti_entry> &A, std::vector<otti_entry> &B,
                 std::vector<otti_entry> &C, std::vector<uint8_t> &vars32, std::vector<uint8_t> &inputs32);
 
+void synth_r1cs_compiler_like(size_t n, size_t num_inputs, uint64_t seed, std::vector<otti_entry> &A, std::vector<otti_entry> &B,
+                              std::vector<otti_entry> &C, std::vector<uint8_t> &vars32, std::vector<uint8_t> &inputs32);
+
 }  // namespace otti

@@ -550,4 +550,47 @@ void synth_r1cs(size_t n, size_t ni, uint64_t seed, std::vector<otti_entry> &A, 
     for (size_t k = 0; k < ni; k++) fr_to_bytes(&inputs32[32 * k], Z[n + 1 + k]);
 }
 
+// "compiler-like" satisfiable instance (second distribution): 90 % of the witness below 2^64, 1..8 non-zeros per row with
+// small signed coefficients, a heavily used constant column, one very long row.  Reported separately from the uniform instance.
+void synth_r1cs_compiler_like(size_t n, size_t ni, uint64_t seed, std::vector<otti_entry> &A, std::vector<otti_entry> &B,
+                              std::vector<otti_entry> &C, std::vector<uint8_t> &vars32, std::vector<uint8_t> &inputs32) {
+    uint64_t st = seed * 0x9e3779b97f4a7c15ULL + 0x1234567;
+    auto rnd = [&]() { st += 0x9e3779b97f4a7c15ULL; uint64_t z = st; z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL; z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL; return z ^ (z >> 31); };
+    const size_t size_z = n + 1 + ni;
+    std::vector<Fr> Z(size_z), Zinv(size_z);
+    for (size_t k = 0; k < size_z; k++) {
+        if (rnd() % 10 != 0) Z[k] = fr_from_u64(rnd() | 1);
+        else { uint8_t w[64]; for (int i = 0; i < 8; i++) { uint64_t x = rnd(); memcpy(w + 8 * i, &x, 8); } Z[k] = fr_from_bytes_wide(w); if (fr_is_zero(Z[k])) Z[k] = fr_one(); }
+    }
+    Z[n] = fr_one();
+    {   // batch inversion of every z entry (all non-zero)
+        std::vector<Fr> pre(size_z); Fr acc = fr_one();
+        for (size_t k = 0; k < size_z; k++) { pre[k] = acc; acc = fr_mul(acc, Z[k]); }
+        acc = fr_inv(acc);
+        for (size_t k = size_z; k-- > 0;) { Zinv[k] = fr_mul(acc, pre[k]); acc = fr_mul(acc, Z[k]); }
+    }
+    A.clear(); B.clear(); C.clear();
+    auto emit = [&](std::vector<otti_entry> &M, size_t row, size_t col, const Fr &v) { otti_entry e; e.row = row; e.col = col; fr_to_bytes(e.val, v); M.push_back(e); };
+    auto lin = [&](std::vector<otti_entry> &M, size_t row, size_t kmax, bool with_const, std::vector<size_t> *used) {
+        Fr sum = fr_zero(); size_t k = 1 + rnd() % kmax;
+        for (size_t t = 0; t < k + (with_const ? 1 : 0); t++) {
+            size_t col = (with_const && t == k) ? n : rnd() % size_z;
+            uint64_t c = 1 + rnd() % 1000; Fr cv = fr_from_u64(c); if (rnd() % 5 == 0) cv = fr_neg(cv);
+            emit(M, row, col, cv); sum = fr_add(sum, fr_mul(cv, Z[col]));
+            if (used) used->push_back(col);
+        }
+        return sum;
+    };
+    for (size_t row = 0; row < n; row++) {
+        Fr a = lin(A, row, row == 3 ? 300 : 8, rnd() % 2 == 0, nullptr);
+        Fr b = lin(B, row, 8, rnd() % 2 == 0, nullptr);
+        std::vector<size_t> used; Fr c = lin(C, row, 6, false, &used);
+        size_t fix = row % n; while (std::find(used.begin(), used.end(), fix) != used.end()) fix = (fix + 1) % n;
+        emit(C, row, fix, fr_mul(fr_sub(fr_mul(a, b), c), Zinv[fix]));
+    }
+    vars32.resize(32 * n); inputs32.resize(32 * ni);
+    for (size_t k = 0; k < n; k++) fr_to_bytes(&vars32[32 * k], Z[k]);
+    for (size_t k = 0; k < ni; k++) fr_to_bytes(&inputs32[32 * k], Z[n + 1 + k]);
+}
+
 }  // namespace otti

@@ -318,3 +318,17 @@ def test_very_long_row_and_column_are_segmented(rng):
     eA, eB, eC = (orc.fr_to_ints(x) for x in orc.eval_table_sparse(oinst, eqrx))
     c = orc.fr_to_ints(coef)
     assert orc.fr_to_ints(got) == [(c[0] * a + c[1] * b + c[2] * d) % orc.L_ORDER for a, b, d in zip(eA, eB, eC)]
+
+
+@pytest.mark.parametrize("lg", [8, 13])
+def test_compiler_like_generator_proofs_match_oracle(lg):
+    n, ni = 1 << lg, 10
+    r = oa.synth_r1cs_compiler_like(n, ni, 5)
+    inst = oa.Instance.new(n, n, ni, r["A"], r["B"], r["C"]); gens = oa.NIZKGens.new(n, n, ni)
+    v, i = oa.VarsAssignment.new(r["vars"]), oa.InputsAssignment.new(r["inputs"])
+    assert inst.is_sat(v, i)
+    proof = oa.NIZK.prove(inst, v, i, gens, b"circ2", b"\x44" * 32)
+    proof.verify(inst, i, gens, b"circ2")
+    oi, og = orc.OInstance(n, n, ni, r["A"], r["B"], r["C"]), orc.OGens(n, n, ni)
+    oproof, _ = orc.nizk_prove(oi, r["vars"], r["inputs"], og, b"circ2", b"\x44" * 32)
+    assert proof.bytes == oproof
