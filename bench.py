@@ -110,7 +110,9 @@ def main():
     # correctness of what was timed
     digests = {hashlib.sha256(p.bytes).hexdigest() for p in proofs}
     assert len(digests) == 1, "proofs of the same inputs and seed differ between steps"
+    t0 = time.perf_counter()
     proofs[-1].verify(inst, inputs, gens, label)
+    t_verify = time.perf_counter() - t0
 
     if dist is not None:
         import torch
@@ -211,7 +213,7 @@ def main():
         "stage_ms": {k: round(v / steps, 3) for k, v in stage_acc.items()},
         "kernel_ms_per_step": {k: round(v[1], 3) for k, v in breakdown.items() if v[0]},
         "whole_proof_algorithmic_GBps": round(proof_gbps, 2), "whole_proof_hbm_frac": round(proof_gbps / (HBM_PEAK_GBPS * world), 6),
-        "witness_upload_ms": round(1e3 * t_upload, 2), "proof_bytes": len(proofs[-1].bytes), "proof_sha256": next(iter(digests)),
+        "witness_upload_ms": round(1e3 * t_upload, 2), "verify_ms": round(1e3 * t_verify, 2), "proof_bytes": len(proofs[-1].bytes), "proof_sha256": next(iter(digests)),
         "oracle_parity_2^12": parity_ok,
     }
     print(json.dumps(out))

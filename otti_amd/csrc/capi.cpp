@@ -132,7 +132,16 @@ int32_t otti_nizk_verify(const otti_instance *inst, const uint8_t *inputs32, siz
     return guarded([&] {
         if (!inst || !gens || !proof) throw Error(OTTI_ERR_BAD_ARG, "null argument");
         std::vector<Fr> inputs = scalars_from_bytes(inputs32, ninputs);
-        int rc = nizk_verify(*inst->I, inputs, *gens->g, tlabel, tlabel_len, proof, proof_len);
+        // The verifier is host code (as in the reference); only its O(nnz + N + V) step — evaluating A, B, C at (rx, ry) — goes to the
+        // device when one is present.  (Verification is not the proving hot path: without a device it simply stays on the host.)
+        Fr evals[3]; const Fr *ev = nullptr;
+        if (otti_device_count() > 0 && inst->I->num_cons >= 4096) {
+            try {
+                NizkProof P = NizkProof::parse(proof, proof_len);
+                instance_evaluate_gpu(*const_cast<Instance *>(inst->I.get()), P.rx, P.ry, evals); ev = evals;
+            } catch (const Error &) { ev = nullptr; }
+        }
+        int rc = nizk_verify(*inst->I, inputs, *gens->g, tlabel, tlabel_len, proof, proof_len, ev);
         if (rc) g_last_error = "proof rejected";
         return rc;
     });

@@ -93,6 +93,8 @@ struct DeviceWitness {
     DeviceWitness(const Instance &I, const std::vector<Fr> &vars_padded, const std::vector<Fr> &inputs);
 };
 void ensure_device_objects(Instance &I, Gens &g);
+// R1CSInstance::evaluate on the device: (A,B,C)(rx,ry) = <eq(rx), M * eq(ry)> for M in {A,B,C}  (verifier's O(nnz + N + V) work)
+void instance_evaluate_gpu(Instance &I, const std::vector<Fr> &rx, const std::vector<Fr> &ry, Fr out[3]);
 std::vector<uint8_t> nizk_prove_resident(Instance &I, DeviceWitness &wit, Gens &g, const void *tlabel, size_t tlabel_len, const uint8_t *seed32,
                                          ProveTimings *tm);
 

@@ -27,6 +27,20 @@ void ensure_device_objects(Instance &I, Gens &g) {
     if (!g.dev) g.dev = build_device_gens(g, device_window_bits());
 }
 
+void instance_evaluate_gpu(Instance &I, const std::vector<Fr> &rx, const std::vector<Fr> &ry, Fr out[3]) {
+    DevCtx &c = DevCtx::get();
+    if (!I.dev) I.dev = upload_instance(I);
+    const size_t N = I.num_cons, V2 = 2 * I.num_vars;
+    if (((size_t)1 << rx.size()) != N || ((size_t)1 << ry.size()) != V2) throw Error(OTTI_ERR_VERIFY_INTERNAL, "challenge vector lengths do not match the instance");
+    DevBuf<Fr> ex(N), ey(V2), Mz[3] = {DevBuf<Fr>(N), DevBuf<Fr>(N), DevBuf<Fr>(N)}, scratch(3 * 4096);
+    dev_eq_evals(c, rx.data(), rx.size(), ex.p, scratch.p);
+    dev_eq_evals(c, ry.data(), ry.size(), ey.p, scratch.p);
+    dev_spmv3(c, I.dev->by_row, ey.p, Mz[0].p, Mz[1].p, Mz[2].p, false, nullptr);
+    for (int k = 0; k < 3; k++) dev_dot(c, ex.p, Mz[k].p, N, 16 + k);
+    c.sync();
+    for (int k = 0; k < 3; k++) out[k] = c.h_results[16 + k];
+}
+
 DeviceWitness::DeviceWitness(const Instance &I, const std::vector<Fr> &vars_padded, const std::vector<Fr> &inputs_) : inputs(inputs_) {
     DevCtx &c = DevCtx::get();
     if (vars_padded.size() != I.num_vars) throw Error(OTTI_ERR_INVALID_NUM_VARS, "witness length != padded num_vars");

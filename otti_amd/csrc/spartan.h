@@ -118,8 +118,9 @@ void sumcheck_round_finish(ZKSumcheckProof &pf, size_t j, const RoundPart1 &p1, 
                            Transcript &tr);
 
 // ---------------------------------------------------------------------------------------------- verifier (lib.rs NIZK::verify)
+// inst_evals: optional (A,B,C)(rx,ry) computed elsewhere (the device: the O(nnz + N + V) part of verification); NULL => host
 int nizk_verify(const Instance &inst, const std::vector<Fr> &inputs, const Gens &g, const void *tlabel, size_t tlabel_len,
-                const uint8_t *proof, size_t proof_len);
+                const uint8_t *proof, size_t proof_len, const Fr *inst_evals = nullptr);
 
 // ---------------------------------------------------------------------------------------------- prover (prover.cpp; GPU)
 struct ProveTimings { double ms[8]; };   // polycommit, multiply_vec, sc_phase_one, eval_table_sparse, sc_phase_two, polyeval, total, (spare)

@@ -455,7 +455,7 @@ void dotproductlog_verify(const DotProductProofLog &pf, size_t n, const Gens &g,
 }  // namespace
 
 int nizk_verify(const Instance &I, const std::vector<Fr> &inputs, const Gens &g, const void *tlabel, size_t tlabel_len, const uint8_t *proof,
-                size_t proof_len) {
+                size_t proof_len, const Fr *inst_evals_opt) {
     try {
         if (inputs.size() != I.num_inputs) return OTTI_ERR_INVALID_NUM_INPUTS;
         NizkProof P = NizkProof::parse(proof, proof_len);
@@ -464,7 +464,9 @@ int nizk_verify(const Instance &I, const std::vector<Fr> &inputs, const Gens &g,
         require(g.num_vars_padded == V && P.rx.size() == nrx && P.ry.size() == nry && P.comm_vars.size() == Lsz);
         Transcript tr(tlabel, tlabel_len);
         tr.append_protocol_name("Spartan NIZK proof");
-        Fr inst_evals[3]; I.evaluate(P.rx, P.ry, inst_evals);
+        Fr inst_evals[3];
+        if (inst_evals_opt) { inst_evals[0] = inst_evals_opt[0]; inst_evals[1] = inst_evals_opt[1]; inst_evals[2] = inst_evals_opt[2]; }
+        else I.evaluate(P.rx, P.ry, inst_evals);
         // R1CSProof::verify
         tr.append_protocol_name("R1CS proof");
         tr.append_message("poly_commitment", "poly_commitment_begin", 21);
