@@ -136,6 +136,11 @@ void dev_dot(DevCtx &c, const Fr *a, const Fr *b, size_t n, int slot);
 // One launch per round.  If fold_first, a and b (length 2*n_cur) are folded to n_cur with (u, u_inv) and s is updated; then, for
 // n_cur >= 2, the next round's c_L, c_R go to extra_out[0], extra_out[2] and the dense scalar rows sL, sR (length R each) to rows[0..2R).
 void dev_bullet_step(DevCtx &c, Fr *a, Fr *b, Fr *s, size_t R, size_t n_cur, bool fold_first, const Fr &u, const Fr &u_inv, Fr *rows, Fr *extra_out);
+// One bullet-reduction round as ONE launch: applies the previous challenge (fold), derives the scalars of L and R from the round state
+// and sums both rows (fused finish; compressed L, R arrive in c.h_points[0..64) after c.wait_points(ticket)).  extra_s: 4 scalars
+// {unused, blind_L, unused, blind_R} (the c_L / c_R terms are computed in the kernel); extra_base: {Q, H}.
+unsigned long long dev_bullet_round(DevCtx &c, const DeviceGens &g, size_t R, size_t n_cur, bool fold, const Fr &u, const Fr &u_inv, const Fr *a_in,
+                                    const Fr *b_in, const Fr *s_in, Fr *a_out, Fr *b_out, Fr *s_out, const Fr *extra_s, const uint32_t *extra_base);
 void dev_scale(DevCtx &c, const Fr *in, const Fr &k, Fr *out, size_t n);
 void dev_fill_one(DevCtx &c, Fr *p, size_t n);
 

@@ -521,6 +521,10 @@ void dev_poly_bound(DevCtx &c, const Fr *Z, size_t L, size_t R, const Fr *Lv, Fr
 // and adds the table entry |d| * 2^(cw) * P[base] (affine Niels, 96-byte gather from HBM/L2; negated in registers when d < 0) into
 // its own accumulator with one 7-multiply mixed addition per pair.  Phase 3: LDS tree over the 256 accumulators.
 constexpr int kMsmMaxChunk = 1024;             // terms per workgroup (LDS: 36 B each)
+// Bullet-reduction round fused into the MSM launch: the scalars of rows L (0) and R (1) are not read from memory but derived in phase 1
+// from the round state (a, b: the two folded vectors; s: coefficients of the original generators), after applying the previous
+// round's challenge.  State is ping-ponged (read *_in, write *_out) so that no workgroup of the launch reads what another one writes.
+struct BulletArgs { int on, fold; uint32_t n; const Fr *a_in, *b_in, *s_in; Fr *a_out, *b_out, *s_out; Fr u, uinv; };
 struct MsmArgs {
     const Niels *table; int c, W; uint32_t E; int lanes;            // lanes = 256 / W term lanes
     const Fr *dense; size_t stride, n_dense; uint32_t chunk, nchunks;
@@ -530,7 +534,11 @@ struct MsmArgs {
     // fused finish (rows <= 2, 1 < nchunks <= 128): the last workgroup to arrive sums every row's partials and mails the extended
     // row sums to pinned host memory, then raises the host flag — no finish launch, no copy, no stream synchronise
     int fuse; uint32_t rows; unsigned *counter; Pt *host_pts; unsigned long long *host_flag; unsigned long long seq;
+    BulletArgs bul;
 };
+__device__ __forceinline__ Fr bullet_fold_a(const BulletArgs &U, size_t x) { return U.fold ? fr_add(fr_mul(U.a_in[x], U.u), fr_mul(U.uinv, U.a_in[U.n + x])) : U.a_in[x]; }
+__device__ __forceinline__ Fr bullet_fold_b(const BulletArgs &U, size_t x) { return U.fold ? fr_add(fr_mul(U.b_in[x], U.uinv), fr_mul(U.u, U.b_in[U.n + x])) : U.b_in[x]; }
+__device__ __forceinline__ Fr bullet_fold_s(const BulletArgs &U, size_t j) { return U.fold ? fr_mul(U.s_in[j], ((j & (2 * (size_t)U.n - 1)) < U.n) ? U.uinv : U.u) : U.s_in[j]; }
 __global__ __launch_bounds__(kBlock) void k_msm_rows(MsmArgs A) {
     // the recoded scalars (phases 1-2) and the reduction tree (phase 3) never live at the same time: one LDS region for both
     constexpr size_t kRawBytes = (kMsmMaxChunk + 8) * 9 * sizeof(uint32_t), kTreeBytes = (kBlock / 2) * sizeof(P10);
@@ -543,8 +551,32 @@ __global__ __launch_bounds__(kBlock) void k_msm_rows(MsmArgs A) {
     const uint32_t n_here = (uint32_t)min((size_t)A.chunk, A.n_dense - j0);
     const uint32_t n_ex = chunk_id == 0 ? (uint32_t)A.n_extra : 0u;
     // ---- phase 1: recoded scalars into LDS
+    __shared__ Fr s_dot;                                       // bullet mode: c_L / c_R of this row (chunk 0 only)
+    if (A.bul.on) {
+        const BulletArgs &U = A.bul; const size_t n = U.n, h = n / 2;
+        if (row == 0) {                                        // persist the folded state for the next round (each element written once)
+            const size_t cx = (n + gridDim.x - 1) / gridDim.x, x0 = (size_t)chunk_id * cx;
+            for (size_t x = x0 + threadIdx.x; x < min(n, x0 + cx); x += blockDim.x) { U.a_out[x] = bullet_fold_a(U, x); U.b_out[x] = bullet_fold_b(U, x); }
+            for (uint32_t t = threadIdx.x; t < n_here; t += blockDim.x) U.s_out[j0 + t] = bullet_fold_s(U, j0 + t);
+        }
+        if (chunk_id == 0) {                                   // c_L = <a_L, b_R> (row 0), c_R = <a_R, b_L> (row 1)
+            Fr acc[1] = {fr_zero()};
+            for (size_t x = threadIdx.x; x < h; x += blockDim.x)
+                acc[0] = fr_add(acc[0], row == 0 ? fr_mul(bullet_fold_a(U, x), bullet_fold_b(U, h + x)) : fr_mul(bullet_fold_a(U, h + x), bullet_fold_b(U, x)));
+            block_reduce<1>(acc);
+            if (threadIdx.x == 0) s_dot = acc[0];
+            __syncthreads();
+        }
+    }
     for (uint32_t t = threadIdx.x; t < n_here + n_ex; t += blockDim.x) {
-        Fr sc = t < n_here ? A.dense[row * A.stride + j0 + t] : A.extra_s[row * A.n_extra + (t - n_here)];
+        Fr sc;
+        if (t >= n_here) sc = (A.bul.on && t == n_here) ? s_dot : A.extra_s[row * A.n_extra + (t - n_here)];
+        else if (A.bul.on) {
+            const BulletArgs &U = A.bul; const size_t j = j0 + t, n = U.n, h = n / 2, i = j & (n - 1);
+            // L = <a_L, G_R>: generator slots of the upper half, paired with a[i - h];  R = <a_R, G_L>: lower half with a[i + h]
+            if (row == 0) sc = i >= h ? fr_mul(bullet_fold_a(U, i - h), bullet_fold_s(U, j)) : fr_zero();
+            else sc = i < h ? fr_mul(bullet_fold_a(U, i + h), bullet_fold_s(U, j)) : fr_zero();
+        } else sc = A.dense[row * A.stride + j0 + t];
         Fr raw = fr_to_raw(sc);
         uint64_t cy = 0;
 #pragma unroll
@@ -627,8 +659,20 @@ __global__ __launch_bounds__(64) void k_encode_points(const Pt *pts, const Pt *a
     uint32_t *o = (uint32_t *)(out32 + 32 * i);
     for (int k = 0; k < 8; k++) o[k] = (uint32_t)enc[4 * k] | ((uint32_t)enc[4 * k + 1] << 8) | ((uint32_t)enc[4 * k + 2] << 16) | ((uint32_t)enc[4 * k + 3] << 24);
 }
+static unsigned long long msm_launch(DevCtx &c, const DeviceGens &g, const Fr *dense, size_t stride, size_t n_dense, size_t rows, const Fr *extra_s,
+                                     const uint32_t *extra_base, size_t n_extra, int mode, const Pt *addend, const BulletArgs *bul);
 unsigned long long dev_msm_rows(DevCtx &c, const DeviceGens &g, const Fr *dense, size_t stride, size_t n_dense, size_t rows, const Fr *extra_s,
                                 const uint32_t *extra_base, size_t n_extra, int mode, const Pt *addend) {
+    return msm_launch(c, g, dense, stride, n_dense, rows, extra_s, extra_base, n_extra, mode, addend, nullptr);
+}
+unsigned long long dev_bullet_round(DevCtx &c, const DeviceGens &g, size_t R, size_t n_cur, bool fold, const Fr &u, const Fr &u_inv, const Fr *a_in,
+                                    const Fr *b_in, const Fr *s_in, Fr *a_out, Fr *b_out, Fr *s_out, const Fr *extra_s, const uint32_t *extra_base) {
+    BulletArgs U; U.on = 1; U.fold = fold ? 1 : 0; U.n = (uint32_t)n_cur; U.a_in = a_in; U.b_in = b_in; U.s_in = s_in;
+    U.a_out = a_out; U.b_out = b_out; U.s_out = s_out; U.u = u; U.uinv = u_inv;
+    return msm_launch(c, g, nullptr, 0, R, 2, extra_s, extra_base, 2, MSM_COMPRESSED, nullptr, &U);
+}
+static unsigned long long msm_launch(DevCtx &c, const DeviceGens &g, const Fr *dense, size_t stride, size_t n_dense, size_t rows, const Fr *extra_s,
+                                     const uint32_t *extra_base, size_t n_extra, int mode, const Pt *addend, const BulletArgs *bul) {
     const bool raw_points = mode == MSM_RAW;
     if (n_extra > 8) throw Error(OTTI_ERR_INTERNAL, "msm: too many extra terms");
     if (!rows) return 0;
@@ -649,6 +693,7 @@ unsigned long long dev_msm_rows(DevCtx &c, const DeviceGens &g, const Fr *dense,
     c.ensure_points(rows, nchunks);
     A.partial = c.msm_partial.p;
     A.fuse = (mode == MSM_COMPRESSED && !addend && rows <= 2 && nchunks > 1 && nchunks <= 128) ? 1 : 0;
+    if (bul) A.bul = *bul; else { memset(&A.bul, 0, sizeof A.bul); }
     A.rows = (uint32_t)rows; A.counter = c.d_counter2.p; A.host_pts = c.d_pts_alias; A.host_flag = c.d_flag_alias; A.seq = A.fuse ? ++c.seq : 0;
     dim3 grid((unsigned)nchunks, (unsigned)rows);
     { KScope ks(c, rows * n_dense >= ((size_t)1 << 16) ? KC_MSM_ROWS : KC_MSM_SMALL); hipLaunchKernelGGL(k_msm_rows, grid, kBlock, 0, c.stream, A); }

@@ -89,12 +89,12 @@ struct Scratch {
     DevBuf<Fr> T[4];          // eq(tau), Az, Bz, Cz  (N each)
     DevBuf<Fr> zw, ABC;       // phase-two working tables (2V each)
     DevBuf<Fr> eqs;           // eq-table scratch (3 * 4096)
-    DevBuf<Fr> blinds, Lv, Rv, LZ, a, s, rows, extras, bound_scratch, pre;
+    DevBuf<Fr> blinds, Lv, Rv, LZ, a, s, b2, s2, rows, extras, bound_scratch, pre;
     void reserve(size_t n, size_t v, size_t Lsz, size_t Rsz, size_t lgR) {
         if (n == N && v == V) return;
         for (auto &t : T) t.alloc(n);
         zw.alloc(2 * v); ABC.alloc(2 * v); eqs.alloc(3 * 4096);
-        blinds.alloc(Lsz); Lv.alloc(Lsz); Rv.alloc(Rsz); LZ.alloc(Rsz); a.alloc(Rsz); s.alloc(Rsz); rows.alloc(2 * Rsz);
+        blinds.alloc(Lsz); Lv.alloc(Lsz); Rv.alloc(Rsz); LZ.alloc(Rsz); a.alloc(Rsz); s.alloc(Rsz); b2.alloc(Rsz); s2.alloc(Rsz); rows.alloc(2 * Rsz);
         extras.alloc(4 * (lgR + 1)); bound_scratch.alloc(64 * Rsz);
         N = n; V = v;
     }
@@ -296,26 +296,30 @@ std::vector<uint8_t> nizk_prove_resident(Instance &I, DeviceWitness &wit, Gens &
         std::vector<Fr> ex(4 * (lgR + 1), fr_zero());
         for (size_t k = 0; k < lgR; k++) { ex[4 * k + 1] = bv1[k]; ex[4 * k + 3] = bv2[k]; }
         OTTI_HIP(hipMemcpyAsync(S.extras.p, ex.data(), ex.size() * sizeof(Fr), hipMemcpyHostToDevice, c.stream));
-        OTTI_HIP(hipMemcpyAsync(S.a.p, S.LZ.p, Rsz * sizeof(Fr), hipMemcpyDeviceToDevice, c.stream));
-        dev_fill_one(c, S.s.p, Rsz);
-        Fr *bvec = S.Rv.p;
+        // round state ping-pongs between two buffer sets: launch k reads set k&1 and writes the folded state to set (k+1)&1
+        Fr *abuf[2] = {S.LZ.p, S.a.p}, *bbuf[2] = {S.Rv.p, S.b2.p}, *sbuf[2] = {S.s.p, S.s2.p};
+        dev_fill_one(c, sbuf[0], Rsz);
         size_t n = Rsz, round = 0;
-        dev_bullet_step(c, S.a.p, bvec, S.s.p, Rsz, n, false, fr_zero(), fr_zero(), S.rows.p, S.extras.p);
         const uint32_t qh[2] = {g.pc_1.G[0], g.pc_n.h};
+        Fr u = fr_zero(), ui = fr_zero();
         while (n != 1) {
-            unsigned long long tk = dev_msm_rows(c, DG, S.rows.p, Rsz, Rsz, 2, S.extras.p + 4 * round, qh, 2);
+            const int in = (int)(round & 1), out = in ^ 1;
+            unsigned long long tk = dev_bullet_round(c, DG, Rsz, n, round != 0, u, ui, abuf[in], bbuf[in], sbuf[in], abuf[out], bbuf[out], sbuf[out],
+                                                     S.extras.p + 4 * round, qh);
             c.wait_points(tk);
             CPoint Lp = point_at(c, 0), Rp = point_at(c, 1);
             tr.append_point("L", Lp.b); tr.append_point("R", Rp.b);
             P.polyeval.L_vec.push_back(Lp); P.polyeval.R_vec.push_back(Rp);
-            Fr u = tr.challenge_scalar("u"), ui = fr_inv(u);
+            u = tr.challenge_scalar("u"); ui = fr_inv(u);
             blind_fin = fr_add(blind_fin, fr_add(fr_mul(fr_mul(bv1[round], u), u), fr_mul(fr_mul(bv2[round], ui), ui)));
             n /= 2; round++;
-            dev_bullet_step(c, S.a.p, bvec, S.s.p, Rsz, n, true, u, ui, S.rows.p, S.extras.p + 4 * round);
         }
-        dev_fetch(c, S.a.p, 13, 1); dev_fetch(c, bvec, 14, 1);
+        // last fold (length 2 -> 1) in place on the current set; s gets its final coefficients
+        Fr *afin = abuf[round & 1], *bvec = bbuf[round & 1], *sfin = sbuf[round & 1];
+        if (round) dev_bullet_step(c, afin, bvec, sfin, Rsz, 1, true, u, ui, S.rows.p, S.extras.p);
+        dev_fetch(c, afin, 13, 1); dev_fetch(c, bvec, 14, 1);
         // delta = d * g_hat + r_delta * h with g_hat = sum_j s[j] P[j]
-        dev_scale(c, S.s.p, d, S.rows.p, Rsz);
+        dev_scale(c, sfin, d, S.rows.p, Rsz);
         OTTI_HIP(hipMemcpyAsync(S.extras.p, &r_delta, sizeof(Fr), hipMemcpyHostToDevice, c.stream));
         unsigned long long tk_delta;
         { uint32_t hb = g.pc_1.h; tk_delta = dev_msm_rows(c, DG, S.rows.p, Rsz, Rsz, 1, S.extras.p, &hb, 1); }
