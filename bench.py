@@ -9,7 +9,12 @@ metric = BASELINE.json's "R1CS constraints/sec proved" on the synthetic 2^20-con
 Every timed proof is checked: all K proofs of a rank are byte-identical (fixed random-tape seed) and the product verifier
 accepts them; rank 0 additionally compares a 2^12 proof with the CPU oracle (checker only, outside the timed region).
 
-N > 1 (this round): each rank proves its own independent instance of the same size — no data-path collective; scaling = weak.
+N > 1, default: each rank proves its own independent instance of the same size — no data-path collective; scaling = weak
+(proofs are independent objects; this is how a node serves a stream of Otti proofs).
+N > 1 with --shard: ALL ranks prove ONE instance together (commitment rows, sum-check tables and the sparse
+matrices are sharded; per-round sums cross ranks through the node-local mailbox of otti_amd/csrc/shard.h; the witness is
+replicated beforehand with a torch.distributed broadcast over RCCL/xGMI); value = N / time of that one proof; scaling = strong.
+OTTI_BENCH_REHEARSE=1 puts every rank on GPU 0 with the gloo backend (how the sharded mode is rehearsed on a one-GPU box).
 """
 import argparse
 import hashlib
@@ -41,11 +46,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist", choices=("uniform", "compiler"), default="uniform", help="synthetic instance distribution (SURVEY 8d); the metric is quoted on 'uniform'")
     ap.add_argument("--cpu-log2", type=int, default=None, help="size of the CPU-baseline sample (default: same workload)")
+    ap.add_argument("--shard", action="store_true", help="N > 1: all ranks prove ONE instance together (strong scaling) instead of one proof per GPU")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    rehearse = bool(os.environ.get("OTTI_BENCH_REHEARSE"))
+    if rehearse:
+        local_rank = 0
     os.environ.setdefault("OTTI_DEVICE", str(local_rank))
     dist = None
     if world > 1 or os.environ.get("OTTI_FORCE_DIST"):      # OTTI_FORCE_DIST: exercise the RCCL path on a one-GPU box
@@ -53,7 +62,12 @@ def main():
         import torch.distributed as dist_mod
         dist = dist_mod
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    xdev = "cpu" if rehearse else "cuda"                     # where tensors handed to torch.distributed live
+    shard = bool(args.shard and world > 1)
 
     import numpy as np
     import otti_amd as oa
@@ -64,10 +78,20 @@ def main():
     lg = args.log2_constraints
     n, ni, label, seed = 1 << lg, 10, b"nizk_example", b"\x2a" * 32
     gen = oa.synth_r1cs if args.dist == "uniform" else oa.synth_r1cs_compiler_like
-    r = gen(n, ni, 1 + rank)                               # each rank its own instance
+    r = gen(n, ni, 1 if shard else 1 + rank)               # one proof per GPU: each rank its own instance; --shard: the same one
     inst = oa.Instance.new(r["num_cons"], r["num_vars"], r["num_inputs"], r["A"], r["B"], r["C"])
     gens = oa.NIZKGens.new(r["num_cons"], r["num_vars"], r["num_inputs"])
     vars_, inputs = oa.VarsAssignment.new(r["vars"]), oa.InputsAssignment.new(r["inputs"])
+    if shard:
+        # the instance is public (every rank builds it); the WITNESS exists on rank 0 only and reaches the other GPUs over RCCL/xGMI
+        import torch
+        wbuf = torch.from_numpy(np.ascontiguousarray(r["vars"])).to(xdev) if rank == 0 else torch.zeros((r["vars"].shape[0], 32), dtype=torch.uint8, device=xdev)
+        ibuf = torch.from_numpy(np.ascontiguousarray(r["inputs"])).to(xdev) if rank == 0 else torch.zeros((ni, 32), dtype=torch.uint8, device=xdev)
+        dist.broadcast(wbuf, src=0); dist.broadcast(ibuf, src=0)
+        vars_, inputs = oa.VarsAssignment.new(wbuf.cpu().numpy()), oa.InputsAssignment.new(ibuf.cpu().numpy())
+        name = [("otti-bench-%d-%d" % (os.getpid(), time.time_ns())) if rank == 0 else None]
+        dist.broadcast_object_list(name, src=0)
+        oa.shard_init(name[0], rank, world)
     inst.prepare_device(gens)                              # CSR upload + generator window table: resident before timing
     t0 = time.perf_counter()
     wit = oa.Witness(inst, vars_, inputs)                  # witness resident in HBM before timing
@@ -82,12 +106,15 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    def prove_once():
+        return oa.NIZK.prove_sharded(inst, wit, gens, label, seed) if shard else oa.NIZK.prove(inst, wit, None, gens, label, seed)
+
     proofs = []
     for _ in range(args.warmup):
-        proofs.append(oa.NIZK.prove(inst, wit, None, gens, label, seed))
+        proofs.append(prove_once())
     # one untimed, fully instrumented proof: per-class kernel time -> picks the dominant kernel class
     oa.stats_enable(True)
-    oa.NIZK.prove(inst, wit, None, gens, label, seed)
+    prove_once()
     breakdown = oa.stats_read()
     # dominant kernel = the streaming/ALU kernel class with the largest summed time.  "msm_small" is the same k_msm_rows kernel in
     # its one/two-row launches of the bullet reduction (latency-bound by construction); it is reported in kernel_ms_per_step only.
@@ -98,7 +125,7 @@ def main():
     t0 = time.perf_counter()
     stage_acc = {}
     for _ in range(args.steps):
-        p = oa.NIZK.prove(inst, wit, None, gens, label, seed)   # returns after the library's stream has been synchronised
+        p = prove_once()                                       # returns after the library's stream has been synchronised
         proofs.append(p)
         for k, v in p.stage_ms.items():
             stage_acc[k] = stage_acc.get(k, 0.0) + v
@@ -116,9 +143,15 @@ def main():
 
     if dist is not None:
         import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        if shard:                                               # every rank must hold the same proof
+            dg = torch.frombuffer(bytearray(hashlib.sha256(proofs[-1].bytes).digest()), dtype=torch.uint8).to(xdev)
+            every = [torch.zeros_like(dg) for _ in range(world)]
+            dist.all_gather(every, dg)
+            assert all(bool((e == dg).all()) for e in every), "ranks of a sharded proof returned different bytes"
+            oa.shard_finalize()
 
     if rank != 0:
         if dist is not None:
@@ -127,7 +160,7 @@ def main():
 
     steps = max(1, args.steps)
     ms_per_step = 1e3 * elapsed / steps
-    value = world * n * steps / elapsed
+    value = (1 if shard else world) * n * steps / elapsed
 
     # oracle cross-check of the GPU path (checker only; small size, outside the timed region)
     import orc
@@ -157,6 +190,8 @@ def main():
             bytes_per_launch = (80 * nnz + 160 * V + 128 * N) / 2.0
         else:
             bytes_per_launch = algorithmic_bytes(N, V, nnz) / max(1, cnt / steps)
+        if shard:
+            bytes_per_launch /= world                      # each rank's launch covers 1/world of the rows / table
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
         traffic = None
         try:   # HBM traffic of the dominant kernel's largest launch, from a separate rocprofv3 --pmc pass (profiles/, see its note)
@@ -172,7 +207,7 @@ def main():
         if dom == "msm_rows":
             cbits = int(os.environ.get("OTTI_MSM_WINDOW", "12"))
             W = 253 // cbits + 1
-            adds = V * W                                   # one mixed addition (7 multiplications in GF(2^255-19)) per scalar and window
+            adds = V * W // (world if shard else 1)        # one mixed addition (7 multiplications in GF(2^255-19)) per scalar and window
             rate = adds / (avg_ms * 1e-3)
             roofline["alu"] = {"bound": "integer ALU (v_mad_u64_u32)", "achieved": round(rate / 1e9, 3), "peak": MADD_PEAK_G, "unit": "G mixed additions/s",
                                "frac": round(rate / 1e9 / MADD_PEAK_G, 4),
@@ -202,17 +237,17 @@ def main():
     out = {
         "metric": "R1CS constraints/sec proved (Spartan NIZK) at 2^%d" % lg, "value": round(value, 1), "unit": "constraints/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "u256 (GF(l) / GF(2^255-19), 8 x u32 limbs)", "data": "synthetic",
+        "scaling": "strong" if shard else "weak", "vs_baseline": None, "dtype": "u256 (GF(l) / GF(2^255-19), 8 x u32 limbs)", "data": "synthetic",
         "config": {"workload": (f"synthetic satisfiable R1CS, 2^{lg} constraints = variables, 10 inputs, 1 nnz/row/matrix, uniform GF(l) witness "
                                 if args.dist == "uniform" else
                                 f"synthetic compiler-like R1CS, 2^{lg} constraints = variables, 10 inputs, 1..8 nnz/row/matrix, 90% of the witness < 2^64, heavy constant column ")
                                + "(SURVEY 8d); one NIZK::prove per step, witness/instance/generators resident in HBM",
-                   "parallelism": "1 proof per GPU" if world > 1 else "single GPU", "msm_window_bits": int(os.environ.get("OTTI_MSM_WINDOW", "12"))},
+                   "parallelism": ("1 proof sharded over %d GPUs" % world if shard else "1 proof per GPU") if world > 1 else "single GPU", "msm_window_bits": int(os.environ.get("OTTI_MSM_WINDOW", "12"))},
         "roofline": roofline,
         "cpu_baseline": cpu_baseline,
         "stage_ms": {k: round(v / steps, 3) for k, v in stage_acc.items()},
         "kernel_ms_per_step": {k: round(v[1], 3) for k, v in breakdown.items() if v[0]},
-        "whole_proof_algorithmic_GBps": round(proof_gbps, 2), "whole_proof_hbm_frac": round(proof_gbps / (HBM_PEAK_GBPS * world), 6),
+        "whole_proof_algorithmic_GBps": round(proof_gbps, 2), "whole_proof_hbm_frac": round(proof_gbps / (HBM_PEAK_GBPS * (world if shard else 1)), 6),
         "witness_upload_ms": round(1e3 * t_upload, 2), "verify_ms": round(1e3 * t_verify, 2), "proof_bytes": len(proofs[-1].bytes), "proof_sha256": next(iter(digests)),
         "oracle_parity_2^12": parity_ok,
     }

@@ -81,6 +81,20 @@ int32_t otti_witness_upload(otti_instance *inst, const uint8_t *vars32, size_t n
 void    otti_witness_free(otti_witness *w);
 int32_t otti_nizk_prove_resident(otti_instance *inst, otti_witness *wit, otti_gens *gens, const uint8_t *tlabel, size_t tlabel_len,
                                  const uint8_t *seed32, uint8_t **proof, size_t *proof_len, double *stage_ms);
+/* ---- one proof over several GPUs of one node (no reference counterpart: upstream `spzk` is one process
+   [REF /root/reference/run.py:52-59]).  One process per GPU.  Every process calls otti_shard_init with the same segment name (a
+   fresh, unique name per job: it names a POSIX shared-memory object, removed again once all ranks are attached), its rank and the
+   world size (a power of two, at most the number of witness-matrix rows); then each calls otti_nizk_prove_sharded with the SAME
+   instance, witness, generators, label and seed.  Every rank returns the same proof bytes, identical to otti_nizk_prove_resident's.
+   While proving, ranks exchange only what the host has to hash anyway (per-round sums, row commitments, the partial L^T Z vector)
+   through that segment; the witness is replicated by the caller beforehand (e.g. torch.distributed broadcast over RCCL).
+   otti_shard_allgather / otti_shard_allreduce are the exchange primitives themselves (host memory; usable without a GPU). */
+int32_t otti_shard_init(const char *segment_name, uint32_t rank, uint32_t world);
+int32_t otti_shard_finalize(void);
+int32_t otti_shard_allgather(const void *mine, size_t nbytes, void *out /* world * nbytes */);
+int32_t otti_shard_allreduce(uint8_t *scalars32 /* canonical, in place */, size_t count);
+int32_t otti_nizk_prove_sharded(otti_instance *inst, otti_witness *wit, otti_gens *gens, const uint8_t *tlabel, size_t tlabel_len,
+                                const uint8_t *seed32, uint8_t **proof, size_t *proof_len, double *stage_ms);
 /* NIZK::verify(&self, &inst, &inputs, &mut Transcript::new(tlabel), &gens) -> Result<(), ProofVerifyError> */
 int32_t otti_nizk_verify(const otti_instance *inst, const uint8_t *inputs32, size_t ninputs, const otti_gens *gens,
                          const uint8_t *tlabel, size_t tlabel_len, const uint8_t *proof, size_t proof_len);

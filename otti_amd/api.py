@@ -75,6 +75,12 @@ _sig("otti_witness_upload", _i32, _vp, _vp, _sz, _vp, _sz, ctypes.POINTER(_vp))
 _sig("otti_witness_free", None, _vp)
 _sig("otti_nizk_prove_resident", _i32, _vp, _vp, _vp, ctypes.c_char_p, _sz, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_sz),
      ctypes.POINTER(ctypes.c_double))
+_sig("otti_shard_init", _i32, ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint32)
+_sig("otti_shard_finalize", _i32)
+_sig("otti_shard_allgather", _i32, _vp, _sz, _vp)
+_sig("otti_shard_allreduce", _i32, _vp, _sz)
+_sig("otti_nizk_prove_sharded", _i32, _vp, _vp, _vp, ctypes.c_char_p, _sz, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_sz),
+     ctypes.POINTER(ctypes.c_double))
 _sig("otti_nizk_verify", _i32, _vp, _vp, _sz, _vp, ctypes.c_char_p, _sz, _vp, _sz)
 _sig("otti_prepare_device", _i32, _vp, _vp)
 _sig("otti_zkif_load", _i32, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.POINTER(_R1CS)))
@@ -280,12 +286,45 @@ class NIZK:
                                    ctypes.byref(p), ctypes.byref(n), ms))
         return cls(cls._take(p, n), dict(zip(STAGES, ms)))
 
+    @classmethod
+    def prove_sharded(cls, inst, witness, gens, transcript_label=b"nizk_example", seed=None):
+        """This rank's part of ONE proof spread over the GPUs of a node (collective over the ranks of ``shard_init``; every rank
+        passes the same instance, resident witness, generators, label and 32-byte seed and gets the same proof bytes back)."""
+        label = bytes(transcript_label)
+        p, n, ms = _vp(), _sz(), (ctypes.c_double * 8)()
+        _check(lib.otti_nizk_prove_sharded(inst._h, witness._h, gens._h, label, len(label), _seed(seed), ctypes.byref(p), ctypes.byref(n), ms))
+        return cls(cls._take(p, n), dict(zip(STAGES, ms)))
+
     def verify(self, inst, inputs, gens, transcript_label=b"nizk_example"):
         """Ok(()) -> None; Err(ProofVerifyError) -> raises"""
         label = bytes(transcript_label)
         i = _scalars(inputs.assignment, "inputs")
         buf = np.frombuffer(self.bytes, dtype=np.uint8)
         _check(lib.otti_nizk_verify(inst._h, _ptr(i), i.shape[0], gens._h, label, len(label), _ptr(buf), buf.size))
+
+
+def shard_init(segment_name, rank, world):
+    """Join the node-local exchange of a sharded proof (collective; ``segment_name`` must be fresh and the same on every rank)."""
+    _check(lib.otti_shard_init(str(segment_name).encode(), rank, world))
+
+
+def shard_finalize():
+    _check(lib.otti_shard_finalize())
+
+
+def shard_allgather(mine, world):
+    """Exchange primitive: every rank's ``mine`` (bytes of equal length), concatenated in rank order."""
+    mine = bytes(mine)
+    out = ctypes.create_string_buffer(len(mine) * world)
+    _check(lib.otti_shard_allgather(ctypes.cast(ctypes.c_char_p(mine), _vp), len(mine), ctypes.cast(out, _vp)))
+    return out.raw
+
+
+def shard_allreduce(scalars32):
+    """Exchange primitive: element-wise sum over ranks of canonical GF(l) scalars, shape (n, 32) uint8."""
+    a = np.ascontiguousarray(scalars32, dtype=np.uint8).reshape(-1, 32).copy()
+    _check(lib.otti_shard_allreduce(_ptr(a), a.shape[0]))
+    return a
 
 
 def _seed(seed):

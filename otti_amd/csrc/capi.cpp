@@ -1,5 +1,6 @@
 // extern "C" surface of libottispartan (include/otti_spartan.h).  No exception crosses this boundary.
 #include "device.h"
+#include "shard.h"
 #include <array>
 #include <mutex>
 
@@ -123,6 +124,43 @@ int32_t otti_nizk_prove_resident(otti_instance *inst, otti_witness *wit, otti_ge
         if (!inst || !wit || !gens || !proof || !proof_len) throw Error(OTTI_ERR_BAD_ARG, "null argument");
         ProveTimings tm{};
         std::vector<uint8_t> pf = nizk_prove_resident(*inst->I, *wit->w, *gens->g, tlabel, tlabel_len, seed32, &tm);
+        if (stage_ms) memcpy(stage_ms, tm.ms, sizeof tm.ms);
+        *proof = to_malloc(pf, proof_len); return OTTI_OK;
+    });
+}
+int32_t otti_shard_init(const char *segment_name, uint32_t rank, uint32_t world) {
+    return guarded([&] {
+        if (!segment_name) throw Error(OTTI_ERR_BAD_ARG, "null argument");
+        shard_comm_set(nullptr);
+        shard_comm_set(new ShardComm(segment_name, (int)rank, (int)world));
+        return OTTI_OK;
+    });
+}
+int32_t otti_shard_finalize(void) { return guarded([&] { shard_comm_set(nullptr); return OTTI_OK; }); }
+int32_t otti_shard_allgather(const void *mine, size_t nbytes, void *out) {
+    return guarded([&] {
+        if (!shard_comm()) throw Error(OTTI_ERR_BAD_ARG, "otti_shard_init has not been called");
+        if (!mine || !out) throw Error(OTTI_ERR_BAD_ARG, "null argument");
+        shard_comm()->allgather(mine, nbytes, out); return OTTI_OK;
+    });
+}
+int32_t otti_shard_allreduce(uint8_t *scalars32, size_t count) {
+    return guarded([&] {
+        if (!shard_comm()) throw Error(OTTI_ERR_BAD_ARG, "otti_shard_init has not been called");
+        std::vector<Fr> v = scalars_from_bytes(scalars32, count);
+        shard_comm()->allreduce_fr(v.data(), count);
+        for (size_t i = 0; i < count; i++) fr_to_bytes(scalars32 + 32 * i, v[i]);
+        return OTTI_OK;
+    });
+}
+int32_t otti_nizk_prove_sharded(otti_instance *inst, otti_witness *wit, otti_gens *gens, const uint8_t *tlabel, size_t tlabel_len,
+                                const uint8_t *seed32, uint8_t **proof, size_t *proof_len, double *stage_ms) {
+    return guarded([&] {
+        if (!inst || !wit || !gens || !proof || !proof_len) throw Error(OTTI_ERR_BAD_ARG, "null argument");
+        if (!shard_comm()) throw Error(OTTI_ERR_BAD_ARG, "otti_shard_init has not been called");
+        if (!seed32) throw Error(OTTI_ERR_BAD_ARG, "a sharded proof needs an explicit random-tape seed (the same on every rank)");
+        ProveTimings tm{};
+        std::vector<uint8_t> pf = nizk_prove_resident(*inst->I, *wit->w, *gens->g, tlabel, tlabel_len, seed32, &tm, shard_comm());
         if (stage_ms) memcpy(stage_ms, tm.ms, sizeof tm.ms);
         *proof = to_malloc(pf, proof_len); return OTTI_OK;
     });

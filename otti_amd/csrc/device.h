@@ -34,6 +34,10 @@ struct DeviceCsrSet {
     DCsr3 view() const { DCsr3 v; for (int k = 0; k < 3; k++) { v.ptr[k] = ptr[k].p; v.idx[k] = idx[k].p; v.val[k] = val[k].p; } return v; }
 };
 struct DeviceInstance { DeviceCsrSet by_row, by_col; size_t nnz = 0; };
+// Rank k of g holds the constraint rows r = k (mod g) (renumbered r / g, columns untouched: multiply_vec output lands where the
+// low-bit-sharded phase-one tables need it) and, as a second copy, the entries of columns c = k (mod g) (renumbered c / g, rows
+// untouched: compute_eval_table_sparse output lands where the phase-two tables need it).  SURVEY.md 8(e).
+struct DeviceShard { int rank = 0, world = 1; DeviceCsrSet by_row, by_col; };
 
 // fixed-base window table: entry (base b, window w, digit d in 1..E) = d * 2^(c*w) * P[b] in affine Niels form
 struct DeviceGens {
@@ -95,8 +99,14 @@ struct DeviceWitness {
 void ensure_device_objects(Instance &I, Gens &g);
 // R1CSInstance::evaluate on the device: (A,B,C)(rx,ry) = <eq(rx), M * eq(ry)> for M in {A,B,C}  (verifier's O(nnz + N + V) work)
 void instance_evaluate_gpu(Instance &I, const std::vector<Fr> &rx, const std::vector<Fr> &ry, Fr out[3]);
+// sh == nullptr (or a world of one): the whole proof on this GPU.  Otherwise this process proves its shard of the SAME proof as the
+// other ranks of sh (collective call: same instance, witness, generators, label and seed on every rank); every rank returns the
+// same bytes, equal to the single-GPU proof.
+class ShardComm;
 std::vector<uint8_t> nizk_prove_resident(Instance &I, DeviceWitness &wit, Gens &g, const void *tlabel, size_t tlabel_len, const uint8_t *seed32,
-                                         ProveTimings *tm);
+                                         ProveTimings *tm, ShardComm *sh = nullptr);
+std::shared_ptr<DeviceShard> upload_instance_shard(const Instance &I, int rank, int world);
+void dev_gather_strided(DevCtx &c, const Fr *in, size_t stride, size_t offset, Fr *out, size_t n);   // out[i] = in[i*stride + offset]
 
 std::shared_ptr<DeviceInstance> upload_instance(const Instance &I);
 std::shared_ptr<DeviceGens> build_device_gens(const Gens &g, int window_bits);

@@ -284,6 +284,34 @@ std::shared_ptr<DeviceInstance> upload_instance(const Instance &I) {
     return d;
 }
 
+std::shared_ptr<DeviceShard> upload_instance_shard(const Instance &I, int rank, int world) {
+    DevCtx::get();
+    if (world < 1 || (world & (world - 1)) || rank < 0 || rank >= world || (size_t)world > I.num_cons || (size_t)world > 2 * I.num_vars)
+        throw Error(OTTI_ERR_BAD_ARG, "shard: world must be a power of two not larger than the instance");
+    auto d = std::make_shared<DeviceShard>();
+    d->rank = rank; d->world = world;
+    const uint32_t g = (uint32_t)world, k = (uint32_t)rank;
+    SparseMat rows[3], cols[3];
+    for (int m = 0; m < 3; m++) {
+        const SparseMat &M = I.M[m];
+        for (size_t e = 0; e < M.val.size(); e++) {
+            if (M.row[e] % g == k) { rows[m].row.push_back(M.row[e] / g); rows[m].col.push_back(M.col[e]); rows[m].val.push_back(M.val[e]); }
+            if (M.col[e] % g == k) { cols[m].row.push_back(M.row[e]); cols[m].col.push_back(M.col[e] / g); cols[m].val.push_back(M.val[e]); }
+        }
+        build_csr(rows[m].by_row, rows[m].row, rows[m].col, rows[m].val, I.num_cons / g);
+        build_csr(cols[m].by_col, cols[m].col, cols[m].row, cols[m].val, 2 * I.num_vars / g);
+    }
+    upload_csr_set(d->by_row, rows, false); upload_csr_set(d->by_col, cols, true);
+    return d;
+}
+__global__ __launch_bounds__(kBlock) void k_gather_strided(const Fr *in, size_t stride, size_t offset, Fr *out, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = in[i * stride + offset];
+}
+void dev_gather_strided(DevCtx &c, const Fr *in, size_t stride, size_t offset, Fr *out, size_t n) {
+    KScope ks(c, KC_OTHER);
+    hipLaunchKernelGGL(k_gather_strided, grid_for(n), kBlock, 0, c.stream, in, stride, offset, out, n);
+}
+
 // ------------------------------------------------------------------------------------------------ K2 eq tables
 struct FrArgs { Fr v[13]; };
 // one workgroup builds eq(r, .) for ell <= 12 by doubling, ping-ponging between two global buffers

@@ -8,6 +8,7 @@
 // fused fold+evaluate kernel before finishing the round's O(1) sigma-protocol work, so the two overlap.
 #include "device.h"
 #include "pool.h"
+#include "shard.h"
 #include <chrono>
 #include <mutex>
 
@@ -103,8 +104,36 @@ Scratch &workspace() { static Scratch s; return s; }
 inline CPoint point_at(const DevCtx &c, size_t i) { CPoint p; memcpy(p.b, c.h_points + 32 * i, 32); return p; }
 }  // namespace
 
+// The last log2(g) rounds of a sharded sum-check: every rank holds the same g-element tables on the host (one element came from each
+// rank) and plays the rounds there.  Same arithmetic as k_sc_cubic_eval / k_sc_quad_eval / k_fold_top.
+static void host_cubic_evals(const std::vector<Fr> T[4], Fr e[3]) {
+    const size_t h = T[0].size() / 2;
+    e[0] = e[1] = e[2] = fr_zero();
+    for (size_t i = 0; i < h; i++) {
+        Fr lo[4], hi[4], p2[4], p3[4];
+        for (int k = 0; k < 4; k++) { lo[k] = T[k][i]; hi[k] = T[k][h + i]; Fr d = fr_sub(hi[k], lo[k]); p2[k] = fr_add(hi[k], d); p3[k] = fr_add(p2[k], d); }
+        e[0] = fr_add(e[0], fr_mul(lo[0], fr_sub(fr_mul(lo[1], lo[2]), lo[3])));
+        e[1] = fr_add(e[1], fr_mul(p2[0], fr_sub(fr_mul(p2[1], p2[2]), p2[3])));
+        e[2] = fr_add(e[2], fr_mul(p3[0], fr_sub(fr_mul(p3[1], p3[2]), p3[3])));
+    }
+}
+static void host_quad_evals(const std::vector<Fr> T[2], Fr e[2]) {
+    const size_t h = T[0].size() / 2;
+    e[0] = e[1] = fr_zero();
+    for (size_t i = 0; i < h; i++) {
+        Fr a2 = fr_add(T[0][h + i], fr_sub(T[0][h + i], T[0][i])), b2 = fr_add(T[1][h + i], fr_sub(T[1][h + i], T[1][i]));
+        e[0] = fr_add(e[0], fr_mul(T[0][i], T[1][i]));
+        e[1] = fr_add(e[1], fr_mul(a2, b2));
+    }
+}
+static void host_fold_top(std::vector<Fr> &t, const Fr &r) {
+    const size_t h = t.size() / 2;
+    for (size_t i = 0; i < h; i++) t[i] = fr_add(t[i], fr_mul(r, fr_sub(t[h + i], t[i])));
+    t.resize(h);
+}
+
 std::vector<uint8_t> nizk_prove_resident(Instance &I, DeviceWitness &wit, Gens &g, const void *tlabel, size_t tlabel_len, const uint8_t *seed32,
-                                         ProveTimings *tm) {
+                                         ProveTimings *tm, ShardComm *sh) {
     static std::mutex prove_mu;                                   // one stream, one workspace: proofs of a process run one at a time
     std::lock_guard<std::mutex> lock(prove_mu);
     DevCtx &c = DevCtx::get();
@@ -115,12 +144,22 @@ std::vector<uint8_t> nizk_prove_resident(Instance &I, DeviceWitness &wit, Gens &
     const size_t ell = ilog2(V), Lsz = (size_t)1 << (ell / 2), Rsz = (size_t)1 << (ell - ell / 2);
     if (g.num_vars_padded != V || g.R != Rsz) throw Error(OTTI_ERR_BAD_ARG, "generators were made for a different instance size");
     if (wit.inputs.size() != I.num_inputs) throw Error(OTTI_ERR_INVALID_NUM_INPUTS, "wrong number of inputs");
+    // sharding: rank rk of G.  Tables are split by the LOW log2(G) index bits, so bound_poly_var_top's pairs (i, i + n/2)
+    // stay on one GPU until a table is down to G elements; witness-matrix rows are split in G contiguous blocks.
+    if (sh && sh->world() == 1) sh = nullptr;
+    const size_t G = sh ? (size_t)sh->world() : 1, rk = sh ? (size_t)sh->rank() : 0, lgG = ilog2(G);
+    const size_t Nl = N / G, V2l = 2 * V / G, Ll = Lsz / G;
+    if (sh) {
+        if (Nl < 2 || V2l < 2 || Ll < 1) throw Error(OTTI_ERR_BAD_ARG, "instance too small to shard over this many GPUs");
+        if (!I.shard || I.shard->rank != (int)rk || I.shard->world != (int)G) I.shard = upload_instance_shard(I, (int)rk, (int)G);
+    }
+    const DeviceCsrSet &rows_set = sh ? I.shard->by_row : DI.by_row, &cols_set = sh ? I.shard->by_col : DI.by_col;
 
     double t_start = now_ms(), t0; ProveTimings T{};
     const size_t lgR = ilog2(Rsz);
     Scratch &S = workspace();
     S.reserve(N, V, Lsz, Rsz, lgR);
-    const Fr *d_vars = wit.z.p;
+    const Fr *d_vars = wit.z.p, *my_rows = d_vars + rk * Ll * Rsz;         // this rank's block of witness-matrix rows
 
     Transcript tr(tlabel, tlabel_len);
     RandomTape tape(seed32);
@@ -131,7 +170,7 @@ std::vector<uint8_t> nizk_prove_resident(Instance &I, DeviceWitness &wit, Gens &
     // ---- polycommit: DensePolynomial::commit (K8).  The witness terms of every row are summed first (no host input needed);
     // meanwhile the host draws the whole random tape (its label sequence is known in advance); the blind terms are added last.
     t0 = now_ms();
-    dev_msm_rows(c, DG, d_vars, Rsz, Rsz, Lsz, nullptr, nullptr, 0, MSM_KEEP);
+    dev_msm_rows(c, DG, my_rows, Rsz, Rsz, Ll, nullptr, nullptr, 0, MSM_KEEP);
     {
         std::vector<std::pair<const char *, size_t>> sched;
         auto sumcheck_sched = [&](size_t rounds, size_t ne) {
@@ -147,13 +186,15 @@ std::vector<uint8_t> nizk_prove_resident(Instance &I, DeviceWitness &wit, Gens &
         tape.prefetch(sched);
     }
     std::vector<Fr> blinds_vars = tape.random_vector("poly_blinds", Lsz);
-    OTTI_HIP(hipMemcpyAsync(S.blinds.p, blinds_vars.data(), Lsz * sizeof(Fr), hipMemcpyHostToDevice, c.stream));
+    OTTI_HIP(hipMemcpyAsync(S.blinds.p, blinds_vars.data() + rk * Ll, Ll * sizeof(Fr), hipMemcpyHostToDevice, c.stream));
     {
         uint32_t hbase = g.pc_n.h;
-        dev_msm_rows(c, DG, nullptr, 0, 0, Lsz, S.blinds.p, &hbase, 1, MSM_COMPRESSED, c.msm_keep.p);
+        dev_msm_rows(c, DG, nullptr, 0, 0, Ll, S.blinds.p, &hbase, 1, MSM_COMPRESSED, c.msm_keep.p);
         c.sync();
         P.comm_vars.resize(Lsz);
-        for (size_t i = 0; i < Lsz; i++) P.comm_vars[i] = point_at(c, i);
+        static_assert(sizeof(CPoint) == 32, "CPoint is 32 packed bytes");
+        if (sh) sh->allgather(c.h_points, Ll * 32, P.comm_vars.data());       // rank order = row-block order
+        else for (size_t i = 0; i < Lsz; i++) P.comm_vars[i] = point_at(c, i);
         tr.append_message("poly_commitment", "poly_commitment_begin", 21);
         for (auto &cp : P.comm_vars) tr.append_point("poly_commitment_share", cp.b);
         tr.append_message("poly_commitment", "poly_commitment_end", 19);
@@ -163,8 +204,10 @@ std::vector<uint8_t> nizk_prove_resident(Instance &I, DeviceWitness &wit, Gens &
     // ---- tau, eq(tau), Az/Bz/Cz (K2, K1)
     t0 = now_ms();
     std::vector<Fr> tau = tr.challenge_vector("challenge_tau", nrx);
-    dev_eq_evals(c, tau.data(), nrx, S.T[0].p, S.eqs.p);
-    dev_spmv3(c, DI.by_row, wit.z.p, S.T[1].p, S.T[2].p, S.T[3].p, false, nullptr);
+    // local eq table: eq(tau, i'*G + rk) = eq(tau_hi, i') * eq(tau_lo, rk)  (index bits are MSB-first over tau)
+    dev_eq_evals(c, tau.data(), nrx - lgG, S.T[0].p, S.eqs.p);
+    if (sh) dev_scale(c, S.T[0].p, eq_evals_host(tau.data() + (nrx - lgG), lgG)[rk], S.T[0].p, Nl);
+    dev_spmv3(c, rows_set, wit.z.p, S.T[1].p, S.T[2].p, S.T[3].p, false, nullptr);
     c.sync();
     T.ms[1] = now_ms() - t0;
 
@@ -179,27 +222,45 @@ std::vector<uint8_t> nizk_prove_resident(Instance &I, DeviceWitness &wit, Gens &
         st.claim = fr_zero(); st.blind_claim = fr_zero();
         { Term t2[2] = {{g.sc_1.G[0], fr_zero()}, {g.sc_1.h, fr_zero()}}; g.commit_terms_c(st.comm_claim.b, t2, 2); }
         P.sc1.comm_polys.resize(nrx); P.sc1.comm_evals.resize(nrx); P.sc1.proofs.resize(nrx);
-        unsigned long long ticket = dev_sc_cubic_eval(c, S.T[0].p, S.T[1].p, S.T[2].p, S.T[3].p, N, 0);
+        std::vector<Fr> tail1[4];
+        unsigned long long ticket = dev_sc_cubic_eval(c, S.T[0].p, S.T[1].p, S.T[2].p, S.T[3].p, Nl, 0);
         double tw = 0, tb = 0, tl = 0, tf = 0, ta;
+        const size_t ndev = nrx - lgG;                                           // rounds played on the device tables
         for (size_t j = 0; j < nrx; j++) {
-            ta = now_ms(); c.wait_ticket(ticket); tw += now_ms() - ta;
-            Fr ev[4] = {c.h_results[0], fr_sub(st.claim, c.h_results[0]), c.h_results[1], c.h_results[2]};
+            Fr e[3];
+            ta = now_ms();
+            if (j < ndev) {
+                c.wait_ticket(ticket);
+                e[0] = c.h_results[0]; e[1] = c.h_results[1]; e[2] = c.h_results[2];
+                if (sh) sh->allreduce_fr(e, 3);                                  // per-round exchange: 96 bytes per rank
+            } else host_cubic_evals(tail1, e);
+            tw += now_ms() - ta;
+            Fr ev[4] = {e[0], fr_sub(st.claim, e[0]), e[1], e[2]};
             ta = now_ms();
             RoundPart1 p1 = sumcheck_round_begin(P.sc1, j, ev, 4, st, g, g.sc_4, tr);
             tb += now_ms() - ta; ta = now_ms();
             P.rx[j] = p1.r_j;
-            size_t len = N >> j;
-            if (len >= 4) ticket = dev_sc_cubic_fold_eval(c, S.T[0].p, S.T[1].p, S.T[2].p, S.T[3].p, len, p1.r_j, 0);
-            else for (auto &t : S.T) dev_fold_top(c, t.p, len, p1.r_j);
+            if (j < ndev) {
+                size_t len = Nl >> j;
+                if (len >= 4) ticket = dev_sc_cubic_fold_eval(c, S.T[0].p, S.T[1].p, S.T[2].p, S.T[3].p, len, p1.r_j, 0);
+                else for (auto &t : S.T) dev_fold_top(c, t.p, len, p1.r_j);
+            } else for (auto &t : tail1) host_fold_top(t, p1.r_j);
             tl += now_ms() - ta; ta = now_ms();
             sumcheck_round_finish(P.sc1, j, p1, st, g, g.sc_4, tr);             // overlaps the device fold
             tf += now_ms() - ta;
+            if (sh && j + 1 == ndev) {                                           // one element per table and rank is left: collect them
+                for (int k = 0; k < 4; k++) dev_fetch(c, S.T[k].p, 8 + k, 1);
+                c.sync();
+                std::vector<Fr> all(4 * G);
+                sh->allgather(&c.h_results[8], 4 * sizeof(Fr), all.data());
+                for (int k = 0; k < 4; k++) { tail1[k].resize(G); for (size_t r = 0; r < G; r++) tail1[k][r] = all[4 * r + k]; }
+            }
         }
         if (getenv("OTTI_TRACE")) fprintf(stderr, "[otti] phase1 rounds=%zu wait %.3f begin %.3f launch %.3f finish %.3f ms\n", nrx, tw, tb, tl, tf);
         blind_claim_postsc1 = st.blinds_evals[nrx - 1];
+        if (sh) for (int k = 0; k < 4; k++) c.h_results[8 + k] = tail1[k][0];
     }
-    for (int k = 0; k < 4; k++) dev_fetch(c, S.T[k].p, 8 + k, 1);
-    c.sync();
+    if (!sh) { for (int k = 0; k < 4; k++) dev_fetch(c, S.T[k].p, 8 + k, 1); c.sync(); }
     const Fr tau_claim = c.h_results[8], Az_claim = c.h_results[9], Bz_claim = c.h_results[10], Cz_claim = c.h_results[11];
     T.ms[2] = now_ms() - t0;
 
@@ -223,10 +284,11 @@ std::vector<uint8_t> nizk_prove_resident(Instance &I, DeviceWitness &wit, Gens &
     Fr blind_claim2 = fr_add(fr_add(fr_mul(rA, Az_blind), fr_mul(rB, Bz_blind)), fr_mul(rC, Cz_blind));
     t0 = now_ms();
     {
-        dev_eq_evals(c, P.rx.data(), nrx, S.T[0].p, S.eqs.p);
+        dev_eq_evals(c, P.rx.data(), nrx, S.T[0].p, S.eqs.p);                // the full table on every rank: its columns need every row
         Fr coef[3] = {rA, rB, rC};
-        dev_spmv3(c, DI.by_col, S.T[0].p, S.ABC.p, nullptr, nullptr, true, coef);
-        OTTI_HIP(hipMemcpyAsync(S.zw.p, wit.z.p, 2 * V * sizeof(Fr), hipMemcpyDeviceToDevice, c.stream));
+        dev_spmv3(c, cols_set, S.T[0].p, S.ABC.p, nullptr, nullptr, true, coef);
+        if (sh) dev_gather_strided(c, wit.z.p, G, rk, S.zw.p, V2l);
+        else OTTI_HIP(hipMemcpyAsync(S.zw.p, wit.z.p, 2 * V * sizeof(Fr), hipMemcpyDeviceToDevice, c.stream));
         c.sync();
     }
     T.ms[3] = now_ms() - t0;
@@ -242,21 +304,40 @@ std::vector<uint8_t> nizk_prove_resident(Instance &I, DeviceWitness &wit, Gens &
         st.claim = claim2; st.blind_claim = blind_claim2;
         { Term t2[2] = {{g.sc_1.G[0], claim2}, {g.sc_1.h, blind_claim2}}; g.commit_terms_c(st.comm_claim.b, t2, 2); }
         P.sc2.comm_polys.resize(nry); P.sc2.comm_evals.resize(nry); P.sc2.proofs.resize(nry);
-        unsigned long long ticket = dev_sc_quad_eval(c, S.zw.p, S.ABC.p, 2 * V, 0);
+        unsigned long long ticket = dev_sc_quad_eval(c, S.zw.p, S.ABC.p, V2l, 0);
+        std::vector<Fr> tail2[2];
+        const size_t ndev = nry - lgG;
         for (size_t j = 0; j < nry; j++) {
-            c.wait_ticket(ticket);
-            Fr ev[3] = {c.h_results[0], fr_sub(st.claim, c.h_results[0]), c.h_results[1]};
+            Fr e[2];
+            if (j < ndev) {
+                c.wait_ticket(ticket);
+                e[0] = c.h_results[0]; e[1] = c.h_results[1];
+                if (sh) sh->allreduce_fr(e, 2);
+            } else host_quad_evals(tail2, e);
+            Fr ev[3] = {e[0], fr_sub(st.claim, e[0]), e[1]};
             RoundPart1 p1 = sumcheck_round_begin(P.sc2, j, ev, 3, st, g, g.sc_3, tr);
             P.ry[j] = p1.r_j;
-            size_t len = (2 * V) >> j;
-            if (len >= 4) ticket = dev_sc_quad_fold_eval(c, S.zw.p, S.ABC.p, len, p1.r_j, 0);
-            else { dev_fold_top(c, S.zw.p, len, p1.r_j); dev_fold_top(c, S.ABC.p, len, p1.r_j); }
+            if (j < ndev) {
+                size_t len = V2l >> j;
+                if (len >= 4) ticket = dev_sc_quad_fold_eval(c, S.zw.p, S.ABC.p, len, p1.r_j, 0);
+                else { dev_fold_top(c, S.zw.p, len, p1.r_j); dev_fold_top(c, S.ABC.p, len, p1.r_j); }
+            } else for (auto &t : tail2) host_fold_top(t, p1.r_j);
             sumcheck_round_finish(P.sc2, j, p1, st, g, g.sc_3, tr);
+            if (sh && j + 1 == ndev) {
+                dev_fetch(c, S.zw.p, 8, 1); dev_fetch(c, S.ABC.p, 9, 1);
+                c.sync();
+                std::vector<Fr> all(2 * G);
+                sh->allgather(&c.h_results[8], 2 * sizeof(Fr), all.data());
+                for (int k = 0; k < 2; k++) { tail2[k].resize(G); for (size_t r = 0; r < G; r++) tail2[k][r] = all[2 * r + k]; }
+            }
         }
         blind_claim_postsc2 = st.blinds_evals[nry - 1];
-        dev_fetch(c, S.zw.p, 8, 1); dev_fetch(c, S.ABC.p, 9, 1);
-        c.sync();
-        claims_phase2[0] = c.h_results[8]; claims_phase2[1] = c.h_results[9];
+        if (sh) { claims_phase2[0] = tail2[0][0]; claims_phase2[1] = tail2[1][0]; }
+        else {
+            dev_fetch(c, S.zw.p, 8, 1); dev_fetch(c, S.ABC.p, 9, 1);
+            c.sync();
+            claims_phase2[0] = c.h_results[8]; claims_phase2[1] = c.h_results[9];
+        }
     }
     T.ms[4] = now_ms() - t0;
 
@@ -268,7 +349,15 @@ std::vector<uint8_t> nizk_prove_resident(Instance &I, DeviceWitness &wit, Gens &
         std::vector<Fr> Lv_host = eq_evals_host(r, lv);                             // L-side table also needed on the host for LZ_blind
         dev_eq_evals(c, r, lv, S.Lv.p, S.eqs.p);
         dev_eq_evals(c, r + lv, ell - lv, S.Rv.p, S.eqs.p);
-        dev_poly_bound(c, d_vars, Lsz, Rsz, S.Lv.p, S.LZ.p, S.bound_scratch.p);
+        dev_poly_bound(c, my_rows, Ll, Rsz, S.Lv.p + rk * Ll, S.LZ.p, S.bound_scratch.p);
+        if (sh) {                                                                    // partial L^T Z of this rank's rows -> sum over ranks
+            std::vector<Fr> lz(Rsz);
+            OTTI_HIP(hipMemcpyAsync(lz.data(), S.LZ.p, Rsz * sizeof(Fr), hipMemcpyDeviceToHost, c.stream));
+            c.sync();
+            sh->allreduce_fr(lz.data(), Rsz);
+            OTTI_HIP(hipMemcpyAsync(S.LZ.p, lz.data(), Rsz * sizeof(Fr), hipMemcpyHostToDevice, c.stream));
+            c.sync();                                                                // lz is about to go out of scope
+        }
         // Z(ry[1..]) = <L^T Z, R> because eq(r, i) factors as L[i_hi] * R[i_lo]
         dev_dot(c, S.LZ.p, S.Rv.p, Rsz, 12);
         Fr LZ_blind = fr_zero();

@@ -31,12 +31,15 @@ struct SparseMat {
 };
 
 struct DeviceInstance;   // kernels.hip
+struct DeviceShard;      // kernels.hip: this rank's slice of the instance when one proof runs over several GPUs (shard.h)
 struct DeviceGens;       // kernels.hip
+void build_csr(Csr &out, const std::vector<uint32_t> &major, const std::vector<uint32_t> &minor, const std::vector<Fr> &val, size_t rows);
 
 struct Instance {
     size_t num_cons = 0, num_vars = 0, num_inputs = 0;      // padded cons / vars (powers of two)
     SparseMat M[3];                                         // A, B, C
     std::shared_ptr<DeviceInstance> dev;                    // uploaded lazily on the first GPU prove
+    std::shared_ptr<DeviceShard> shard;                     // uploaded lazily on the first sharded prove
     // Fr tuple evaluation used by the verifier: (A,B,C)(rx, ry)
     void evaluate(const std::vector<Fr> &rx, const std::vector<Fr> &ry, Fr out[3]) const;
     bool is_sat(const std::vector<Fr> &vars_padded, const std::vector<Fr> &inputs) const;

@@ -8,7 +8,7 @@
 namespace otti {
 
 // ================================================================================================ instance (lib.rs Instance::new)
-static void build_csr(Csr &out, const std::vector<uint32_t> &major, const std::vector<uint32_t> &minor, const std::vector<Fr> &val, size_t rows) {
+void build_csr(Csr &out, const std::vector<uint32_t> &major, const std::vector<uint32_t> &minor, const std::vector<Fr> &val, size_t rows) {
     out.rows = rows; out.ptr.assign(rows + 1, 0);
     for (uint32_t r : major) out.ptr[r + 1]++;
     for (size_t i = 0; i < rows; i++) out.ptr[i + 1] += out.ptr[i];
