@@ -196,7 +196,7 @@ def main():
         traffic = None
         try:   # HBM traffic of the dominant kernel's largest launch, from a separate rocprofv3 --pmc pass (profiles/, see its note)
             pm = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
-            kname = {"msm_rows": "k_msm_rows", "sc_cubic": "k_sc_cubic_fold_eval", "sc_quad": "k_sc_quad_fold_eval", "spmv": "k_spmv3_light"}.get(dom)
+            kname = {"msm_rows": "k_msm_rows<false>", "sc_cubic": "k_sc_cubic_fold_eval", "sc_quad": "k_sc_quad_fold_eval", "spmv": "k_spmv3_light"}.get(dom)
             if kname and lg == 20 and int(os.environ.get("OTTI_MSM_WINDOW", "12")) == 12:
                 traffic = pm["kernels"][kname]["traffic_bytes_corrected"]
         except Exception:

@@ -258,9 +258,9 @@ int32_t otti_k_eval_table_sparse(otti_instance *inst, const uint8_t *eq_rx, cons
 }
 int32_t otti_k_eq_evals(const uint8_t *r, size_t ell, uint8_t *out, float *ms) {
     return guarded([&] {
-        if (ell > 24) throw Error(OTTI_ERR_BAD_ARG, "ell > 24");
+        if (ell > 25) throw Error(OTTI_ERR_BAD_ARG, "ell > 25");
         DevCtx &c = DevCtx::get(); std::vector<Fr> rr(ell + 1); for (size_t i = 0; i < ell; i++) rr[i] = fr_load(r + 32 * i);
-        size_t n = (size_t)1 << ell; DevBuf<Fr> o(n), s(3 * 4096);
+        size_t n = (size_t)1 << ell; DevBuf<Fr> o(n), s(5 * 4096);
         KTimer t(c, ms); dev_eq_evals(c, rr.data(), ell, o.p, s.p); t.stop();
         download(c, out, o.p, n); c.sync(); return OTTI_OK;
     });

@@ -340,8 +340,8 @@ void dev_eq_evals(DevCtx &c, const Fr *r, size_t ell, Fr *out, Fr *scratch) {
     KScope ks(c, KC_EQ);
     if (ell <= 12) { small(r, (int)ell, out, scratch); return; }
     int lo_bits = 12, hi_bits = (int)ell - 12;
-    if (hi_bits > 12) throw Error(OTTI_ERR_BAD_ARG, "eq table larger than 2^24");
-    Fr *lo = scratch, *hi = scratch + 4096, *tmp = scratch + 8192;       // scratch >= 3 * 4096
+    if (hi_bits > 13) throw Error(OTTI_ERR_BAD_ARG, "eq table larger than 2^25");
+    Fr *lo = scratch, *hi = scratch + 4096, *tmp = hi + (hi_bits > 12 ? 8192 : 4096);   // scratch >= 3 * 4096 (5 * 4096 for ell = 25)
     small(r + hi_bits, lo_bits, lo, tmp);
     small(r, hi_bits, hi, tmp);                                          // same stream: ordered after the first use of tmp
     size_t n = (size_t)1 << ell;
@@ -567,7 +567,10 @@ struct MsmArgs {
 __device__ __forceinline__ Fr bullet_fold_a(const BulletArgs &U, size_t x) { return U.fold ? fr_add(fr_mul(U.a_in[x], U.u), fr_mul(U.uinv, U.a_in[U.n + x])) : U.a_in[x]; }
 __device__ __forceinline__ Fr bullet_fold_b(const BulletArgs &U, size_t x) { return U.fold ? fr_add(fr_mul(U.b_in[x], U.uinv), fr_mul(U.u, U.b_in[U.n + x])) : U.b_in[x]; }
 __device__ __forceinline__ Fr bullet_fold_s(const BulletArgs &U, size_t j) { return U.fold ? fr_mul(U.s_in[j], ((j & (2 * (size_t)U.n - 1)) < U.n) ? U.uinv : U.u) : U.s_in[j]; }
-__global__ __launch_bounds__(kBlock) void k_msm_rows(MsmArgs A) {
+// kSmall = false: the bulk launches (a commitment: many rows, every workgroup a full chunk) — no bullet bookkeeping, no fused finish.
+// kSmall = true: the one/two-row launches of the evaluation proof, latency-bound, with both.  Two instantiations also keep the two
+// apart in profiles (k_msm_rows<false> is the kernel bench.py's roofline object is about).
+template <bool kSmall> __global__ __launch_bounds__(kBlock) void k_msm_rows(MsmArgs A) {
     // the recoded scalars (phases 1-2) and the reduction tree (phase 3) never live at the same time: one LDS region for both
     constexpr size_t kRawBytes = (kMsmMaxChunk + 8) * 9 * sizeof(uint32_t), kTreeBytes = (kBlock / 2) * sizeof(P10);
     __shared__ __attribute__((aligned(16))) unsigned char s_mem[kRawBytes > kTreeBytes ? kRawBytes : kTreeBytes];
@@ -580,7 +583,8 @@ __global__ __launch_bounds__(kBlock) void k_msm_rows(MsmArgs A) {
     const uint32_t n_ex = chunk_id == 0 ? (uint32_t)A.n_extra : 0u;
     // ---- phase 1: recoded scalars into LDS
     __shared__ Fr s_dot;                                       // bullet mode: c_L / c_R of this row (chunk 0 only)
-    if (A.bul.on) {
+    const bool bullet = kSmall && A.bul.on;
+    if (bullet) {
         const BulletArgs &U = A.bul; const size_t n = U.n, h = n / 2;
         if (row == 0) {                                        // persist the folded state for the next round (each element written once)
             const size_t cx = (n + gridDim.x - 1) / gridDim.x, x0 = (size_t)chunk_id * cx;
@@ -598,8 +602,8 @@ __global__ __launch_bounds__(kBlock) void k_msm_rows(MsmArgs A) {
     }
     for (uint32_t t = threadIdx.x; t < n_here + n_ex; t += blockDim.x) {
         Fr sc;
-        if (t >= n_here) sc = (A.bul.on && t == n_here) ? s_dot : A.extra_s[row * A.n_extra + (t - n_here)];
-        else if (A.bul.on) {
+        if (t >= n_here) sc = (bullet && t == n_here) ? s_dot : A.extra_s[row * A.n_extra + (t - n_here)];
+        else if (bullet) {
             const BulletArgs &U = A.bul; const size_t j = j0 + t, n = U.n, h = n / 2, i = j & (n - 1);
             // L = <a_L, G_R>: generator slots of the upper half, paired with a[i - h];  R = <a_R, G_L>: lower half with a[i + h]
             if (row == 0) sc = i >= h ? fr_mul(bullet_fold_a(U, i - h), bullet_fold_s(U, j)) : fr_zero();
@@ -641,7 +645,7 @@ __global__ __launch_bounds__(kBlock) void k_msm_rows(MsmArgs A) {
         if ((int)threadIdx.x < sft) acc = p10_add(acc, sm[threadIdx.x], d2);
         __syncthreads();
     }
-    if (!A.fuse) { if (threadIdx.x == 0) A.partial[row * A.nchunks + chunk_id] = p10_pack(acc); return; }
+    if (!kSmall || !A.fuse) { if (threadIdx.x == 0) A.partial[row * A.nchunks + chunk_id] = p10_pack(acc); return; }
     if (threadIdx.x == 0) { Pt pk = p10_pack(acc); store_words_sc1(&A.partial[row * A.nchunks + chunk_id], pk.X.v, 32); }
     if (!arrive_and_check_last(A.counter, gridDim.x * gridDim.y)) return;
     {   // 128 threads per row: one partial each, 7-level tree
@@ -724,7 +728,12 @@ static unsigned long long msm_launch(DevCtx &c, const DeviceGens &g, const Fr *d
     if (bul) A.bul = *bul; else { memset(&A.bul, 0, sizeof A.bul); }
     A.rows = (uint32_t)rows; A.counter = c.d_counter2.p; A.host_pts = c.d_pts_alias; A.host_flag = c.d_flag_alias; A.seq = A.fuse ? ++c.seq : 0;
     dim3 grid((unsigned)nchunks, (unsigned)rows);
-    { KScope ks(c, rows * n_dense >= ((size_t)1 << 16) ? KC_MSM_ROWS : KC_MSM_SMALL); hipLaunchKernelGGL(k_msm_rows, grid, kBlock, 0, c.stream, A); }
+    const bool bulk = rows * n_dense >= ((size_t)1 << 16) && !A.fuse && !bul;
+    {
+        KScope ks(c, bulk ? KC_MSM_ROWS : KC_MSM_SMALL);
+        if (bulk) hipLaunchKernelGGL(k_msm_rows<false>, grid, kBlock, 0, c.stream, A);
+        else hipLaunchKernelGGL(k_msm_rows<true>, grid, kBlock, 0, c.stream, A);
+    }
     if (A.fuse) { c.pending_host_encode = rows; return A.seq; }
     // rows with a single chunk need no finish pass: their partial IS the row sum
     const Pt *finals = c.msm_partial.p;

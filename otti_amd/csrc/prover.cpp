@@ -33,7 +33,7 @@ void instance_evaluate_gpu(Instance &I, const std::vector<Fr> &rx, const std::ve
     if (!I.dev) I.dev = upload_instance(I);
     const size_t N = I.num_cons, V2 = 2 * I.num_vars;
     if (((size_t)1 << rx.size()) != N || ((size_t)1 << ry.size()) != V2) throw Error(OTTI_ERR_VERIFY_INTERNAL, "challenge vector lengths do not match the instance");
-    DevBuf<Fr> ex(N), ey(V2), Mz[3] = {DevBuf<Fr>(N), DevBuf<Fr>(N), DevBuf<Fr>(N)}, scratch(3 * 4096);
+    DevBuf<Fr> ex(N), ey(V2), Mz[3] = {DevBuf<Fr>(N), DevBuf<Fr>(N), DevBuf<Fr>(N)}, scratch(5 * 4096);
     dev_eq_evals(c, rx.data(), rx.size(), ex.p, scratch.p);
     dev_eq_evals(c, ry.data(), ry.size(), ey.p, scratch.p);
     dev_spmv3(c, I.dev->by_row, ey.p, Mz[0].p, Mz[1].p, Mz[2].p, false, nullptr);

@@ -1,0 +1,45 @@
+"""Turn the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; counter_collection.csv each) into profiles/<round>_pmc_traffic.json:
+per kernel, the launch with the largest FETCH_SIZE + WRITE_SIZE, and its HBM traffic in bytes.
+Counter unit: KiB.  gfx950 correction (MI355X guide, HBM / rocprofv3 section): FETCH_SIZE reports half of the bytes of wide coalesced
+reads, so it is doubled; WRITE_SIZE is taken as is.
+usage: pmc_summary.py <fetch.csv> <write.csv> <out.json>"""
+import csv
+import json
+import sys
+
+KERNELS = ("k_msm_rows<false>", "k_msm_rows<true>", "k_sc_cubic_fold_eval", "k_sc_quad_fold_eval", "k_sc_cubic_eval", "k_sc_quad_eval", "k_spmv3_light", "k_eq_expand",
+           "k_poly_bound_slab", "k_gather_strided")
+
+
+def load(path, counter):
+    rows = {}
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        rows[int(r["Dispatch_Id"])] = (r["Kernel_Name"], float(r["Counter_Value"]))
+    return rows
+
+
+def main():
+    fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
+    out = {}
+    for k in KERNELS:
+        best = None
+        for d, (name, f) in fetch.items():
+            if (k + "(") not in name:
+                continue
+            w = write.get(d, (name, 0.0))
+            w = w[1] if ((k + "(") in w[0]) else 0.0          # the two passes dispatch the same sequence
+            if best is None or f + w > best[0] + best[1]:
+                best = (f, w)
+        if best:
+            out[k] = {"largest_launch_FETCH_SIZE_KiB": best[0], "largest_launch_WRITE_SIZE_KiB": best[1],
+                      "traffic_bytes_corrected": int((2 * best[0] + best[1]) * 1024)}
+    json.dump({"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python3 bench.py --steps 1 --warmup 1 "
+                       "--no-cpu-baseline` (2^20, c=12). Unit of the counters: KiB. gfx950 correction (MI355X guide): FETCH_SIZE reports half of the "
+                       "bytes of wide coalesced 16-B-per-lane reads, so it is doubled; for the scattered 16-B loads of the window-table gathers that "
+                       "factor is not calibrated and the corrected figure is an upper estimate.", "kernels": out}, open(sys.argv[3], "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
