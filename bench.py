@@ -92,7 +92,10 @@ def main():
         name = [("otti-bench-%d-%d" % (os.getpid(), time.time_ns())) if rank == 0 else None]
         dist.broadcast_object_list(name, src=0)
         oa.shard_init(name[0], rank, world)
+    t0 = time.perf_counter()
     inst.prepare_device(gens)                              # CSR upload + generator window table: resident before timing
+    t_prepare = time.perf_counter() - t0
+    cbits, table_bytes = gens.table_info
     t0 = time.perf_counter()
     wit = oa.Witness(inst, vars_, inputs)                  # witness resident in HBM before timing
     t_upload = time.perf_counter() - t0
@@ -197,7 +200,7 @@ def main():
         try:   # HBM traffic of the dominant kernel's largest launch, from a separate rocprofv3 --pmc pass (profiles/, see its note)
             pm = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
             kname = {"msm_rows": "k_msm_rows<false>", "sc_cubic": "k_sc_cubic_fold_eval", "sc_quad": "k_sc_quad_fold_eval", "spmv": "k_spmv3_light"}.get(dom)
-            if kname and lg == 20 and int(os.environ.get("OTTI_MSM_WINDOW", "12")) == 12:
+            if kname and lg == pm.get("log2_constraints", 20) and cbits == pm.get("msm_window_bits", 12):
                 traffic = pm["kernels"][kname]["traffic_bytes_corrected"]
         except Exception:
             traffic = None
@@ -205,7 +208,6 @@ def main():
                     "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic, "launches": cnt, "avg_launch_ms": round(avg_ms, 4),
                     "algorithmic_bytes_per_launch": int(bytes_per_launch)}
         if dom == "msm_rows":
-            cbits = int(os.environ.get("OTTI_MSM_WINDOW", "12"))
             W = 253 // cbits + 1
             adds = V * W // (world if shard else 1)        # one mixed addition (7 multiplications in GF(2^255-19)) per scalar and window
             rate = adds / (avg_ms * 1e-3)
@@ -242,13 +244,13 @@ def main():
                                 if args.dist == "uniform" else
                                 f"synthetic compiler-like R1CS, 2^{lg} constraints = variables, 10 inputs, 1..8 nnz/row/matrix, 90% of the witness < 2^64, heavy constant column ")
                                + "(SURVEY 8d); one NIZK::prove per step, witness/instance/generators resident in HBM",
-                   "parallelism": ("1 proof sharded over %d GPUs" % world if shard else "1 proof per GPU") if world > 1 else "single GPU", "msm_window_bits": int(os.environ.get("OTTI_MSM_WINDOW", "12"))},
+                   "parallelism": ("1 proof sharded over %d GPUs" % world if shard else "1 proof per GPU") if world > 1 else "single GPU", "msm_window_bits": cbits, "msm_table_GB": round(table_bytes / 1e9, 2)},
         "roofline": roofline,
         "cpu_baseline": cpu_baseline,
         "stage_ms": {k: round(v / steps, 3) for k, v in stage_acc.items()},
         "kernel_ms_per_step": {k: round(v[1], 3) for k, v in breakdown.items() if v[0]},
         "whole_proof_algorithmic_GBps": round(proof_gbps, 2), "whole_proof_hbm_frac": round(proof_gbps / (HBM_PEAK_GBPS * (world if shard else 1)), 6),
-        "witness_upload_ms": round(1e3 * t_upload, 2), "verify_ms": round(1e3 * t_verify, 2), "proof_bytes": len(proofs[-1].bytes), "proof_sha256": next(iter(digests)),
+        "prepare_device_ms": round(1e3 * t_prepare, 1), "witness_upload_ms": round(1e3 * t_upload, 2), "verify_ms": round(1e3 * t_verify, 2), "proof_bytes": len(proofs[-1].bytes), "proof_sha256": next(iter(digests)),
         "oracle_parity_2^12": parity_ok,
     }
     print(json.dumps(out))

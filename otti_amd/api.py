@@ -69,6 +69,7 @@ _sig("otti_instance_is_sat", _i32, _vp, _vp, _sz, _vp, _sz, ctypes.POINTER(_i32)
 _sig("otti_gens_new", _i32, _u64, _u64, _u64, ctypes.POINTER(_vp))
 _sig("otti_gens_free", None, _vp)
 _sig("otti_gens_points", _i32, _vp, _vp, _sz)
+_sig("otti_gens_table_info", _i32, _vp, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(_u64))
 _sig("otti_nizk_prove", _i32, _vp, _vp, _sz, _vp, _sz, _vp, ctypes.c_char_p, _sz, _vp, ctypes.c_uint32,
      ctypes.POINTER(_vp), ctypes.POINTER(_sz), ctypes.POINTER(ctypes.c_double))
 _sig("otti_witness_upload", _i32, _vp, _vp, _sz, _vp, _sz, ctypes.POINTER(_vp))
@@ -229,6 +230,13 @@ class NIZKGens:
         h = _vp()
         _check(lib.otti_gens_new(num_cons, num_vars, num_inputs, ctypes.byref(h)))
         return cls(h)
+
+    @property
+    def table_info(self):
+        """(window bits, bytes) of the device-side fixed-base table; (0, 0) before it has been built"""
+        c, b = ctypes.c_uint32(), _u64()
+        _check(lib.otti_gens_table_info(self._h, ctypes.byref(c), ctypes.byref(b)))
+        return c.value, b.value
 
     def points(self, count):
         out = np.zeros((count, 32), dtype=np.uint8)

@@ -76,6 +76,15 @@ int32_t otti_gens_new(uint64_t nc, uint64_t nv, uint64_t ni, otti_gens **out) {
     });
 }
 void otti_gens_free(otti_gens *p) { delete p; }
+int32_t otti_gens_table_info(const otti_gens *gens, uint32_t *window_bits, uint64_t *table_bytes) {
+    return guarded([&] {
+        if (!gens) throw Error(OTTI_ERR_BAD_ARG, "null argument");
+        const DeviceGens *d = gens->g->dev.get();
+        if (window_bits) *window_bits = d ? (uint32_t)d->c : 0;
+        if (table_bytes) *table_bytes = d ? (uint64_t)d->table.n * sizeof(Niels) : 0;
+        return OTTI_OK;
+    });
+}
 int32_t otti_gens_points(const otti_gens *gens, uint8_t *out32, size_t count) {
     return guarded([&] {
         if (!gens || count > gens->g->P.size()) throw Error(OTTI_ERR_BAD_ARG, "count exceeds the generator stream");
@@ -88,6 +97,7 @@ int32_t otti_prepare_device(otti_instance *inst, otti_gens *gens) {
     return guarded([&] {
         if (inst && !inst->I->dev) inst->I->dev = upload_instance(*inst->I);
         if (inst && gens) ensure_device_objects(*inst->I, *gens->g);
+        else if (gens && !gens->g->dev) gens->g->dev = build_device_gens(*gens->g, device_window_bits(gens->g->R + 2));
         return OTTI_OK;
     });
 }
@@ -315,7 +325,7 @@ int32_t otti_k_msm_rows(otti_gens *gens, const uint8_t *Z, size_t L, size_t R, c
     return guarded([&] {
         DevCtx &c = DevCtx::get(); Gens &g = *gens->g;
         if (R != g.R) throw Error(OTTI_ERR_BAD_ARG, "row length differs from the generator count");
-        if (!g.dev) g.dev = build_device_gens(g, getenv("OTTI_MSM_WINDOW") ? atoi(getenv("OTTI_MSM_WINDOW")) : 12);
+        if (!g.dev) g.dev = build_device_gens(g, device_window_bits(g.R + 2));
         Staged z(c, Z, L * R), bl(c, blinds, L);
         uint32_t hb = g.pc_n.h;
         KTimer t(c, ms); dev_msm_rows(c, *g.dev, z.d.p, R, R, L, bl.d.p, &hb, 1); t.stop();

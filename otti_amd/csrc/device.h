@@ -97,6 +97,7 @@ struct DeviceWitness {
     DeviceWitness(const Instance &I, const std::vector<Fr> &vars_padded, const std::vector<Fr> &inputs);
 };
 void ensure_device_objects(Instance &I, Gens &g);
+int device_window_bits(size_t nbases);                   // window width of the fixed-base table (prover.cpp)
 // R1CSInstance::evaluate on the device: (A,B,C)(rx,ry) = <eq(rx), M * eq(ry)> for M in {A,B,C}  (verifier's O(nnz + N + V) work)
 void instance_evaluate_gpu(Instance &I, const std::vector<Fr> &rx, const std::vector<Fr> &ry, Fr out[3]);
 // sh == nullptr (or a world of one): the whole proof on this GPU.  Otherwise this process proves its shard of the SAME proof as the

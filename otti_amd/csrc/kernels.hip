@@ -782,42 +782,54 @@ void DevCtx::encode_pending() {
     pending_host_encode = 0;
 }
 
-// table build: one thread per (base, window); extended points first, then a per-thread batch inversion to affine Niels
-__global__ __launch_bounds__(kBlock) void k_table_ext(const Pt *bases, size_t nb, int c, int W, size_t E, Pt *tmp) {
+// table build.  Row (base b, window w) holds d * B for d = 1..E with B = 2^(cw) * P[b].  Rows are cut into blocks of T entries:
+// k_table_starts (one thread per row) walks the block starts (kT+1) * B; k_table_fill (one thread per block) fills its T extended
+// points by repeated addition of B, then turns them into affine Niels form with one batch inversion over the block.
+__global__ __launch_bounds__(kBlock) void k_table_starts(const Pt *bases, size_t nb, int c, int W, size_t nblk, int lgT, Pt *starts) {
     size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (t >= nb * W) return;
     size_t b = t / W; int w = (int)(t % W);
     Pt B = bases[b];
     for (int k = 0; k < c * w; k++) B = pt_dbl(B);
-    Pt acc = B; Pt *row = tmp + t * E;
+    Pt TB = B;
+    for (int k = 0; k < lgT; k++) TB = pt_dbl(TB);
+    Pt acc = B; Pt *row = starts + t * nblk;
     row[0] = acc;
-    for (size_t d = 1; d < E; d++) { acc = pt_add(acc, B); row[d] = acc; }
+    for (size_t k = 1; k < nblk; k++) { acc = pt_add(acc, TB); row[k] = acc; }
 }
-__global__ __launch_bounds__(kBlock) void k_table_affine(Pt *tmp, size_t nrows, size_t E, Niels *out) {
+__global__ __launch_bounds__(kBlock) void k_table_fill(const Pt *starts, size_t nrows, size_t nblk, size_t T, Pt *tmp, Niels *out) {
     size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (t >= nrows) return;
-    Pt *row = tmp + t * E; Niels *orow = out + t * E;
+    if (t >= nrows * nblk) return;
+    const size_t r = t / nblk;
+    const Pt B = starts[r * nblk];
+    Pt acc = starts[t];
+    Pt *blk = tmp + t * T; Niels *oblk = out + t * T;                                      // row r, block k: entries r*E + k*T ..
     Fp prod = fp_one();
-    for (size_t d = 0; d < E; d++) { row[d].T = prod; prod = fp_mul(prod, row[d].Z); }     // T is not needed for the affine form
+    for (size_t d = 0; d < T; d++) {
+        if (d) acc = pt_add(acc, B);
+        Pt p = acc; p.T = prod;                                                             // T is not needed for the affine form: park the prefix product there
+        blk[d] = p; prod = fp_mul(prod, acc.Z);
+    }
     Fp inv = fp_inv(prod);
-    for (size_t d = E; d-- > 0;) { Pt p = row[d]; Fp zinv = fp_mul(inv, p.T); inv = fp_mul(inv, p.Z); orow[d] = pt_to_niels(p, zinv); }
+    for (size_t d = T; d-- > 0;) { Pt p = blk[d]; Fp zinv = fp_mul(inv, p.T); inv = fp_mul(inv, p.Z); oblk[d] = pt_to_niels(p, zinv); }
 }
 std::shared_ptr<DeviceGens> build_device_gens(const Gens &g, int c) {
     DevCtx &ctx = DevCtx::get();
     auto d = std::make_shared<DeviceGens>();
     d->c = c; d->W = 253 / c + 1; d->E = (size_t)1 << (c - 1); d->nbases = g.P.size();
-    size_t per_base = (size_t)d->W * d->E;
+    const size_t per_base = (size_t)d->W * d->E;
+    const int lgT = std::min(6, c - 1); const size_t T = (size_t)1 << lgT, nblk = d->E / T;
     d->table.alloc(d->nbases * per_base);
-    DevBuf<Pt> bases(d->nbases);
+    DevBuf<Pt> bases(d->nbases), starts(d->nbases * d->W * nblk);
     OTTI_HIP(hipMemcpy(bases.p, g.P.data(), d->nbases * sizeof(Pt), hipMemcpyHostToDevice));
-    size_t chunk = std::max<size_t>(1, ((size_t)1 << 30) / (per_base * sizeof(Pt)));            // <= 1 GiB of extended temporaries
+    { size_t n = d->nbases * d->W; hipLaunchKernelGGL(k_table_starts, (unsigned)((n + kBlock - 1) / kBlock), kBlock, 0, ctx.stream, (const Pt *)bases.p, d->nbases, c, d->W, nblk, lgT, starts.p); }
+    size_t chunk = std::max<size_t>(1, ((size_t)4 << 30) / (per_base * sizeof(Pt)));            // <= 4 GiB of extended temporaries
     chunk = std::min(chunk, d->nbases);
     DevBuf<Pt> tmp(chunk * per_base);
     for (size_t b0 = 0; b0 < d->nbases; b0 += chunk) {
-        size_t nb = std::min(chunk, d->nbases - b0), nthreads = nb * d->W;
-        unsigned grid = (unsigned)((nthreads + kBlock - 1) / kBlock);
-        hipLaunchKernelGGL(k_table_ext, grid, kBlock, 0, ctx.stream, (const Pt *)(bases.p + b0), nb, c, d->W, d->E, tmp.p);
-        hipLaunchKernelGGL(k_table_affine, grid, kBlock, 0, ctx.stream, tmp.p, nthreads, d->E, d->table.p + b0 * per_base);
+        size_t nb = std::min(chunk, d->nbases - b0), nrows = nb * d->W, nthreads = nrows * nblk;
+        hipLaunchKernelGGL(k_table_fill, (unsigned)((nthreads + kBlock - 1) / kBlock), kBlock, 0, ctx.stream, (const Pt *)(starts.p + b0 * d->W * nblk), nrows, nblk, T,
+                           tmp.p, d->table.p + b0 * per_base);
     }
     ctx.sync();
     return d;

@@ -2,6 +2,8 @@
 // fixed-base scalar multiplications and point compressions (5-9 us each) between two device launches; spreading them over a few
 // spinning host threads halves the per-round latency.  Workers spin only while a proof is in flight (Session), otherwise they sleep.
 #pragma once
+#include <sched.h>
+#include <stdlib.h>
 #include <atomic>
 #include <condition_variable>
 #include <functional>
@@ -59,7 +61,11 @@ private:
 #endif
     }
     SpinPool() {
+        // cores this process may use: its affinity mask, shared with the other rank processes of the node (one per GPU)
         unsigned hc = std::thread::hardware_concurrency();
+        cpu_set_t set; CPU_ZERO(&set);
+        if (sched_getaffinity(0, sizeof set, &set) == 0 && CPU_COUNT(&set) > 0) hc = (unsigned)CPU_COUNT(&set);
+        if (const char *e = getenv("LOCAL_WORLD_SIZE")) { int v = atoi(e); if (v > 1) hc = hc / (unsigned)v; }
         int n = hc >= 8 ? 3 : hc >= 4 ? 2 : hc >= 2 ? 1 : 0;
         if (const char *e = getenv("OTTI_HOST_THREADS")) { int v = atoi(e); if (v >= 1 && v <= 16) n = v - 1; }
         slots_ = std::vector<Slot>(n > 0 ? n : 1);

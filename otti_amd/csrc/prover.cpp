@@ -16,16 +16,26 @@ namespace otti {
 
 static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-static int device_window_bits() {
-    const char *e = getenv("OTTI_MSM_WINDOW");
-    int c = e ? atoi(e) : 12;
-    if (c < 4 || c > 16) c = 12;
-    return c;
+// Window width c of the fixed-base table.  Every bit of c removes additions from every MSM of every proof (W = floor(253/c)+1 per
+// scalar) and doubles the table; the table is built once per generator set and HBM is 288 GB, so take the widest window whose table
+// fits a budget (default 64 GiB: c = 16 for R = 1024, 15 for R = 2048, 14 for R = 4096).  OTTI_MSM_WINDOW pins c;
+// OTTI_MSM_TABLE_GB changes the budget (one-shot callers such as spzk pick a small table: building it costs more than it saves).
+int device_window_bits(size_t nbases) {
+    if (const char *e = getenv("OTTI_MSM_WINDOW")) { int c = atoi(e); if (c >= 4 && c <= 16) return c; }
+    double budget_gb = 64.0;
+    if (const char *e = getenv("OTTI_MSM_TABLE_GB")) { double v = atof(e); if (v > 0) budget_gb = v; }
+    int best = 8;
+    const int widest = nbases < 256 ? 12 : 16;             // tiny instances (R < 256) are launch-bound whatever the window: keep their tables small
+    for (int c = 8; c <= widest; c++) {
+        const double W = 253 / c + 1, bytes = (double)nbases * W * (double)((size_t)1 << (c - 1)) * sizeof(Niels);
+        if (bytes <= budget_gb * 1073741824.0) best = c;
+    }
+    return best;
 }
 
 void ensure_device_objects(Instance &I, Gens &g) {
     if (!I.dev) I.dev = upload_instance(I);
-    if (!g.dev) g.dev = build_device_gens(g, device_window_bits());
+    if (!g.dev) g.dev = build_device_gens(g, device_window_bits(g.R + 2));
 }
 
 void instance_evaluate_gpu(Instance &I, const std::vector<Fr> &rx, const std::vector<Fr> &ry, Fr out[3]) {

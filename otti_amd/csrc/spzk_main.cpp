@@ -37,6 +37,9 @@ int main(int argc, char **argv) {
         return 0;
     }
     if (strcmp(argv[1], "verify")) return usage();
+    // one proof per process: the generator window table is built and used once, so a narrow window (small table, ~7 ms to build for
+    // R = 1024) beats the wide one a long-lived prover process amortises (see prover.cpp device_window_bits); an explicit setting wins
+    setenv("OTTI_MSM_WINDOW", "10", 0);
     bool nizk = false; std::vector<const char *> files; const char *seed_hex = nullptr, *proof_out = nullptr, *label = "nizk_example";
     for (int i = 2; i < argc; i++) {
         if (!strcmp(argv[i], "--nizk")) nizk = true;

@@ -2,7 +2,7 @@
 per kernel, the launch with the largest FETCH_SIZE + WRITE_SIZE, and its HBM traffic in bytes.
 Counter unit: KiB.  gfx950 correction (MI355X guide, HBM / rocprofv3 section): FETCH_SIZE reports half of the bytes of wide coalesced
 reads, so it is doubled; WRITE_SIZE is taken as is.
-usage: pmc_summary.py <fetch.csv> <write.csv> <out.json>"""
+usage: pmc_summary.py <fetch.csv> <write.csv> <out.json> [msm_window_bits [log2_constraints]]"""
 import csv
 import json
 import sys
@@ -36,9 +36,11 @@ def main():
             out[k] = {"largest_launch_FETCH_SIZE_KiB": best[0], "largest_launch_WRITE_SIZE_KiB": best[1],
                       "traffic_bytes_corrected": int((2 * best[0] + best[1]) * 1024)}
     json.dump({"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python3 bench.py --steps 1 --warmup 1 "
-                       "--no-cpu-baseline` (2^20, c=12). Unit of the counters: KiB. gfx950 correction (MI355X guide): FETCH_SIZE reports half of the "
+                       "--no-cpu-baseline` (2^20; window width in msm_window_bits). Unit of the counters: KiB. gfx950 correction (MI355X guide): FETCH_SIZE reports half of the "
                        "bytes of wide coalesced 16-B-per-lane reads, so it is doubled; for the scattered 16-B loads of the window-table gathers that "
-                       "factor is not calibrated and the corrected figure is an upper estimate.", "kernels": out}, open(sys.argv[3], "w"), indent=1)
+                       "factor is not calibrated and the corrected figure is an upper estimate.",
+               "msm_window_bits": int(sys.argv[4]) if len(sys.argv) > 4 else 12, "log2_constraints": int(sys.argv[5]) if len(sys.argv) > 5 else 20,
+               "kernels": out}, open(sys.argv[3], "w"), indent=1)
 
 
 if __name__ == "__main__":
