@@ -286,6 +286,33 @@ def test_spzk_cli_end_to_end(tmp_path):
     assert res.returncode != 0 and "Verification successful" not in res.stdout
 
 
+def test_spzk_prove_and_verify_as_separate_processes(tmp_path):
+    """`spzk prove … --proof-out` and `spzk verify … --proof-in` (the verifier gets no witness file)."""
+    import os
+    import subprocess
+    spzk = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "otti_amd", "spzk")
+    pre = str(tmp_path / "syn")
+    assert subprocess.run([spzk, "synth", "1000", pre, "5", "9"], capture_output=True).returncode == 0
+    res = subprocess.run([spzk, "prove", "--nizk", pre + ".zkif", pre + ".inp.zkif", pre + ".wit.zkif", "--proof-out", pre + ".proof", "--seed", "07" * 32],
+                         capture_output=True, text=True)
+    assert res.returncode == 0 and "Proof written" in res.stdout and "Verification" not in res.stdout, res.stderr
+    res = subprocess.run([spzk, "verify", "--nizk", pre + ".zkif", pre + ".inp.zkif", "--proof-in", pre + ".proof"], capture_output=True, text=True)
+    assert res.returncode == 0 and "Verification successful" in res.stdout, res.stdout + res.stderr
+    r = oa.zkif_load(pre + ".zkif", pre + ".inp.zkif", pre + ".wit.zkif")
+    oi, og = orc.OInstance(r["num_cons"], r["num_vars"], r["num_inputs"], r["A"], r["B"], r["C"]), orc.OGens(r["num_cons"], r["num_vars"], r["num_inputs"])
+    oproof, _ = orc.nizk_prove(oi, r["vars"], r["inputs"], og, b"nizk_example", b"\x07" * 32)
+    assert open(pre + ".proof", "rb").read() == oproof
+    # a flipped proof byte, a truncated proof and a different label are all rejected by the separate verifier
+    pf = bytearray(oproof); pf[len(pf) // 2] ^= 4
+    open(pre + ".bad", "wb").write(bytes(pf))
+    assert subprocess.run([spzk, "verify", "--nizk", pre + ".zkif", pre + ".inp.zkif", "--proof-in", pre + ".bad"], capture_output=True).returncode != 0
+    open(pre + ".bad", "wb").write(oproof[:-5])
+    assert subprocess.run([spzk, "verify", "--nizk", pre + ".zkif", pre + ".inp.zkif", "--proof-in", pre + ".bad"], capture_output=True).returncode != 0
+    assert subprocess.run([spzk, "verify", "--nizk", pre + ".zkif", pre + ".inp.zkif", "--proof-in", pre + ".proof", "--label", "other"],
+                          capture_output=True).returncode != 0
+    assert subprocess.run([spzk, "prove", "--nizk", pre + ".zkif", pre + ".inp.zkif", pre + ".wit.zkif"], capture_output=True).returncode == 2   # no --proof-out
+
+
 def test_golden_proof_digests_on_gpu():
     import json
     import os
