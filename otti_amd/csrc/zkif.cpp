@@ -10,6 +10,10 @@
 #include "spartan.h"
 #include <stdio.h>
 #include <stdlib.h>
+#include <fcntl.h>
+#include <unistd.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <map>
 #include <algorithm>
 
@@ -70,24 +74,38 @@ VarList read_variables(const Table &t) {
     return v;
 }
 
-std::vector<uint8_t> read_file(const char *path) {
-    FILE *f = fopen(path, "rb");
-    if (!f) throw Error(OTTI_ERR_IO, std::string("cannot open ") + path);
-    std::vector<uint8_t> d; uint8_t tmp[1 << 16]; size_t k;
-    while ((k = fread(tmp, 1, sizeof tmp, f)) > 0) d.insert(d.end(), tmp, tmp + k);
-    fclose(f);
-    return d;
-}
+// A .zkif file as a read-only memory map: multi-GB constraint files (2^24 constraints) are paged in by the kernel as the two passes
+// walk them, never copied into the process heap.
+struct FileView {
+    const uint8_t *p = nullptr; size_t n = 0; int fd = -1;
+    explicit FileView(const char *path) {
+        fd = open(path, O_RDONLY);
+        if (fd < 0) throw Error(OTTI_ERR_IO, std::string("cannot open ") + path);
+        struct stat st;
+        if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) { close(fd); throw Error(OTTI_ERR_IO, std::string("not a regular file: ") + path); }
+        n = (size_t)st.st_size;
+        if (n) {
+            void *m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m == MAP_FAILED) { close(fd); throw Error(OTTI_ERR_IO, std::string("cannot map ") + path); }
+            p = (const uint8_t *)m;
+            madvise(m, n, MADV_SEQUENTIAL);
+        }
+    }
+    FileView(const FileView &) = delete; FileView &operator=(const FileView &) = delete;
+    ~FileView() { if (p) munmap((void *)p, n); if (fd >= 0) close(fd); }
+    const uint8_t *data() const { return p; }
+    size_t size() const { return n; }
+};
 
 struct Messages {
     bool have_header = false; VarList instance; uint64_t free_variable_id = 0; std::vector<uint8_t> field_maximum;
     VarList witness; bool have_witness = false;
 };
 // walks the size-prefixed messages of one file; fn(type, message table, buffer)
-template <class F> void for_each_message(const std::vector<uint8_t> &file, F &&fn) {
+template <class F> void for_each_message(const FileView &file, F &&fn) {
     size_t off = 0;
     while (off + 4 <= file.size()) {
-        uint32_t sz = (uint32_t)file[off] | ((uint32_t)file[off + 1] << 8) | ((uint32_t)file[off + 2] << 16) | ((uint32_t)file[off + 3] << 24);
+        const uint8_t *q = file.data() + off; uint32_t sz = (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16) | ((uint32_t)q[3] << 24);
         if (sz < 8 || sz > file.size() - off - 4) throw Error(OTTI_ERR_IO, "zkif: bad message size prefix");
         Buf b{file.data() + off + 4, sz};
         if (memcmp(b.p + 4, "zkif", 4) != 0) throw Error(OTTI_ERR_IO, "zkif: missing file identifier");
@@ -98,7 +116,7 @@ template <class F> void for_each_message(const std::vector<uint8_t> &file, F &&f
     if (off != file.size()) throw Error(OTTI_ERR_IO, "zkif: trailing bytes");
 }
 // pass 1: headers and witness only (ConstraintSystem messages are skipped by their size prefix)
-void parse_headers(const std::vector<uint8_t> &file, Messages &m) {
+void parse_headers(const FileView &file, Messages &m) {
     for_each_message(file, [&](uint8_t type, const Table &msg, const Buf &b) {
         if (type == 1) {                       // CircuitHeader
             VarList iv = read_variables(msg.sub(0));
@@ -246,10 +264,10 @@ static void append_lc(std::vector<otti_entry> &out, const Table &vars, uint64_t 
 
 otti_r1cs *zkif_load_impl(const char *circuit_path, const char *inputs_path, const char *witness_path) {
     Messages m;
-    std::vector<uint8_t> circuit = read_file(circuit_path);
+    FileView circuit(circuit_path);
     parse_headers(circuit, m);
-    if (inputs_path) parse_headers(read_file(inputs_path), m);
-    if (witness_path) parse_headers(read_file(witness_path), m);
+    if (inputs_path) { FileView f(inputs_path); parse_headers(f, m); }
+    if (witness_path) { FileView f(witness_path); parse_headers(f, m); }
     if (!m.have_header) throw Error(OTTI_ERR_IO, "zkif: no CircuitHeader message");
     if (!m.field_maximum.empty()) {
         static const uint8_t lm1[32] = {0xec, 0xd3, 0xf5, 0x5c, 0x1a, 0x63, 0x12, 0x58, 0xd6, 0x9c, 0xf7, 0xa2, 0xde, 0xf9, 0xde, 0x14,
