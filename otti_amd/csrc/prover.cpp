@@ -203,7 +203,11 @@ std::vector<uint8_t> nizk_prove_resident(Instance &I, DeviceWitness &wit, Gens &
     {
         uint32_t hbase = g.pc_n.h;
         dev_msm_rows(c, DG, nullptr, 0, 0, Ll, S.blinds.p, &hbase, 1, MSM_COMPRESSED, c.msm_keep.p);
-        c.sync();
+        // Az, Bz, Cz do not depend on the transcript: queue them behind the commitment so that they run while the host hashes it
+        OTTI_HIP(hipEventRecord(c.ev0, c.stream));
+        dev_spmv3(c, rows_set, wit.z.p, S.T[1].p, S.T[2].p, S.T[3].p, false, nullptr);
+        OTTI_HIP(hipEventSynchronize(c.ev0));
+        c.encode_pending();
         P.comm_vars.resize(Lsz);
         static_assert(sizeof(CPoint) == 32, "CPoint is 32 packed bytes");
         if (sh) sh->allgather(c.h_points, Ll * 32, P.comm_vars.data());       // rank order = row-block order
@@ -220,8 +224,7 @@ std::vector<uint8_t> nizk_prove_resident(Instance &I, DeviceWitness &wit, Gens &
     // local eq table: eq(tau, i'*G + rk) = eq(tau_hi, i') * eq(tau_lo, rk)  (index bits are MSB-first over tau)
     dev_eq_evals(c, tau.data(), nrx - lgG, S.T[0].p, S.eqs.p);
     if (sh) dev_scale(c, S.T[0].p, eq_evals_host(tau.data() + (nrx - lgG), lgG)[rk], S.T[0].p, Nl);
-    dev_spmv3(c, rows_set, wit.z.p, S.T[1].p, S.T[2].p, S.T[3].p, false, nullptr);
-    c.sync();
+    c.sync();                                                         // multiply_vec was queued during polycommit; this stage is what is left of it
     T.ms[1] = now_ms() - t0;
 
     // ---- sum-check phase one (K3 + K4): comb = eq * (Az * Bz - Cz), claim 0
