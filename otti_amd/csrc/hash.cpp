@@ -111,6 +111,11 @@ Fr RandomTape::random_scalar(const char *label) {
     }
     return t_.challenge_scalar(label);
 }
+Fr RandomTape::Cursor::random_scalar(const char *label) {
+    if (pos_ < t_.head_ || pos_ >= t_.queue_.size()) throw std::logic_error("RandomTape::Cursor: read outside the prefetched, unconsumed part of the tape");
+    if (strcmp(t_.queue_[pos_].first, label) != 0) throw std::logic_error(std::string("RandomTape::Cursor: prefetched label '") + t_.queue_[pos_].first + "' but '" + label + "' was asked for");
+    return t_.queue_[pos_++].second;
+}
 void RandomTape::prefetch(const std::vector<std::pair<const char *, size_t>> &schedule) {
     if (head_ != queue_.size()) throw std::logic_error("RandomTape: prefetch with unread values pending");
     queue_.clear(); head_ = 0;

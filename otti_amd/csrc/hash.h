@@ -54,15 +54,30 @@ private:
 
 // libspartan RandomTape: a second transcript whose challenges are the prover's blinds.  Upstream seeds it from OsRng;
 // here the caller supplies 32 bytes (NULL => OS entropy) so that a proof is a deterministic function of its inputs.
-class RandomTape {
+// anything that hands out the tape's scalars in order (the tape itself, or a read-ahead cursor over its prefetched queue)
+class ScalarSource {
+public:
+    virtual ~ScalarSource() {}
+    virtual Fr random_scalar(const char *label) = 0;
+    std::vector<Fr> random_vector(const char *label, size_t n) { std::vector<Fr> v(n); for (auto &x : v) x = random_scalar(label); return v; }
+};
+class RandomTape : public ScalarSource {
 public:
     explicit RandomTape(const uint8_t seed32[32]);
-    Fr random_scalar(const char *label);
-    std::vector<Fr> random_vector(const char *label, size_t n) { std::vector<Fr> v(n); for (auto &x : v) x = random_scalar(label); return v; }
+    Fr random_scalar(const char *label) override;
     // The tape is a transcript of its own: its outputs depend only on the seed and on the sequence of labels asked for.  The prover
     // knows that sequence in advance, so it draws everything in one go (while the device is busy with the witness commitment);
     // later random_scalar calls pop the queue and check that the label is the scheduled one.
     void prefetch(const std::vector<std::pair<const char *, size_t>> &schedule);
+    // Reads prefetched values ahead of the protocol WITHOUT consuming them (label-checked like the real draws): lets the prover start
+    // work that depends on the tape alone — e.g. the second sum-check's blinding commitments — long before the protocol gets there.
+    class Cursor : public ScalarSource {
+    public:
+        Cursor(const RandomTape &t, size_t queue_index) : t_(t), pos_(queue_index) {}
+        Fr random_scalar(const char *label) override;
+    private:
+        const RandomTape &t_; size_t pos_;
+    };
 private:
     Transcript t_;
     std::vector<std::pair<const char *, Fr>> queue_; size_t head_ = 0;

@@ -72,11 +72,16 @@ DevCtx &DevCtx::get() {
 }
 
 void DevCtx::ensure_points(size_t rows, size_t splits) {
-    if (rows * splits > msm_partial_cap) { msm_partial.alloc(rows * splits); msm_partial_cap = rows * splits; }
-    if (rows > points_cap) {
+    // Growing these buffers invalidates results of launches still in flight (h_points in particular is read by the host after an event
+    // wait), so capacities start generous and the prover sizes them for the whole proof before its first launch; a later growth
+    // drains the stream first.
+    const size_t want_partial = std::max<size_t>(rows * splits, 8192), want_rows = std::max<size_t>(rows, 2 * kHostPtsCap);
+    if (want_partial > msm_partial_cap) { if (stream) OTTI_HIP(hipStreamSynchronize(stream)); msm_partial.alloc(want_partial); msm_partial_cap = want_partial; }
+    if (want_rows > points_cap) {
+        if (stream) OTTI_HIP(hipStreamSynchronize(stream));
         if (h_points) (void)hipHostFree(h_points);
-        OTTI_HIP(hipHostMalloc((void **)&h_points, rows * 32, hipHostMallocDefault));
-        d_points.alloc(rows * 32); msm_final.alloc(rows); points_cap = rows;
+        OTTI_HIP(hipHostMalloc((void **)&h_points, want_rows * 32, hipHostMallocDefault));
+        d_points.alloc(want_rows * 32); msm_final.alloc(want_rows); points_cap = want_rows;
     }
     if (!h_pts) {
         OTTI_HIP(hipHostMalloc((void **)&h_pts, kHostPtsCap * sizeof(Pt), hipHostMallocDefault));

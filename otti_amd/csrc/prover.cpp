@@ -69,32 +69,50 @@ DeviceWitness::DeviceWitness(const Instance &I, const std::vector<Fr> &vars_padd
 }
 
 namespace {
-// Everything a sum-check's rounds need that depends on the random tape alone, as ONE batched fixed-base MSM: for each round the
-// four points delta_j = commit(d_vec_j, r_delta_j), blinds_poly[j]*h_n, blinds_evals[j]*h_1, r_beta_j*h_1 (extended, not compressed).
-void precompute_round_points(DevCtx &c, const DeviceGens &DG, const Gens &g, const GensView &gn, SumcheckState &st, size_t ne, DevBuf<Fr> &scratch) {
-    const size_t n = st.pre.size(), nb = ne + 2;                       // bases: G_0..G_{ne-1}, h_n, h_1
+// Everything the rounds of BOTH sum-checks need that depends on the random tape alone, as ONE batched fixed-base MSM: for each round
+// the four points delta_j = commit(d_vec_j, r_delta_j), blinds_poly[j]*h_n, blinds_evals[j]*h_1, r_beta_j*h_1 (extended, not
+// compressed).  Launched right behind the witness commitment (the second sum-check's tape values are read ahead with a
+// RandomTape::Cursor) and collected when the first sum-check starts.
+struct RoundPointsJob { size_t n1 = 0, n2 = 0; std::vector<Fr> scalars; };   // scalars: host source of an in-flight async copy
+RoundPointsJob precompute_round_points_launch(DevCtx &c, const DeviceGens &DG, const Gens &g, const SumcheckState &s1, const SumcheckState &s2, DevBuf<Fr> &scratch) {
+    RoundPointsJob job; job.n1 = s1.pre.size(); job.n2 = s2.pre.size();
+    const size_t n = job.n1 + job.n2;
     if (4 * n > kHostPtsCap) throw Error(OTTI_ERR_INTERNAL, "too many sum-check rounds");
-    std::vector<uint32_t> bases(nb);
-    for (size_t i = 0; i < ne; i++) bases[i] = gn.G[i];
-    bases[ne] = gn.h; bases[ne + 1] = g.sc_1.h;
+    std::vector<uint32_t> bases;                                      // the generator-stream indices either sum-check touches (6 of them)
+    auto col = [&](uint32_t idx) { for (size_t i = 0; i < bases.size(); i++) if (bases[i] == idx) return i; bases.push_back(idx); return bases.size() - 1; };
+    struct Cols { size_t G[4], h, h1; } cs[2];
+    const GensView *gv[2] = {&g.sc_4, &g.sc_3}; const size_t ne[2] = {4, 3};
+    for (int k = 0; k < 2; k++) { for (size_t i = 0; i < ne[k]; i++) cs[k].G[i] = col(gv[k]->G[i]); cs[k].h = col(gv[k]->h); cs[k].h1 = col(g.sc_1.h); }
+    const size_t nb = bases.size();
+    if (nb > 8) throw Error(OTTI_ERR_INTERNAL, "sum-check generators do not share one short base list");
     std::vector<Fr> sc(4 * n * nb, fr_zero());
-    for (size_t j = 0; j < n; j++) {
-        Fr *r0 = &sc[(4 * j + 0) * nb], *r1 = &sc[(4 * j + 1) * nb], *r2 = &sc[(4 * j + 2) * nb], *r3 = &sc[(4 * j + 3) * nb];
-        for (size_t i = 0; i < ne; i++) r0[i] = st.pre[j].d[i];
-        r0[ne] = st.pre[j].r_delta;
-        r1[ne] = st.blinds_poly[j];
-        r2[ne + 1] = st.blinds_evals[j];
-        r3[ne + 1] = st.pre[j].r_beta;
-    }
     if (scratch.n < sc.size()) scratch.alloc(sc.size());
+    const SumcheckState *st[2] = {&s1, &s2}; size_t row = 0;
+    for (int k = 0; k < 2; k++)
+        for (size_t j = 0; j < st[k]->pre.size(); j++, row += 4) {
+            Fr *r0 = &sc[(row + 0) * nb], *r1 = &sc[(row + 1) * nb], *r2 = &sc[(row + 2) * nb], *r3 = &sc[(row + 3) * nb];
+            for (size_t i = 0; i < ne[k]; i++) r0[cs[k].G[i]] = st[k]->pre[j].d[i];
+            r0[cs[k].h] = st[k]->pre[j].r_delta;
+            r1[cs[k].h] = st[k]->blinds_poly[j];
+            r2[cs[k].h1] = st[k]->blinds_evals[j];
+            r3[cs[k].h1] = st[k]->pre[j].r_beta;
+        }
     OTTI_HIP(hipMemcpyAsync(scratch.p, sc.data(), sc.size() * sizeof(Fr), hipMemcpyHostToDevice, c.stream));
     dev_msm_rows(c, DG, nullptr, 0, 0, 4 * n, scratch.p, bases.data(), nb, MSM_RAW);
-    c.sync();
-    for (size_t j = 0; j < n; j++) { st.pre[j].delta = c.h_pts[4 * j]; st.pre[j].bp_h = c.h_pts[4 * j + 1]; st.pre[j].be_h = c.h_pts[4 * j + 2]; st.pre[j].rb_h = c.h_pts[4 * j + 3]; }
+    OTTI_HIP(hipEventRecord(c.ev1, c.stream));
+    job.scalars = std::move(sc);                                      // must outlive the copy queued above
+    return job;
+}
+void precompute_round_points_collect(DevCtx &c, const RoundPointsJob &job, SumcheckState &s1, SumcheckState &s2) {
+    OTTI_HIP(hipEventSynchronize(c.ev1));
+    SumcheckState *st[2] = {&s1, &s2}; size_t row = 0;
+    for (int k = 0; k < 2; k++)
+        for (auto &p : st[k]->pre) { p.delta = c.h_pts[row]; p.bp_h = c.h_pts[row + 1]; p.be_h = c.h_pts[row + 2]; p.rb_h = c.h_pts[row + 3]; row += 4; }
     // compress the deltas now, off the per-round path, striped over the helper threads
+    std::vector<RoundPre *> all; for (int k = 0; k < 2; k++) for (auto &p : st[k]->pre) all.push_back(&p);
     SpinPool &pool = SpinPool::get(); const int nt = pool.workers() + 1;
     std::vector<std::function<void()>> tasks(nt);
-    for (int t = 0; t < nt; t++) tasks[t] = [&, t] { for (size_t j = t; j < n; j += nt) pt_encode(st.pre[j].delta_c.b, st.pre[j].delta); };
+    for (int t = 0; t < nt; t++) tasks[t] = [&, t] { for (size_t j = t; j < all.size(); j += nt) pt_encode(all[j]->delta_c.b, all[j]->delta); };
     pool.parallel(tasks.data(), nt);
 }
 // HBM working set of one proof; kept across proofs of the same shape (hipMalloc/hipFree of ~0.5 GB costs more than a sum-check)
@@ -172,11 +190,13 @@ std::vector<uint8_t> nizk_prove_resident(Instance &I, DeviceWitness &wit, Gens &
     const size_t lgR = ilog2(Rsz);
     Scratch &S = workspace();
     S.reserve(N, V, Lsz, Rsz, lgR);
+    c.ensure_points(std::max(Lsz, 4 * (nrx + nry)), 2 * std::max<size_t>(1, Rsz / 256));   // every MSM result buffer of this proof, before the first launch
     const Fr *d_vars = wit.z.p, *my_rows = d_vars + rk * Ll * Rsz;         // this rank's block of witness-matrix rows
 
     Transcript tr(tlabel, tlabel_len);
     RandomTape tape(seed32);
     NizkProof P;
+    SumcheckState early1, early2; RoundPointsJob round_points;       // tape-only parts of both sum-checks, started during polycommit
     tr.append_protocol_name("Spartan NIZK proof");
     tr.append_protocol_name("R1CS proof");
 
@@ -184,16 +204,18 @@ std::vector<uint8_t> nizk_prove_resident(Instance &I, DeviceWitness &wit, Gens &
     // meanwhile the host draws the whole random tape (its label sequence is known in advance); the blind terms are added last.
     t0 = now_ms();
     dev_msm_rows(c, DG, my_rows, Rsz, Rsz, Ll, nullptr, nullptr, 0, MSM_KEEP, nullptr, wit.small_fraction > kSparseWitness);
+    size_t off_sc1 = 0, off_sc2 = 0;                                  // where the two sum-checks' draws sit in the prefetched tape
     {
         std::vector<std::pair<const char *, size_t>> sched;
         auto sumcheck_sched = [&](size_t rounds, size_t ne) {
             sched.push_back({"blinds_poly", rounds}); sched.push_back({"blinds_evals", rounds});
             for (size_t j = 0; j < rounds; j++) { sched.push_back({"d_vec", ne}); sched.push_back({"r_delta", 1}); sched.push_back({"r_beta", 1}); }
         };
+        auto drawn = [&] { size_t n = 0; for (auto &e : sched) n += e.second; return n; };
         sched.push_back({"poly_blinds", Lsz});
-        sumcheck_sched(nrx, 4);
+        off_sc1 = drawn(); sumcheck_sched(nrx, 4);
         for (const char *l : {"Az_blind", "Bz_blind", "Cz_blind", "prod_Az_Bz_blind", "t1", "t2", "b1", "b2", "b3", "b4", "b5", "r"}) sched.push_back({l, 1});
-        sumcheck_sched(nry, 3);
+        off_sc2 = drawn(); sumcheck_sched(nry, 3);
         sched.push_back({"blind_eval", 1}); sched.push_back({"d", 1}); sched.push_back({"r_delta", 2});
         sched.push_back({"blinds_vec_1", 2 * lgR}); sched.push_back({"blinds_vec_2", 2 * lgR}); sched.push_back({"r", 1});
         tape.prefetch(sched);
@@ -206,6 +228,9 @@ std::vector<uint8_t> nizk_prove_resident(Instance &I, DeviceWitness &wit, Gens &
         // Az, Bz, Cz do not depend on the transcript: queue them behind the commitment so that they run while the host hashes it
         OTTI_HIP(hipEventRecord(c.ev0, c.stream));
         dev_spmv3(c, rows_set, wit.z.p, S.T[1].p, S.T[2].p, S.T[3].p, false, nullptr);
+        // ... and so do the blinding commitments of every sum-check round (tape-only): one batched launch for both sum-checks
+        { RandomTape::Cursor c1(tape, off_sc1), c2(tape, off_sc2); sumcheck_draw_tape(early1, c1, nrx, 4); sumcheck_draw_tape(early2, c2, nry, 3); }
+        round_points = precompute_round_points_launch(c, DG, g, early1, early2, S.pre);
         OTTI_HIP(hipEventSynchronize(c.ev0));
         c.encode_pending();
         P.comm_vars.resize(Lsz);
@@ -234,7 +259,8 @@ std::vector<uint8_t> nizk_prove_resident(Instance &I, DeviceWitness &wit, Gens &
     {
         SumcheckState st;
         sumcheck_draw_tape(st, tape, nrx, 4);
-        precompute_round_points(c, DG, g, g.sc_4, st, 4, S.pre);
+        precompute_round_points_collect(c, round_points, early1, early2);
+        st.pre = std::move(early1.pre);
         st.claim = fr_zero(); st.blind_claim = fr_zero();
         { Term t2[2] = {{g.sc_1.G[0], fr_zero()}, {g.sc_1.h, fr_zero()}}; g.commit_terms_c(st.comm_claim.b, t2, 2); }
         P.sc1.comm_polys.resize(nrx); P.sc1.comm_evals.resize(nrx); P.sc1.proofs.resize(nrx);
@@ -276,7 +302,13 @@ std::vector<uint8_t> nizk_prove_resident(Instance &I, DeviceWitness &wit, Gens &
         blind_claim_postsc1 = st.blinds_evals[nrx - 1];
         if (sh) for (int k = 0; k < 4; k++) c.h_results[8 + k] = tail1[k][0];
     }
-    if (!sh) { for (int k = 0; k < 4; k++) dev_fetch(c, S.T[k].p, 8 + k, 1); c.sync(); }
+    if (!sh) { for (int k = 0; k < 4; k++) dev_fetch(c, S.T[k].p, 8 + k, 1); OTTI_HIP(hipEventRecord(c.ev0, c.stream)); }
+    // what phase two needs from rx alone — eq(rx, .) (the full table on every rank: a column needs every row) and the working copy of
+    // z — is queued now, so the device builds it while the host runs the sigma protocols between the phases
+    dev_eq_evals(c, P.rx.data(), nrx, S.T[0].p, S.eqs.p);
+    if (sh) dev_gather_strided(c, wit.z.p, G, rk, S.zw.p, V2l);
+    else OTTI_HIP(hipMemcpyAsync(S.zw.p, wit.z.p, 2 * V * sizeof(Fr), hipMemcpyDeviceToDevice, c.stream));
+    if (!sh) OTTI_HIP(hipEventSynchronize(c.ev0));
     const Fr tau_claim = c.h_results[8], Az_claim = c.h_results[9], Bz_claim = c.h_results[10], Cz_claim = c.h_results[11];
     T.ms[2] = now_ms() - t0;
 
@@ -300,11 +332,8 @@ std::vector<uint8_t> nizk_prove_resident(Instance &I, DeviceWitness &wit, Gens &
     Fr blind_claim2 = fr_add(fr_add(fr_mul(rA, Az_blind), fr_mul(rB, Bz_blind)), fr_mul(rC, Cz_blind));
     t0 = now_ms();
     {
-        dev_eq_evals(c, P.rx.data(), nrx, S.T[0].p, S.eqs.p);                // the full table on every rank: its columns need every row
         Fr coef[3] = {rA, rB, rC};
         dev_spmv3(c, cols_set, S.T[0].p, S.ABC.p, nullptr, nullptr, true, coef);
-        if (sh) dev_gather_strided(c, wit.z.p, G, rk, S.zw.p, V2l);
-        else OTTI_HIP(hipMemcpyAsync(S.zw.p, wit.z.p, 2 * V * sizeof(Fr), hipMemcpyDeviceToDevice, c.stream));
         c.sync();
     }
     T.ms[3] = now_ms() - t0;
@@ -316,7 +345,7 @@ std::vector<uint8_t> nizk_prove_resident(Instance &I, DeviceWitness &wit, Gens &
     {
         SumcheckState st;
         sumcheck_draw_tape(st, tape, nry, 3);
-        precompute_round_points(c, DG, g, g.sc_3, st, 3, S.pre);
+        st.pre = std::move(early2.pre);
         st.claim = claim2; st.blind_claim = blind_claim2;
         { Term t2[2] = {{g.sc_1.G[0], claim2}, {g.sc_1.h, blind_claim2}}; g.commit_terms_c(st.comm_claim.b, t2, 2); }
         P.sc2.comm_polys.resize(nry); P.sc2.comm_evals.resize(nry); P.sc2.proofs.resize(nry);

@@ -114,7 +114,7 @@ struct RoundPre {
 struct SumcheckState { Fr claim; CPoint comm_claim; Fr blind_claim; std::vector<Fr> blinds_poly, blinds_evals; std::vector<RoundPre> pre; };
 struct RoundPart1 { Fr poly[4]; size_t ne; Fr r_j; };
 // draws blinds_poly, blinds_evals and every round's (d_vec, r_delta, r_beta) from the tape in upstream's order
-void sumcheck_draw_tape(SumcheckState &st, RandomTape &tape, size_t num_rounds, size_t ne);
+void sumcheck_draw_tape(SumcheckState &st, ScalarSource &tape, size_t num_rounds, size_t ne);
 RoundPart1 sumcheck_round_begin(ZKSumcheckProof &pf, size_t j, const Fr *evals, size_t ne, const SumcheckState &st, const Gens &g,
                                 const GensView &gn, Transcript &tr);
 void sumcheck_round_finish(ZKSumcheckProof &pf, size_t j, const RoundPart1 &p1, SumcheckState &st, const Gens &g, const GensView &gn,

@@ -213,7 +213,7 @@ ProductProof product_prove(CPoint &X, CPoint &Y, CPoint &Z, const Gens &g, Trans
 // sumcheck.rs + nizk/mod.rs DotProductProof::prove.  NOTE on tape order: upstream draws blinds_poly and blinds_evals when the
 // sum-check starts and (d_vec, r_delta, r_beta) inside each round's DotProductProof::prove; nothing else touches the tape in
 // between, so drawing all rounds' values right after the blinds yields the same values.
-void sumcheck_draw_tape(SumcheckState &st, RandomTape &tape, size_t num_rounds, size_t ne) {
+void sumcheck_draw_tape(SumcheckState &st, ScalarSource &tape, size_t num_rounds, size_t ne) {
     st.blinds_poly = tape.random_vector("blinds_poly", num_rounds);
     st.blinds_evals = tape.random_vector("blinds_evals", num_rounds);
     st.pre.resize(num_rounds);

@@ -342,6 +342,19 @@ def test_spzk_prove_and_verify_as_separate_processes(tmp_path):
     assert subprocess.run([spzk, "prove", "--nizk", pre + ".zkif", pre + ".inp.zkif", pre + ".wit.zkif"], capture_output=True).returncode == 2   # no --proof-out
 
 
+@pytest.mark.parametrize("window", ["10", None])
+def test_fresh_process_growing_instances(window):
+    """Regression: a result buffer of the device context that grew while an earlier launch's results were still in flight."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    if window:
+        env["OTTI_MSM_WINDOW"] = window
+    res = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "fresh_process_check.py")], env=env, capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout + res.stderr
+
+
 def test_golden_proof_digests_on_gpu():
     import json
     import os
