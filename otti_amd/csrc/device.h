@@ -1,4 +1,4 @@
-// Device layer of the proving path: HBM-resident objects and the kernel launch functions (kernels.hip).
+// Device layer of the proving path: HBM-resident objects and the kernel launch functions (k_*.hip).
 // Everything runs on one HIP stream owned by DevCtx; results that the Fiat-Shamir transcript needs come back through
 // a small pinned buffer.  No function here falls back to the host: without a gfx950 device they throw Error(OTTI_ERR_NO_DEVICE).
 #pragma once

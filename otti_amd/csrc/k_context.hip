@@ -1,0 +1,141 @@
+// gfx950 (MI355X, CDNA4) kernels of the Spartan NIZK proving path (this file: the device context, kernel timing, host waits;
+// kernels live in k_field.hip, k_sparse.hip, k_sumcheck.hip, k_msm.hip).  Wave64; 256 CUs in 8 XCDs; every kernel here is integer
+// work on 256-bit field elements (8 x u32 limbs, v_mad_u64_u32 chains) — no MFMA applies.  Streaming kernels (K1-K7, K9)
+// move 32-byte elements with two 16-byte accesses per lane and are HBM-bound; the fixed-base MSM (K8) is integer-ALU-bound.
+//
+// Kernel <-> upstream hot loop [RECALL: the reference's Spartan/ submodule is empty]:
+//   k_spmv3_*            K1 sparse_mlpoly.rs SparseMatPolynomial::multiply_vec, K6 compute_eval_table_sparse (transposed copy)
+//   k_eq_small/_expand   K2 dense_mlpoly.rs EqPolynomial::evals
+//   k_sc_*               K3/K7 sumcheck.rs prove_cubic_with_additive_term / prove_quad inner loops, fused with
+//                        K4 dense_mlpoly.rs DensePolynomial::bound_poly_var_top of the previous round
+//   k_fold_top/_bot      K4/K5 bound_poly_var_top / bound_poly_var_bot
+//   k_msm_rows/_finish   K8 DensePolynomial::commit_inner -> Commitments::commit (dalek vartime_multiscalar_mul), also K10's L/R
+//   k_poly_bound_*       K9 DensePolynomial::bound
+//   k_bullet_step        K10 nizk/bullet.rs BulletReductionProof::prove scalar bookkeeping
+#include "kernels_common.h"
+
+namespace otti {
+
+void hip_check(hipError_t e, const char *what, const char *file, int line) {
+    if (e == hipSuccess) return;
+    char buf[512]; snprintf(buf, sizeof buf, "HIP error %d (%s) at %s:%d: %s", (int)e, hipGetErrorString(e), file, line, what);
+    throw Error(OTTI_ERR_NO_DEVICE, buf);
+}
+
+// ------------------------------------------------------------------------------------------------ context
+DevCtx &DevCtx::get() {
+    static std::mutex mu; static DevCtx *ctx = nullptr; static bool failed = false; static std::string why;
+    std::lock_guard<std::mutex> lk(mu);
+    if (ctx) return *ctx;
+    if (failed) throw Error(OTTI_ERR_NO_DEVICE, why);
+    try {
+        int count = 0;
+        hipError_t e = hipGetDeviceCount(&count);
+        if (e != hipSuccess || count == 0) throw Error(OTTI_ERR_NO_DEVICE, "no HIP device visible: the MI355X proving path has no CPU fallback");
+        int dev = 0;
+        const char *env = getenv("OTTI_DEVICE"); if (!env) env = getenv("LOCAL_RANK");
+        if (env) dev = atoi(env) % count;
+        OTTI_HIP(hipSetDevice(dev));
+        hipDeviceProp_t prop; OTTI_HIP(hipGetDeviceProperties(&prop, dev));
+        if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+            char buf[256]; snprintf(buf, sizeof buf, "device %d is %s; this library carries gfx950 code objects only", dev, prop.gcnArchName);
+            throw Error(OTTI_ERR_NO_DEVICE, buf);
+        }
+        DevCtx *c = new DevCtx();
+        c->device = dev; c->num_cu = prop.multiProcessorCount;
+        OTTI_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->partials.alloc((size_t)kMaxBlocks * 4);
+        c->results.alloc(kResultSlots);
+        OTTI_HIP(hipHostMalloc((void **)&c->h_results, kResultSlots * sizeof(Fr), hipHostMallocDefault));
+        OTTI_HIP(hipHostGetDevicePointer((void **)&c->d_results_alias, c->h_results, 0));
+        OTTI_HIP(hipHostMalloc((void **)&c->h_flag, 64, hipHostMallocDefault));
+        *c->h_flag = 0;
+        OTTI_HIP(hipHostGetDevicePointer((void **)&c->d_flag_alias, c->h_flag, 0));
+        c->d_counter.alloc(1);
+        OTTI_HIP(hipMemset(c->d_counter.p, 0, sizeof(unsigned)));
+        OTTI_HIP(hipEventCreate(&c->ev0)); OTTI_HIP(hipEventCreate(&c->ev1));
+        ctx = c;
+        return *ctx;
+    } catch (const Error &e) { failed = true; why = e.what(); throw; }
+}
+
+void DevCtx::ensure_points(size_t rows, size_t splits) {
+    // Growing these buffers invalidates results of launches still in flight (h_points in particular is read by the host after an event
+    // wait), so capacities start generous and the prover sizes them for the whole proof before its first launch; a later growth
+    // drains the stream first.
+    const size_t want_partial = std::max<size_t>(rows * splits, 8192), want_rows = std::max<size_t>(rows, 2 * kHostPtsCap);
+    if (want_partial > msm_partial_cap) { if (stream) OTTI_HIP(hipStreamSynchronize(stream)); msm_partial.alloc(want_partial); msm_partial_cap = want_partial; }
+    if (want_rows > points_cap) {
+        if (stream) OTTI_HIP(hipStreamSynchronize(stream));
+        if (h_points) (void)hipHostFree(h_points);
+        OTTI_HIP(hipHostMalloc((void **)&h_points, want_rows * 32, hipHostMallocDefault));
+        d_points.alloc(want_rows * 32); msm_final.alloc(want_rows); points_cap = want_rows;
+    }
+    if (!h_pts) {
+        OTTI_HIP(hipHostMalloc((void **)&h_pts, kHostPtsCap * sizeof(Pt), hipHostMallocDefault));
+        OTTI_HIP(hipHostGetDevicePointer((void **)&d_pts_alias, h_pts, 0));
+        d_counter2.alloc(1); OTTI_HIP(hipMemset(d_counter2.p, 0, sizeof(unsigned)));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ kernel timing
+KStats &KStats::get() { static KStats s; return s; }
+int KStats::begin(DevCtx &c, int k) {
+    if (!on || !((mask >> k) & 1u)) return -1;
+    if (pool.empty()) { pool.resize(16384); for (auto &e : pool) OTTI_HIP(hipEventCreate(&e)); cls.resize(8192); }
+    if (used + 1 > cls.size()) return -1;                     // pool exhausted until the next flush
+    int rec = (int)used++;
+    cls[rec] = k;
+    OTTI_HIP(hipEventRecord(pool[2 * rec], c.stream));
+    return rec;
+}
+void KStats::end(DevCtx &c, int rec) { if (rec >= 0) (void)hipEventRecord(pool[2 * rec + 1], c.stream); }
+void KStats::flush() {
+    for (size_t r = 0; r < used; r++) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, pool[2 * r], pool[2 * r + 1]) == hipSuccess) { total_ms[cls[r]] += ms; count[cls[r]]++; }
+    }
+    used = 0;
+}
+void KStats::reset() { used = 0; for (int k = 0; k < KC_COUNT; k++) { total_ms[k] = 0; count[k] = 0; } }
+
+Mailbox DevCtx::next_mailbox(int slot) {
+    Mailbox mb; mb.partials = partials.p; mb.counter = d_counter.p; mb.host_results = d_results_alias; mb.host_flag = d_flag_alias;
+    mb.seq = ++seq; mb.slot = slot; return mb;
+}
+void DevCtx::wait_ticket(unsigned long long ticket) {
+    volatile unsigned long long *f = h_flag;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0;; spins++) {
+        if (*f >= ticket) return;
+#if defined(__x86_64__)
+        _mm_pause();
+#endif
+        if ((spins & 0xffff) == 0xffff && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) {
+            OTTI_HIP(hipStreamSynchronize(stream));          // surfaces a device fault as an error instead of spinning forever
+            if (*f >= ticket) return;
+            throw Error(OTTI_ERR_INTERNAL, "sum-check round result never arrived");
+        }
+    }
+}
+void DevCtx::wait_points(unsigned long long ticket) {
+    if (!ticket) { sync(); return; }
+    wait_ticket(ticket);
+    encode_pending();
+}
+void DevCtx::sync() {
+    OTTI_HIP(hipStreamSynchronize(stream));
+    encode_pending();
+}
+void DevCtx::encode_pending() {
+    if (pending_host_encode >= 2) {
+        SpinPool &pool = SpinPool::get(); const int nt = std::min<int>(pool.workers() + 1, (int)pending_host_encode);
+        const size_t n = pending_host_encode;
+        std::vector<std::function<void()>> tasks(nt);
+        for (int t = 0; t < nt; t++) tasks[t] = [this, t, nt, n] { for (size_t i = t; i < n; i += nt) pt_encode(h_points + 32 * i, h_pts[i]); };
+        pool.parallel(tasks.data(), nt);
+    } else if (pending_host_encode == 1) pt_encode(h_points, h_pts[0]);
+    pending_host_encode = 0;
+}
+
+}  // namespace otti

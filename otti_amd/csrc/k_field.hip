@@ -1,0 +1,35 @@
+// Element-wise field kernels, conversions, strided gather.
+#include "kernels_common.h"
+
+namespace otti {
+
+// ------------------------------------------------------------------------------------------------ element-wise
+__global__ void k_fr_op(int op, const Fr *a, const Fr *b, Fr *out, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        Fr x = a[i], y = b[i];
+        out[i] = op == 0 ? fr_mul(x, y) : op == 1 ? fr_add(x, y) : fr_sub(x, y);
+    }
+}
+__global__ void k_fr_scale(const Fr *in, Fr k, Fr *out, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = fr_mul(in[i], k);
+}
+__global__ void k_fr_fill(Fr *p, Fr v, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+void dev_fr_op(DevCtx &c, int op, const Fr *a, const Fr *b, Fr *out, size_t n) { if (n) hipLaunchKernelGGL(k_fr_op, grid_for(n), kBlock, 0, c.stream, op, a, b, out, n); }
+void dev_scale(DevCtx &c, const Fr *in, const Fr &k, Fr *out, size_t n) { if (n) hipLaunchKernelGGL(k_fr_scale, grid_for(n), kBlock, 0, c.stream, in, k, out, n); }
+void dev_from_canonical(DevCtx &c, const Fr *in, Fr *out, size_t n) { dev_scale(c, in, fr_R2(), out, n); }
+void dev_to_canonical(DevCtx &c, const Fr *in, Fr *out, size_t n) { Fr one = fr_zero(); one.v[0] = 1; dev_scale(c, in, one, out, n); }
+void dev_fill_zero(DevCtx &c, Fr *p, size_t n) { if (n) OTTI_HIP(hipMemsetAsync(p, 0, n * sizeof(Fr), c.stream)); }
+void dev_fill_one(DevCtx &c, Fr *p, size_t n) { if (n) hipLaunchKernelGGL(k_fr_fill, grid_for(n), kBlock, 0, c.stream, p, fr_one(), n); }
+void dev_fetch(DevCtx &c, const Fr *src, int slot, size_t n) { OTTI_HIP(hipMemcpyAsync(c.h_results + slot, src, n * sizeof(Fr), hipMemcpyDeviceToHost, c.stream)); }
+
+__global__ __launch_bounds__(kBlock) void k_gather_strided(const Fr *in, size_t stride, size_t offset, Fr *out, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = in[i * stride + offset];
+}
+void dev_gather_strided(DevCtx &c, const Fr *in, size_t stride, size_t offset, Fr *out, size_t n) {
+    KScope ks(c, KC_OTHER);
+    hipLaunchKernelGGL(k_gather_strided, grid_for(n), kBlock, 0, c.stream, in, stride, offset, out, n);
+}
+
+}  // namespace otti

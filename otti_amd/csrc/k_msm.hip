@@ -1,0 +1,385 @@
+// K8 fixed-base MSM over the generator window table (commitments, bullet-reduction rounds), the table build, K10 bookkeeping.
+#include "kernels_common.h"
+
+namespace otti {
+
+// ------------------------------------------------------------------------------------------------ K8 fixed-base MSM
+// One workgroup sums a chunk of one row's terms.  Phase 1 stages the chunk's scalars in LDS as s' = raw(s) + K with
+// K = sum_w 2^(c-1+cw): the signed radix-2^c digit of window w is then (window w of s') - 2^(c-1), with no carry chain between
+// windows, so any thread can take any (term, window) pair.  Phase 2: thread (term lane tl, window w) walks the terms tl, tl+lanes, ..
+// and adds the table entry |d| * 2^(cw) * P[base] (affine Niels, 96-byte gather from HBM/L2; negated in registers when d < 0) into
+// its own accumulator with one 7-multiply mixed addition per pair.  Phase 3: LDS tree over the 256 accumulators.
+constexpr int kMsmMaxChunk = 1024;             // terms per workgroup (LDS: 36 B each)
+constexpr int kMsmBulkChunk = 512;             // bulk launches: terms per workgroup, and
+constexpr int kMsmListCap = (kMsmBulkChunk + 8) * 16;   // their (term, window) work-list entries (2 B each): (chunk + extras) * W must fit
+static_assert(kMsmMaxChunk + 8 <= 2048, "work-list entries pack the term index in 11 bits");
+// Bullet-reduction round fused into the MSM launch: the scalars of rows L (0) and R (1) are not read from memory but derived in phase 1
+// from the round state (a, b: the two folded vectors; s: coefficients of the original generators), after applying the previous
+// round's challenge.  State is ping-ponged (read *_in, write *_out) so that no workgroup of the launch reads what another one writes.
+struct BulletArgs { int on, fold; uint32_t n; const Fr *a_in, *b_in, *s_in; Fr *a_out, *b_out, *s_out; Fr u, uinv; };
+struct MsmArgs {
+    const Niels *table; int c, W; uint32_t E; int lanes;            // lanes = 256 / W term lanes
+    const Fr *dense; size_t stride, n_dense; uint32_t chunk, nchunks;
+    const Fr *extra_s; uint32_t extra_base[8]; int n_extra;
+    uint32_t K[9];                                                  // recoding constant (288 bits)
+    Pt *partial;
+    // fused finish (rows <= 2, 1 < nchunks <= 128): the last workgroup to arrive sums every row's partials and mails the extended
+    // row sums to pinned host memory, then raises the host flag — no finish launch, no copy, no stream synchronise
+    int fuse; uint32_t rows; unsigned *counter; Pt *host_pts; unsigned long long *host_flag; unsigned long long seq;
+    BulletArgs bul;
+};
+__device__ __forceinline__ Fr bullet_fold_a(const BulletArgs &U, size_t x) { return U.fold ? fr_add(fr_mul(U.a_in[x], U.u), fr_mul(U.uinv, U.a_in[U.n + x])) : U.a_in[x]; }
+__device__ __forceinline__ Fr bullet_fold_b(const BulletArgs &U, size_t x) { return U.fold ? fr_add(fr_mul(U.b_in[x], U.uinv), fr_mul(U.u, U.b_in[U.n + x])) : U.b_in[x]; }
+__device__ __forceinline__ Fr bullet_fold_s(const BulletArgs &U, size_t j) { return U.fold ? fr_mul(U.s_in[j], ((j & (2 * (size_t)U.n - 1)) < U.n) ? U.uinv : U.u) : U.s_in[j]; }
+// kKind = MSM_BULK: the bulk launches (a commitment: many rows, every workgroup a full chunk) — no bullet bookkeeping, no fused finish.
+// kKind = MSM_BULK_SPARSE: the same for scalars that are mostly small numbers (compacted work list, see phase 2).
+// kKind = MSM_SMALL: the one/two-row launches of the evaluation proof, latency-bound, with both.  Separate instantiations also keep them
+// apart in profiles (k_msm_rows<false> is the kernel bench.py's roofline object is about).
+enum { MSM_BULK = 0, MSM_SMALL = 1, MSM_BULK_SPARSE = 2 };
+template <int kKind> __global__ __launch_bounds__(kBlock) void k_msm_rows(MsmArgs A) {
+    constexpr bool kSmall = kKind == MSM_SMALL;
+    // the recoded scalars (phases 1-2) and the reduction tree (phase 3) never live at the same time: one LDS region for both
+    constexpr size_t kRawBytes = ((kKind == MSM_BULK_SPARSE ? kMsmBulkChunk : kMsmMaxChunk) + 8) * 9 * sizeof(uint32_t), kTreeBytes = (kBlock / 2) * sizeof(P10);
+    __shared__ __attribute__((aligned(16))) unsigned char s_mem[kRawBytes > kTreeBytes ? kRawBytes : kTreeBytes];
+    __shared__ uint32_t s_base[8];
+    uint32_t *s_raw = reinterpret_cast<uint32_t *>(s_mem);
+    P10 *sm = reinterpret_cast<P10 *>(s_mem);
+    const size_t row = blockIdx.y; const uint32_t chunk_id = blockIdx.x;
+    const size_t j0 = (size_t)chunk_id * A.chunk;
+    const uint32_t n_here = (uint32_t)min((size_t)A.chunk, A.n_dense - j0);
+    const uint32_t n_ex = chunk_id == 0 ? (uint32_t)A.n_extra : 0u;
+    // ---- phase 1: recoded scalars into LDS
+    __shared__ Fr s_dot;                                       // bullet mode: c_L / c_R of this row (chunk 0 only)
+    const bool bullet = kSmall && A.bul.on;
+    if (bullet) {
+        const BulletArgs &U = A.bul; const size_t n = U.n, h = n / 2;
+        if (row == 0) {                                        // persist the folded state for the next round (each element written once)
+            const size_t cx = (n + gridDim.x - 1) / gridDim.x, x0 = (size_t)chunk_id * cx;
+            for (size_t x = x0 + threadIdx.x; x < min(n, x0 + cx); x += blockDim.x) { U.a_out[x] = bullet_fold_a(U, x); U.b_out[x] = bullet_fold_b(U, x); }
+            for (uint32_t t = threadIdx.x; t < n_here; t += blockDim.x) U.s_out[j0 + t] = bullet_fold_s(U, j0 + t);
+        }
+        if (chunk_id == 0) {                                   // c_L = <a_L, b_R> (row 0), c_R = <a_R, b_L> (row 1)
+            Fr acc[1] = {fr_zero()};
+            for (size_t x = threadIdx.x; x < h; x += blockDim.x)
+                acc[0] = fr_add(acc[0], row == 0 ? fr_mul(bullet_fold_a(U, x), bullet_fold_b(U, h + x)) : fr_mul(bullet_fold_a(U, h + x), bullet_fold_b(U, x)));
+            block_reduce<1>(acc);
+            if (threadIdx.x == 0) s_dot = acc[0];
+            __syncthreads();
+        }
+    }
+    for (uint32_t t = threadIdx.x; t < n_here + n_ex; t += blockDim.x) {
+        Fr sc;
+        if (t >= n_here) sc = (bullet && t == n_here) ? s_dot : A.extra_s[row * A.n_extra + (t - n_here)];
+        else if (bullet) {
+            const BulletArgs &U = A.bul; const size_t j = j0 + t, n = U.n, h = n / 2, i = j & (n - 1);
+            // L = <a_L, G_R>: generator slots of the upper half, paired with a[i - h];  R = <a_R, G_L>: lower half with a[i + h]
+            if (row == 0) sc = i >= h ? fr_mul(bullet_fold_a(U, i - h), bullet_fold_s(U, j)) : fr_zero();
+            else sc = i < h ? fr_mul(bullet_fold_a(U, i + h), bullet_fold_s(U, j)) : fr_zero();
+        } else sc = A.dense[row * A.stride + j0 + t];
+        Fr raw = fr_to_raw(sc);
+        uint64_t cy = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) { cy += (uint64_t)raw.v[i] + A.K[i]; s_raw[t * 9 + i] = (uint32_t)cy; cy >>= 32; }
+        s_raw[t * 9 + 8] = (uint32_t)cy + A.K[8];
+    }
+    if (threadIdx.x < 8) s_base[threadIdx.x] = A.extra_base[threadIdx.x];
+    __syncthreads();
+    // ---- phase 2: one mixed addition per (term, window) pair, in 26/25-bit limbs (fp10.h)
+    P10 acc = p10_identity();
+    const int w = threadIdx.x % A.W, tl = threadIdx.x / A.W;
+    if constexpr (kKind == MSM_BULK_SPARSE) {
+        // First compact the pairs whose digit is non-zero into an LDS work list (wave-aggregated append), then every thread takes
+        // list entries round-robin.  A witness produced by a compiler is mostly small numbers (bits, counters, fixed-point values):
+        // with c = 16 a 64-bit scalar has 4-5 non-zero digits out of 16, and with the fixed (term, window) mapping below the lanes
+        // of its empty windows would idle while the others work.  (For uniform scalars the list would simply be all pairs, at the
+        // price of half-size chunks; the host picks this variant from the witness's share of small values.)
+        __shared__ uint16_t s_list[kMsmListCap];
+        __shared__ uint32_t s_count;
+        if (threadIdx.x == 0) s_count = 0;
+        __syncthreads();
+        const uint32_t n_tot = n_here + n_ex, iters = (n_tot + A.lanes - 1) / A.lanes;
+        const int pos = w * A.c, limb = pos >> 5, off = pos & 31;
+        const uint32_t mask = (1u << A.c) - 1u; const int half = 1 << (A.c - 1);
+        const unsigned lane = threadIdx.x & 63;
+        for (uint32_t it = 0; it < iters; it++) {
+            const uint32_t t = (uint32_t)tl + it * (uint32_t)A.lanes;
+            bool nz = false;
+            if (tl < A.lanes && t < n_tot) {
+                uint64_t x = s_raw[t * 9 + limb];
+                if (limb < 8) x |= (uint64_t)s_raw[t * 9 + limb + 1] << 32;
+                nz = ((uint32_t)(x >> off) & mask) != (uint32_t)half;
+            }
+            const unsigned long long bal = __ballot(nz);
+            uint32_t base_pos = 0;
+            if (lane == 0 && bal) base_pos = atomicAdd(&s_count, (uint32_t)__popcll(bal));
+            base_pos = __shfl(base_pos, 0);
+            if (nz) s_list[base_pos + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)((t << 5) | (uint32_t)w);
+        }
+        __syncthreads();
+        const uint32_t count = s_count;
+        const size_t WE = (size_t)A.W * A.E;
+        for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) {
+            const uint32_t e16 = s_list[i], t = e16 >> 5, ww = e16 & 31u;
+            const int p2 = (int)ww * A.c, l2 = p2 >> 5, o2 = p2 & 31;
+            uint64_t x = s_raw[t * 9 + l2];
+            if (l2 < 8) x |= (uint64_t)s_raw[t * 9 + l2 + 1] << 32;
+            const int d = (int)((uint32_t)(x >> o2) & mask) - half;
+            const size_t base = t < n_here ? j0 + t : (size_t)s_base[t - n_here];
+            const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
+            N10 e = n10_unpack(A.table[base * WE + (size_t)ww * A.E + (mag - 1)]);
+            if (d < 0) e = n10_negate(e);
+            acc = p10_madd(acc, e);
+        }
+    } else if (tl < A.lanes) {
+        const int pos = w * A.c, limb = pos >> 5, off = pos & 31;
+        const uint32_t mask = (1u << A.c) - 1u; const int half = 1 << (A.c - 1);
+        const size_t WE = (size_t)A.W * A.E;
+        for (uint32_t t = tl; t < n_here + n_ex; t += A.lanes) {
+            uint64_t x = s_raw[t * 9 + limb];
+            if (limb < 8) x |= (uint64_t)s_raw[t * 9 + limb + 1] << 32;
+            int d = (int)((uint32_t)(x >> off) & mask) - half;
+            if (d == 0) continue;
+            size_t base = t < n_here ? j0 + t : (size_t)s_base[t - n_here];
+            uint32_t mag = (uint32_t)(d < 0 ? -d : d);
+            N10 e = n10_unpack(A.table[base * WE + (size_t)w * A.E + (mag - 1)]);
+            if (d < 0) e = n10_negate(e);
+            acc = p10_madd(acc, e);
+        }
+    }
+    // ---- phase 3: LDS tree (reuses the scalar region: everyone must be done reading it)
+    __syncthreads();
+    const F10 d2 = f10_const(fp_2D());
+    for (int sft = kBlock / 2; sft >= 1; sft >>= 1) {
+        if ((int)threadIdx.x >= sft && (int)threadIdx.x < 2 * sft) sm[threadIdx.x - sft] = acc;
+        __syncthreads();
+        if ((int)threadIdx.x < sft) acc = p10_add(acc, sm[threadIdx.x], d2);
+        __syncthreads();
+    }
+    if (!kSmall || !A.fuse) { if (threadIdx.x == 0) A.partial[row * A.nchunks + chunk_id] = p10_pack(acc); return; }
+    if (threadIdx.x == 0) { Pt pk = p10_pack(acc); store_words_sc1(&A.partial[row * A.nchunks + chunk_id], pk.X.v, 32); }
+    if (!arrive_and_check_last(A.counter, gridDim.x * gridDim.y)) return;
+    {   // 128 threads per row: one partial each, 7-level tree
+        const uint32_t r = threadIdx.x >> 7, idx = threadIdx.x & 127;
+        P10 sum = p10_identity();
+        if (r < A.rows && idx < A.nchunks) { Pt pk; load_words_sc1(pk.X.v, &A.partial[(size_t)r * A.nchunks + idx], 32); sum = p10_unpack(pk); }
+        for (int sft = 64; sft >= 1; sft >>= 1) {
+            if ((int)idx >= sft && (int)idx < 2 * sft) sm[r * 64 + idx - sft] = sum;
+            __syncthreads();
+            if ((int)idx < sft) sum = p10_add(sum, sm[r * 64 + idx], d2);
+            __syncthreads();
+        }
+        if (idx == 0 && r < A.rows) { A.host_pts[r] = p10_pack(sum); __threadfence_system(); }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence_system();
+            __hip_atomic_store(A.host_flag, A.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+// one wave per row: sum the row's chunk partials into one extended point
+__global__ __launch_bounds__(64) void k_msm_finish(const Pt *partial, uint32_t nchunks, size_t rows, Pt *final_pts) {
+    __shared__ P10 sm[32];
+    const size_t row = blockIdx.x;
+    const F10 d2 = f10_const(fp_2D());
+    P10 acc = p10_identity();
+    for (uint32_t k = threadIdx.x; k < nchunks; k += 64) acc = p10_add(acc, p10_unpack(partial[row * nchunks + k]), d2);
+    for (int sft = 32; sft >= 1; sft >>= 1) {
+        if ((int)threadIdx.x >= sft && (int)threadIdx.x < 2 * sft) sm[threadIdx.x - sft] = acc;
+        __syncthreads();
+        if ((int)threadIdx.x < sft) acc = p10_add(acc, sm[threadIdx.x], d2);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) final_pts[row] = p10_pack(acc);
+}
+// RFC 9496 encode, one lane per point (the inverse square root is a ~265-multiplication dependent chain: pack 64 rows per wave)
+__global__ __launch_bounds__(64) void k_encode_points(const Pt *pts, const Pt *addend, size_t n, uint8_t *out32) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    P10 p = p10_unpack(pts[i]);
+    if (addend) p = p10_add(p, p10_unpack(addend[i]), f10_const(fp_2D()));
+    uint8_t enc[32]; p10_encode(enc, p);
+    uint32_t *o = (uint32_t *)(out32 + 32 * i);
+    for (int k = 0; k < 8; k++) o[k] = (uint32_t)enc[4 * k] | ((uint32_t)enc[4 * k + 1] << 8) | ((uint32_t)enc[4 * k + 2] << 16) | ((uint32_t)enc[4 * k + 3] << 24);
+}
+static unsigned long long msm_launch(DevCtx &c, const DeviceGens &g, const Fr *dense, size_t stride, size_t n_dense, size_t rows, const Fr *extra_s,
+                                     const uint32_t *extra_base, size_t n_extra, int mode, const Pt *addend, const BulletArgs *bul, bool sparse_hint);
+unsigned long long dev_msm_rows(DevCtx &c, const DeviceGens &g, const Fr *dense, size_t stride, size_t n_dense, size_t rows, const Fr *extra_s,
+                                const uint32_t *extra_base, size_t n_extra, int mode, const Pt *addend, bool sparse_hint) {
+    return msm_launch(c, g, dense, stride, n_dense, rows, extra_s, extra_base, n_extra, mode, addend, nullptr, sparse_hint);
+}
+// share of the n scalars whose canonical value is below 2^128 (what a compiled circuit's witness is mostly made of)
+__global__ __launch_bounds__(kBlock) void k_count_small(const Fr *z, size_t n, unsigned long long *count) {
+    unsigned mine = 0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        Fr r = fr_to_raw(z[i]);
+        mine += (r.v[4] | r.v[5] | r.v[6] | r.v[7]) == 0 ? 1u : 0u;
+    }
+    for (int o = 32; o >= 1; o >>= 1) mine += __shfl_down(mine, o);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(count, (unsigned long long)mine);
+}
+double dev_small_fraction(DevCtx &c, const Fr *z, size_t n) {
+    if (!n) return 0.0;
+    DevBuf<unsigned long long> cnt(1);
+    OTTI_HIP(hipMemsetAsync(cnt.p, 0, sizeof(unsigned long long), c.stream));
+    hipLaunchKernelGGL(k_count_small, grid_for(n), kBlock, 0, c.stream, z, n, cnt.p);
+    unsigned long long h = 0;
+    OTTI_HIP(hipMemcpyAsync(&h, cnt.p, sizeof h, hipMemcpyDeviceToHost, c.stream));
+    OTTI_HIP(hipStreamSynchronize(c.stream));
+    return (double)h / (double)n;
+}
+unsigned long long dev_bullet_round(DevCtx &c, const DeviceGens &g, size_t R, size_t n_cur, bool fold, const Fr &u, const Fr &u_inv, const Fr *a_in,
+                                    const Fr *b_in, const Fr *s_in, Fr *a_out, Fr *b_out, Fr *s_out, const Fr *extra_s, const uint32_t *extra_base) {
+    BulletArgs U; U.on = 1; U.fold = fold ? 1 : 0; U.n = (uint32_t)n_cur; U.a_in = a_in; U.b_in = b_in; U.s_in = s_in;
+    U.a_out = a_out; U.b_out = b_out; U.s_out = s_out; U.u = u; U.uinv = u_inv;
+    return msm_launch(c, g, nullptr, 0, R, 2, extra_s, extra_base, 2, MSM_COMPRESSED, nullptr, &U, false);
+}
+static unsigned long long msm_launch(DevCtx &c, const DeviceGens &g, const Fr *dense, size_t stride, size_t n_dense, size_t rows, const Fr *extra_s,
+                                     const uint32_t *extra_base, size_t n_extra, int mode, const Pt *addend, const BulletArgs *bul, bool sparse_hint) {
+    const bool raw_points = mode == MSM_RAW;
+    if (n_extra > 8) throw Error(OTTI_ERR_INTERNAL, "msm: too many extra terms");
+    if (!rows) return 0;
+    MsmArgs A;
+    A.table = g.table.p; A.c = g.c; A.W = g.W; A.E = (uint32_t)g.E; A.lanes = kBlock / g.W;
+    A.dense = dense; A.stride = stride; A.n_dense = n_dense; A.extra_s = extra_s; A.n_extra = (int)n_extra;
+    for (int i = 0; i < 8; i++) A.extra_base[i] = i < (int)n_extra ? extra_base[i] : 0;
+    // chunking: aim for >= 1024 workgroups (4 per CU) but keep at least one term per term lane and at most kMsmMaxChunk per workgroup
+    size_t nchunks = std::max<size_t>(1, (1024 + rows - 1) / rows);
+    nchunks = std::min(nchunks, std::max<size_t>(1, n_dense / (size_t)A.lanes));
+    if (!n_dense) nchunks = 1;
+    // bulk launches keep a (term, window) work list in LDS: (chunk + extras) * W <= kMsmListCap;  W <= 32 there (5-bit window field)
+    const bool bulk = rows * n_dense >= ((size_t)1 << 16) && !bul;
+    const bool sparse = bulk && sparse_hint && g.W <= 32;
+    const size_t max_chunk = sparse ? std::min<size_t>(kMsmBulkChunk, (size_t)kMsmListCap / (size_t)g.W - n_extra) : (size_t)kMsmMaxChunk;
+    nchunks = std::max(nchunks, (n_dense + max_chunk - 1) / max_chunk);
+    size_t chunk = n_dense ? (n_dense + nchunks - 1) / nchunks : 1;
+    nchunks = n_dense ? (n_dense + chunk - 1) / chunk : 1;
+    A.chunk = (uint32_t)chunk; A.nchunks = (uint32_t)nchunks;
+    for (int i = 0; i < 9; i++) A.K[i] = 0;
+    for (int w = 0; w < g.W; w++) { int bit = g.c - 1 + g.c * w; A.K[bit >> 5] |= 1u << (bit & 31); }
+    c.ensure_points(rows, nchunks);
+    A.partial = c.msm_partial.p;
+    A.fuse = (!bulk && mode == MSM_COMPRESSED && !addend && rows <= 2 && nchunks > 1 && nchunks <= 128) ? 1 : 0;
+    if (bul) A.bul = *bul; else { memset(&A.bul, 0, sizeof A.bul); }
+    A.rows = (uint32_t)rows; A.counter = c.d_counter2.p; A.host_pts = c.d_pts_alias; A.host_flag = c.d_flag_alias; A.seq = A.fuse ? ++c.seq : 0;
+    dim3 grid((unsigned)nchunks, (unsigned)rows);
+    {
+        KScope ks(c, bulk ? KC_MSM_ROWS : KC_MSM_SMALL);
+        if (sparse) hipLaunchKernelGGL(k_msm_rows<MSM_BULK_SPARSE>, grid, kBlock, 0, c.stream, A);
+        else if (bulk) hipLaunchKernelGGL(k_msm_rows<MSM_BULK>, grid, kBlock, 0, c.stream, A);
+        else hipLaunchKernelGGL(k_msm_rows<MSM_SMALL>, grid, kBlock, 0, c.stream, A);
+    }
+    if (A.fuse) { c.pending_host_encode = rows; return A.seq; }
+    // rows with a single chunk need no finish pass: their partial IS the row sum
+    const Pt *finals = c.msm_partial.p;
+    if (nchunks > 1) {
+        KScope ks(c, KC_MSM_FINISH);
+        hipLaunchKernelGGL(k_msm_finish, (unsigned)rows, 64, 0, c.stream, (const Pt *)c.msm_partial.p, (uint32_t)nchunks, rows, c.msm_final.p);
+        finals = c.msm_final.p;
+    }
+    if (mode == MSM_KEEP) {
+        if (c.msm_keep.n < rows) c.msm_keep.alloc(rows);
+        OTTI_HIP(hipMemcpyAsync(c.msm_keep.p, finals, rows * sizeof(Pt), hipMemcpyDeviceToDevice, c.stream));
+        c.pending_host_encode = 0;
+    } else if (raw_points) {
+        if (rows > kHostPtsCap) throw Error(OTTI_ERR_INTERNAL, "msm: too many raw rows");
+        OTTI_HIP(hipMemcpyAsync(c.h_pts, finals, rows * sizeof(Pt), hipMemcpyDeviceToHost, c.stream));
+        c.pending_host_encode = 0;
+    } else if (rows > kHostEncodeRows || addend) {
+        KScope ks(c, KC_MSM_FINISH);
+        hipLaunchKernelGGL(k_encode_points, (unsigned)((rows + 63) / 64), 64, 0, c.stream, finals, addend, rows, c.d_points.p);
+        OTTI_HIP(hipMemcpyAsync(c.h_points, c.d_points.p, rows * 32, hipMemcpyDeviceToHost, c.stream));
+        c.pending_host_encode = 0;
+    } else {
+        // a handful of points: the dependent inverse-square-root chain runs ~30x faster on a host core than on one GPU lane
+        OTTI_HIP(hipMemcpyAsync(c.h_pts, finals, rows * sizeof(Pt), hipMemcpyDeviceToHost, c.stream));
+        c.pending_host_encode = rows;
+    }
+    return 0;
+}
+// table build.  Row (base b, window w) holds d * B for d = 1..E with B = 2^(cw) * P[b].  Rows are cut into blocks of T entries:
+// k_table_starts (one thread per row) walks the block starts (kT+1) * B; k_table_fill (one thread per block) fills its T extended
+// points by repeated addition of B, then turns them into affine Niels form with one batch inversion over the block.
+__global__ __launch_bounds__(kBlock) void k_table_starts(const Pt *bases, size_t nb, int c, int W, size_t nblk, int lgT, Pt *starts) {
+    size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (t >= nb * W) return;
+    size_t b = t / W; int w = (int)(t % W);
+    Pt B = bases[b];
+    for (int k = 0; k < c * w; k++) B = pt_dbl(B);
+    Pt TB = B;
+    for (int k = 0; k < lgT; k++) TB = pt_dbl(TB);
+    Pt acc = B; Pt *row = starts + t * nblk;
+    row[0] = acc;
+    for (size_t k = 1; k < nblk; k++) { acc = pt_add(acc, TB); row[k] = acc; }
+}
+__global__ __launch_bounds__(kBlock) void k_table_fill(const Pt *starts, size_t nrows, size_t nblk, size_t T, Pt *tmp, Niels *out) {
+    size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (t >= nrows * nblk) return;
+    const size_t r = t / nblk;
+    const Pt B = starts[r * nblk];
+    Pt acc = starts[t];
+    Pt *blk = tmp + t * T; Niels *oblk = out + t * T;                                      // row r, block k: entries r*E + k*T ..
+    Fp prod = fp_one();
+    for (size_t d = 0; d < T; d++) {
+        if (d) acc = pt_add(acc, B);
+        Pt p = acc; p.T = prod;                                                             // T is not needed for the affine form: park the prefix product there
+        blk[d] = p; prod = fp_mul(prod, acc.Z);
+    }
+    Fp inv = fp_inv(prod);
+    for (size_t d = T; d-- > 0;) { Pt p = blk[d]; Fp zinv = fp_mul(inv, p.T); inv = fp_mul(inv, p.Z); oblk[d] = pt_to_niels(p, zinv); }
+}
+std::shared_ptr<DeviceGens> build_device_gens(const Gens &g, int c) {
+    DevCtx &ctx = DevCtx::get();
+    auto d = std::make_shared<DeviceGens>();
+    d->c = c; d->W = 253 / c + 1; d->E = (size_t)1 << (c - 1); d->nbases = g.P.size();
+    const size_t per_base = (size_t)d->W * d->E;
+    const int lgT = std::min(6, c - 1); const size_t T = (size_t)1 << lgT, nblk = d->E / T;
+    d->table.alloc(d->nbases * per_base);
+    DevBuf<Pt> bases(d->nbases), starts(d->nbases * d->W * nblk);
+    OTTI_HIP(hipMemcpy(bases.p, g.P.data(), d->nbases * sizeof(Pt), hipMemcpyHostToDevice));
+    { size_t n = d->nbases * d->W; hipLaunchKernelGGL(k_table_starts, (unsigned)((n + kBlock - 1) / kBlock), kBlock, 0, ctx.stream, (const Pt *)bases.p, d->nbases, c, d->W, nblk, lgT, starts.p); }
+    size_t chunk = std::max<size_t>(1, ((size_t)4 << 30) / (per_base * sizeof(Pt)));            // <= 4 GiB of extended temporaries
+    chunk = std::min(chunk, d->nbases);
+    DevBuf<Pt> tmp(chunk * per_base);
+    for (size_t b0 = 0; b0 < d->nbases; b0 += chunk) {
+        size_t nb = std::min(chunk, d->nbases - b0), nrows = nb * d->W, nthreads = nrows * nblk;
+        hipLaunchKernelGGL(k_table_fill, (unsigned)((nthreads + kBlock - 1) / kBlock), kBlock, 0, ctx.stream, (const Pt *)(starts.p + b0 * d->W * nblk), nrows, nblk, T,
+                           tmp.p, d->table.p + b0 * per_base);
+    }
+    ctx.sync();
+    return d;
+}
+
+// ------------------------------------------------------------------------------------------------ K10 bullet reduction bookkeeping
+// Instead of folding the generator vector (n/2 two-scalar multiplications per round upstream), keep the ORIGINAL generators and a
+// coefficient vector s with G^(k)_i = sum_{j = i mod n} s[j] * P[j]; L and R of each round are then fixed-base MSM rows over P.
+__global__ __launch_bounds__(1024) void k_bullet_step(Fr *a, Fr *b, Fr *s, size_t R, size_t n, int fold_first, Fr u, Fr uinv, Fr *rows, Fr *extra_out) {
+    if (fold_first) {
+        for (size_t i = threadIdx.x; i < n; i += blockDim.x) {
+            a[i] = fr_add(fr_mul(a[i], u), fr_mul(uinv, a[n + i]));
+            b[i] = fr_add(fr_mul(b[i], uinv), fr_mul(u, b[n + i]));
+        }
+        for (size_t j = threadIdx.x; j < R; j += blockDim.x) s[j] = fr_mul(s[j], ((j & (2 * n - 1)) < n) ? uinv : u);
+        __syncthreads();
+    }
+    if (n < 2) return;
+    size_t h = n / 2;
+    Fr acc[2] = {fr_zero(), fr_zero()};
+    for (size_t i = threadIdx.x; i < h; i += blockDim.x) {
+        acc[0] = fr_add(acc[0], fr_mul(a[i], b[h + i]));       // c_L = <a_L, b_R>
+        acc[1] = fr_add(acc[1], fr_mul(a[h + i], b[i]));       // c_R = <a_R, b_L>
+    }
+    block_reduce<2>(acc);
+    if (threadIdx.x == 0) { extra_out[0] = acc[0]; extra_out[2] = acc[1]; }
+    for (size_t j = threadIdx.x; j < R; j += blockDim.x) {
+        size_t i = j & (n - 1);
+        Fr sj = s[j];
+        rows[j] = i >= h ? fr_mul(a[i - h], sj) : fr_zero();       // L = <a_L, G_R> : generator slots in the upper half
+        rows[R + j] = i < h ? fr_mul(a[i + h], sj) : fr_zero();    // R = <a_R, G_L>
+    }
+}
+void dev_bullet_step(DevCtx &c, Fr *a, Fr *b, Fr *s, size_t R, size_t n_cur, bool fold_first, const Fr &u, const Fr &u_inv, Fr *rows, Fr *extra_out) {
+    KScope ks(c, KC_BULLET);
+    hipLaunchKernelGGL(k_bullet_step, 1, 1024, 0, c.stream, a, b, s, R, n_cur, (int)fold_first, u, u_inv, rows, extra_out);
+}
+
+}  // namespace otti

@@ -1,0 +1,217 @@
+// K2 eq tables, K3/K4/K5/K7 sum-check rounds and folds, K9 DensePolynomial::bound.
+#include "kernels_common.h"
+
+namespace otti {
+
+// ------------------------------------------------------------------------------------------------ K2 eq tables
+struct FrArgs { Fr v[13]; };
+// one workgroup builds eq(r, .) for ell <= 12 by doubling, ping-ponging between two global buffers
+__global__ __launch_bounds__(1024) void k_eq_small(FrArgs r, int ell, Fr *out, Fr *tmp) {
+    Fr *cur = (ell & 1) ? tmp : out, *nxt = (ell & 1) ? out : tmp;   // after ell swaps the result sits in `out`
+    if (threadIdx.x == 0) cur[0] = fr_one();
+    __syncthreads();
+    size_t size = 1;
+    for (int j = 0; j < ell; j++) {
+        Fr rj = r.v[j];
+        for (size_t k = threadIdx.x; k < size; k += blockDim.x) { Fr v = cur[k], hi = fr_mul(v, rj); nxt[2 * k + 1] = hi; nxt[2 * k] = fr_sub(v, hi); }
+        __syncthreads();
+        Fr *t = cur; cur = nxt; nxt = t; size *= 2;
+    }
+}
+// out[i] = hi[i >> lo_bits] * lo[i & (2^lo_bits - 1)]  (index bits are MSB-first over r, so the product of two sub-tables is the table)
+__global__ __launch_bounds__(kBlock) void k_eq_expand(const Fr *hi, const Fr *lo, int lo_bits, Fr *out, size_t n) {
+    size_t mask = ((size_t)1 << lo_bits) - 1;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = fr_mul(hi[i >> lo_bits], lo[i & mask]);
+}
+void dev_eq_evals(DevCtx &c, const Fr *r, size_t ell, Fr *out, Fr *scratch) {
+    auto small = [&](const Fr *rr, int e, Fr *dst, Fr *tmp) {
+        FrArgs a; for (int i = 0; i < 13; i++) a.v[i] = i < e ? rr[i] : fr_zero();
+        hipLaunchKernelGGL(k_eq_small, 1, 1024, 0, c.stream, a, e, dst, tmp);
+    };
+    KScope ks(c, KC_EQ);
+    if (ell <= 12) { small(r, (int)ell, out, scratch); return; }
+    int lo_bits = 12, hi_bits = (int)ell - 12;
+    if (hi_bits > 13) throw Error(OTTI_ERR_BAD_ARG, "eq table larger than 2^25");
+    Fr *lo = scratch, *hi = scratch + 4096, *tmp = hi + (hi_bits > 12 ? 8192 : 4096);   // scratch >= 3 * 4096 (5 * 4096 for ell = 25)
+    small(r + hi_bits, lo_bits, lo, tmp);
+    small(r, hi_bits, hi, tmp);                                          // same stream: ordered after the first use of tmp
+    size_t n = (size_t)1 << ell;
+    hipLaunchKernelGGL(k_eq_expand, grid_for(n), kBlock, 0, c.stream, hi, lo, lo_bits, out, n);
+}
+
+// ------------------------------------------------------------------------------------------------ K3/K4/K7 sum-check rounds
+struct Pair { Fr lo, hi; };
+__device__ __forceinline__ void cubic_accum(Fr (&acc)[3], const Pair &a, const Pair &b, const Pair &c, const Pair &d) {
+    // comb = A * (B * C - D) at t = 0, 2, 3 with X(2) = 2 X[hi] - X[lo], X(3) = X(2) + X[hi] - X[lo]
+    acc[0] = fr_add(acc[0], fr_mul(a.lo, fr_sub(fr_mul(b.lo, c.lo), d.lo)));
+    Fr da = fr_sub(a.hi, a.lo), db = fr_sub(b.hi, b.lo), dc = fr_sub(c.hi, c.lo), dd = fr_sub(d.hi, d.lo);
+    Fr a2 = fr_add(a.hi, da), b2 = fr_add(b.hi, db), c2 = fr_add(c.hi, dc), d2 = fr_add(d.hi, dd);
+    acc[1] = fr_add(acc[1], fr_mul(a2, fr_sub(fr_mul(b2, c2), d2)));
+    Fr a3 = fr_add(a2, da), b3 = fr_add(b2, db), c3 = fr_add(c2, dc), d3 = fr_add(d2, dd);
+    acc[2] = fr_add(acc[2], fr_mul(a3, fr_sub(fr_mul(b3, c3), d3)));
+}
+__device__ __forceinline__ void quad_accum(Fr (&acc)[2], const Pair &a, const Pair &b) {
+    acc[0] = fr_add(acc[0], fr_mul(a.lo, b.lo));
+    Fr a2 = fr_sub(fr_add(a.hi, a.hi), a.lo), b2 = fr_sub(fr_add(b.hi, b.hi), b.lo);
+    acc[1] = fr_add(acc[1], fr_mul(a2, b2));
+}
+__device__ __forceinline__ Pair load_pair(const Fr *T, size_t i, size_t half) { Pair p; p.lo = T[i]; p.hi = T[i + half]; return p; }
+// fold the table of length 4q by r (bound_poly_var_top) for the two entries that form pair i of the folded table
+__device__ __forceinline__ Pair fold_pair(Fr *T, size_t i, size_t q, const Fr &r) {
+    Fr a = T[i], b = T[i + q], c = T[i + 2 * q], d = T[i + 3 * q];
+    Pair p; p.lo = fr_add(a, fr_mul(r, fr_sub(c, a))); p.hi = fr_add(b, fr_mul(r, fr_sub(d, b)));
+    T[i] = p.lo; T[i + q] = p.hi;
+    return p;
+}
+template <int K> __device__ __forceinline__ void store_partials(Fr (&acc)[K], Fr *partials) {
+    block_reduce<K>(acc);
+    if (threadIdx.x == 0) for (int k = 0; k < K; k++) partials[(size_t)blockIdx.x * K + k] = acc[k];
+}
+// Round sums without a second launch or a stream synchronise: every workgroup publishes its partial sums, the last one to arrive
+// (agent-scope counter; release/acquire per the gfx950 inter-workgroup recipe) adds them up, writes the K totals straight into
+// pinned host memory and then stores the launch's sequence number into a host-visible flag the prover thread is spinning on.
+template <int K> __device__ __forceinline__ void finish_in_kernel(Fr (&acc)[K], const Mailbox &mb) {
+    block_reduce<K>(acc);
+    if (gridDim.x > 1) {
+        if (threadIdx.x == 0) for (int k = 0; k < K; k++) store_words_sc1(&mb.partials[(size_t)blockIdx.x * K + k], acc[k].v, 8);
+        if (!arrive_and_check_last(mb.counter, gridDim.x)) return;
+        for (int k = 0; k < K; k++) acc[k] = fr_zero();
+        for (unsigned b = threadIdx.x; b < gridDim.x; b += blockDim.x)
+            for (int k = 0; k < K; k++) { Fr t; load_words_sc1(t.v, &mb.partials[(size_t)b * K + k], 8); acc[k] = fr_add(acc[k], t); }
+        block_reduce<K>(acc);
+    }
+    if (threadIdx.x == 0) {
+        for (int k = 0; k < K; k++) mb.host_results[mb.slot + k] = acc[k];
+        __threadfence_system();
+        __hip_atomic_store(mb.host_flag, mb.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+// All of an item's loads are issued before any arithmetic so that their HBM latency is paid once per item, not once per table.
+__global__ __launch_bounds__(kBlock) void k_sc_cubic_eval(const Fr *A, const Fr *B, const Fr *C, const Fr *D, size_t half, Mailbox mb) {
+    Fr acc[3] = {fr_zero(), fr_zero(), fr_zero()};
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x) {
+        Pair a, b, c, d;
+        a.lo = A[i]; a.hi = A[i + half]; b.lo = B[i]; b.hi = B[i + half]; c.lo = C[i]; c.hi = C[i + half]; d.lo = D[i]; d.hi = D[i + half];
+        __builtin_amdgcn_sched_barrier(0);                    // keep the scheduler from sinking the loads next to their uses
+        cubic_accum(acc, a, b, c, d);
+    }
+    finish_in_kernel<3>(acc, mb);
+}
+__device__ __forceinline__ Pair fold_regs(const Fr &x0, const Fr &x1, const Fr &x2, const Fr &x3, const Fr &r) {
+    Pair p; p.lo = fr_add(x0, fr_mul(r, fr_sub(x2, x0))); p.hi = fr_add(x1, fr_mul(r, fr_sub(x3, x1))); return p;
+}
+__global__ __launch_bounds__(kBlock) void k_sc_cubic_fold_eval(Fr *A, Fr *B, Fr *C, Fr *D, size_t q, Fr r, Mailbox mb) {
+    Fr acc[3] = {fr_zero(), fr_zero(), fr_zero()};
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < q; i += (size_t)gridDim.x * blockDim.x) {
+        // two load groups of eight elements: all sixteen in flight at once would need the whole register file (one wave per SIMD)
+        Fr a0 = A[i], a1 = A[i + q], a2 = A[i + 2 * q], a3 = A[i + 3 * q];
+        Fr b0 = B[i], b1 = B[i + q], b2 = B[i + 2 * q], b3 = B[i + 3 * q];
+        __builtin_amdgcn_sched_barrier(0);
+        Pair a = fold_regs(a0, a1, a2, a3, r); A[i] = a.lo; A[i + q] = a.hi;
+        Fr c0 = C[i], c1 = C[i + q], c2 = C[i + 2 * q], c3 = C[i + 3 * q];
+        Fr d0 = D[i], d1 = D[i + q], d2 = D[i + 2 * q], d3 = D[i + 3 * q];
+        __builtin_amdgcn_sched_barrier(0);
+        Pair b = fold_regs(b0, b1, b2, b3, r); B[i] = b.lo; B[i + q] = b.hi;
+        Pair c = fold_regs(c0, c1, c2, c3, r); C[i] = c.lo; C[i + q] = c.hi;
+        Pair d = fold_regs(d0, d1, d2, d3, r); D[i] = d.lo; D[i + q] = d.hi;
+        cubic_accum(acc, a, b, c, d);
+    }
+    finish_in_kernel<3>(acc, mb);
+}
+__global__ __launch_bounds__(kBlock) void k_sc_quad_eval(const Fr *A, const Fr *B, size_t half, Mailbox mb) {
+    Fr acc[2] = {fr_zero(), fr_zero()};
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x) {
+        Pair a, b;
+        a.lo = A[i]; a.hi = A[i + half]; b.lo = B[i]; b.hi = B[i + half];
+        __builtin_amdgcn_sched_barrier(0);
+        quad_accum(acc, a, b);
+    }
+    finish_in_kernel<2>(acc, mb);
+}
+__global__ __launch_bounds__(kBlock) void k_sc_quad_fold_eval(Fr *A, Fr *B, size_t q, Fr r, Mailbox mb) {
+    Fr acc[2] = {fr_zero(), fr_zero()};
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < q; i += (size_t)gridDim.x * blockDim.x) {
+        Fr a0 = A[i], a1 = A[i + q], a2 = A[i + 2 * q], a3 = A[i + 3 * q];
+        Fr b0 = B[i], b1 = B[i + q], b2 = B[i + 2 * q], b3 = B[i + 3 * q];
+        __builtin_amdgcn_sched_barrier(0);
+        Pair a = fold_regs(a0, a1, a2, a3, r); A[i] = a.lo; A[i + q] = a.hi;
+        Pair b = fold_regs(b0, b1, b2, b3, r); B[i] = b.lo; B[i + q] = b.hi;
+        quad_accum(acc, a, b);
+    }
+    finish_in_kernel<2>(acc, mb);
+}
+__global__ __launch_bounds__(kBlock) void k_fold_top(Fr *Z, size_t half, Fr r) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x) {
+        Fr a = Z[i], b = Z[i + half]; Z[i] = fr_add(a, fr_mul(r, fr_sub(b, a)));
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_fold_bot(const Fr *Z, Fr *out, size_t half, Fr r) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x) {
+        Fr a = Z[2 * i], b = Z[2 * i + 1]; out[i] = fr_add(a, fr_mul(r, fr_sub(b, a)));
+    }
+}
+template <int K> static void finish_round(DevCtx &c, int nblocks, int slot) {
+    { KScope ks(c, KC_REDUCE); hipLaunchKernelGGL(k_reduce_partials<K>, 1, kBlock, 0, c.stream, (const Fr *)c.partials.p, nblocks, c.results.p + slot); }
+    dev_fetch(c, c.results.p + slot, slot, K);
+}
+unsigned long long dev_sc_cubic_eval(DevCtx &c, const Fr *A, const Fr *B, const Fr *C, const Fr *D, size_t len, int slot) {
+    size_t half = len / 2; int g = grid_for(half); Mailbox mb = c.next_mailbox(slot);
+    KScope ks(c, KC_SC_CUBIC); hipLaunchKernelGGL(k_sc_cubic_eval, g, kBlock, 0, c.stream, A, B, C, D, half, mb);
+    return mb.seq;
+}
+unsigned long long dev_sc_cubic_fold_eval(DevCtx &c, Fr *A, Fr *B, Fr *C, Fr *D, size_t len, const Fr &r, int slot) {
+    if (len < 4) throw Error(OTTI_ERR_INTERNAL, "fold_eval needs len >= 4");
+    size_t q = len / 4; int g = grid_for(q); Mailbox mb = c.next_mailbox(slot);
+    KScope ks(c, KC_SC_CUBIC); hipLaunchKernelGGL(k_sc_cubic_fold_eval, g, kBlock, 0, c.stream, A, B, C, D, q, r, mb);
+    return mb.seq;
+}
+unsigned long long dev_sc_quad_eval(DevCtx &c, const Fr *A, const Fr *B, size_t len, int slot) {
+    size_t half = len / 2; int g = grid_for(half); Mailbox mb = c.next_mailbox(slot);
+    KScope ks(c, KC_SC_QUAD); hipLaunchKernelGGL(k_sc_quad_eval, g, kBlock, 0, c.stream, A, B, half, mb);
+    return mb.seq;
+}
+unsigned long long dev_sc_quad_fold_eval(DevCtx &c, Fr *A, Fr *B, size_t len, const Fr &r, int slot) {
+    if (len < 4) throw Error(OTTI_ERR_INTERNAL, "fold_eval needs len >= 4");
+    size_t q = len / 4; int g = grid_for(q); Mailbox mb = c.next_mailbox(slot);
+    KScope ks(c, KC_SC_QUAD); hipLaunchKernelGGL(k_sc_quad_fold_eval, g, kBlock, 0, c.stream, A, B, q, r, mb);
+    return mb.seq;
+}
+void dev_fold_top(DevCtx &c, Fr *Z, size_t len, const Fr &r) { size_t h = len / 2; if (h) hipLaunchKernelGGL(k_fold_top, grid_for(h), kBlock, 0, c.stream, Z, h, r); }
+void dev_fold_bot(DevCtx &c, const Fr *Z, Fr *out, size_t len, const Fr &r) { size_t h = len / 2; if (h) hipLaunchKernelGGL(k_fold_bot, grid_for(h), kBlock, 0, c.stream, Z, out, h, r); }
+
+__global__ __launch_bounds__(kBlock) void k_dot(const Fr *a, const Fr *b, size_t n, Fr *partials) {
+    Fr acc[1] = {fr_zero()};
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) acc[0] = fr_add(acc[0], fr_mul(a[i], b[i]));
+    store_partials<1>(acc, partials);
+}
+void dev_dot(DevCtx &c, const Fr *a, const Fr *b, size_t n, int slot) {
+    int g = grid_for(n);
+    hipLaunchKernelGGL(k_dot, g, kBlock, 0, c.stream, a, b, n, c.partials.p);
+    finish_round<1>(c, g, slot);
+}
+
+// ------------------------------------------------------------------------------------------------ K9 DensePolynomial::bound
+__global__ __launch_bounds__(kBlock) void k_poly_bound_slab(const Fr *Z, size_t L, size_t R, const Fr *Lv, size_t rows_per_slab, Fr *scratch) {
+    size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (j >= R) return;
+    size_t i0 = blockIdx.y * rows_per_slab, i1 = min(L, i0 + rows_per_slab);
+    Fr acc = fr_zero();
+    for (size_t i = i0; i < i1; i++) acc = fr_add(acc, fr_mul(Lv[i], Z[i * R + j]));
+    scratch[(size_t)blockIdx.y * R + j] = acc;
+}
+__global__ __launch_bounds__(kBlock) void k_colsum(const Fr *scratch, size_t slabs, size_t R, Fr *out) {
+    size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (j >= R) return;
+    Fr acc = scratch[j];
+    for (size_t s = 1; s < slabs; s++) acc = fr_add(acc, scratch[s * R + j]);
+    out[j] = acc;
+}
+void dev_poly_bound(DevCtx &c, const Fr *Z, size_t L, size_t R, const Fr *Lv, Fr *out, Fr *scratch) {
+    size_t slabs = std::min<size_t>(L, 64), rps = (L + slabs - 1) / slabs;
+    KScope ks(c, KC_BOUND);
+    dim3 grid((unsigned)((R + kBlock - 1) / kBlock), (unsigned)slabs);
+    hipLaunchKernelGGL(k_poly_bound_slab, grid, kBlock, 0, c.stream, Z, L, R, Lv, rps, scratch);
+    hipLaunchKernelGGL(k_colsum, (unsigned)((R + kBlock - 1) / kBlock), kBlock, 0, c.stream, (const Fr *)scratch, slabs, R, out);
+}
+
+}  // namespace otti

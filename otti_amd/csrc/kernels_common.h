@@ -1,0 +1,83 @@
+// Shared by the k_*.hip translation units: launch geometry, the inter-workgroup hand-off used by every kernel whose last workgroup
+// finishes the job (sum-check rounds, small MSMs), and the wave/block reductions of field elements.
+#pragma once
+#include "device.h"
+#include "fp10.h"
+#include "pool.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <algorithm>
+#include <chrono>
+#include <mutex>
+
+namespace otti {
+
+constexpr int kBlock = 256;
+constexpr int kMaxBlocks = 2048;           // 8 workgroups per CU; grid-stride beyond that
+constexpr int kHeavyRow = 64;              // sparse rows longer than this go to the one-workgroup-per-row kernel
+
+static inline int grid_for(size_t n) { size_t b = (n + kBlock - 1) / kBlock; return (int)std::max<size_t>(1, std::min<size_t>(b, kMaxBlocks)); }
+
+// ------------------------------------------------------------------------------------------------ inter-workgroup hand-off
+// Publishing a workgroup's partial result to the LAST workgroup of the same launch.  A per-workgroup agent release fence
+// (buffer_wbl2) serialises on the XCD's L2 and cost ~100 us over a 2048-workgroup grid; instead every handed-off byte is written
+// with write-through (sc1) stores and read with sc1 loads (8-byte relaxed agent-scope atomics lower to exactly those), the storing
+// lane drains its stores (s_waitcnt vmcnt(0)) before its agent-scope counter add, and the last arriver's other waves read only
+// after a workgroup barrier behind the lane whose add returned last (MI355X guide, "valid forms", sc1 row).
+__device__ __forceinline__ void store_words_sc1(void *dst, const uint32_t *w, int nwords) {
+    unsigned long long *p = reinterpret_cast<unsigned long long *>(dst);
+    for (int i = 0; i < nwords / 2; i++)
+        __hip_atomic_store(p + i, (unsigned long long)w[2 * i] | ((unsigned long long)w[2 * i + 1] << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void load_words_sc1(uint32_t *w, const void *src, int nwords) {
+    const unsigned long long *p = reinterpret_cast<const unsigned long long *>(src);
+    for (int i = 0; i < nwords / 2; i++) {
+        unsigned long long v = __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        w[2 * i] = (uint32_t)v; w[2 * i + 1] = (uint32_t)(v >> 32);
+    }
+}
+// true in every thread of exactly one workgroup: the last one to call it in this launch (counter is left at zero for the next launch)
+__device__ __forceinline__ bool arrive_and_check_last(unsigned *counter, unsigned total) {
+    __shared__ int s_is_last;
+    if (threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this lane's sc1 stores have left
+        unsigned old = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_is_last = (old == total - 1) ? 1 : 0;
+        if (s_is_last) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    return s_is_last != 0;
+}
+
+// ------------------------------------------------------------------------------------------------ wave / block reductions of Fr
+__device__ __forceinline__ Fr shfl_xor_fr(const Fr &x, int mask) {
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.v[i] = (uint32_t)__shfl_xor((int)x.v[i], mask, 64);
+    return r;
+}
+// sums acc[0..K) over the workgroup (blockDim.x a multiple of 64, <= 1024); thread 0 ends up with the totals
+template <int K> __device__ __forceinline__ void block_reduce(Fr (&acc)[K]) {
+    __shared__ Fr sm[K][16];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1)
+#pragma unroll
+        for (int k = 0; k < K; k++) acc[k] = fr_add(acc[k], shfl_xor_fr(acc[k], off));
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();                         // protects sm against a previous use
+    if (lane == 0) for (int k = 0; k < K; k++) sm[k][wave] = acc[k];
+    __syncthreads();
+    if (threadIdx.x == 0)
+        for (int k = 0; k < K; k++) { Fr t = sm[k][0]; for (int w = 1; w < nw; w++) t = fr_add(t, sm[k][w]); acc[k] = t; }
+}
+template <int K> __global__ __launch_bounds__(kBlock) void k_reduce_partials(const Fr *partials, int nblocks, Fr *out) {
+    Fr acc[K];
+    for (int k = 0; k < K; k++) acc[k] = fr_zero();
+    for (int b = threadIdx.x; b < nblocks; b += blockDim.x)
+        for (int k = 0; k < K; k++) acc[k] = fr_add(acc[k], partials[(size_t)b * K + k]);
+    block_reduce<K>(acc);
+    if (threadIdx.x == 0) for (int k = 0; k < K; k++) out[k] = acc[k];
+}
+
+
+}  // namespace otti

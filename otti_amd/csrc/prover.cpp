@@ -426,7 +426,7 @@ std::vector<uint8_t> nizk_prove_resident(Instance &I, DeviceWitness &wit, Gens &
         { Term t2[2] = {{g.pc_1.G[0], eval_vars_at_ry}, {g.pc_1.h, blind_eval}}; g.commit_terms_c(P.comm_vars_at_ry.b, t2, 2); }
         tr.append_point("Cy", P.comm_vars_at_ry.b);
         Fr blind_fin = fr_add(LZ_blind, blind_eval);
-        // BulletReductionProof::prove on the original generators (see kernels.hip k_bullet_step)
+        // BulletReductionProof::prove on the original generators (see k_msm.hip)
         std::vector<Fr> ex(4 * (lgR + 1), fr_zero());
         for (size_t k = 0; k < lgR; k++) { ex[4 * k + 1] = bv1[k]; ex[4 * k + 3] = bv2[k]; }
         OTTI_HIP(hipMemcpyAsync(S.extras.p, ex.data(), ex.size() * sizeof(Fr), hipMemcpyHostToDevice, c.stream));

@@ -1,5 +1,5 @@
 // Host-side model of the Spartan NIZK objects for the MI355X proving path: instance (sparse A,B,C), generators,
-// proof layout, sigma protocols, verifier.  The prover's data-parallel work lives in kernels.hip / prover.cpp.
+// proof layout, sigma protocols, verifier.  The prover's data-parallel work lives in k_*.hip / prover.cpp.
 // Mirrors upstream libspartan's public API for this path [RECALL lib.rs: Instance, VarsAssignment, InputsAssignment,
 // NIZKGens, NIZK::{prove,verify}], reached from `spzk verify --nizk` [REF /root/reference/run.py:58, run.py:100].
 #pragma once
@@ -30,9 +30,9 @@ struct SparseMat {
     Csr by_row, by_col;                                     // multiply_vec / compute_eval_table_sparse access paths
 };
 
-struct DeviceInstance;   // kernels.hip
-struct DeviceShard;      // kernels.hip: this rank's slice of the instance when one proof runs over several GPUs (shard.h)
-struct DeviceGens;       // kernels.hip
+struct DeviceInstance;   // device.h / k_sparse.hip
+struct DeviceShard;      // device.h / k_sparse.hip: this rank's slice of the instance when one proof runs over several GPUs (shard.h)
+struct DeviceGens;       // device.h / k_msm.hip
 void build_csr(Csr &out, const std::vector<uint32_t> &major, const std::vector<uint32_t> &minor, const std::vector<Fr> &val, size_t rows);
 
 struct Instance {
