@@ -47,6 +47,8 @@ def main():
     ap.add_argument("--dist", choices=("uniform", "compiler"), default="uniform", help="synthetic instance distribution (SURVEY 8d); the metric is quoted on 'uniform'")
     ap.add_argument("--cpu-log2", type=int, default=None, help="size of the CPU-baseline sample (default: same workload)")
     ap.add_argument("--shard", action="store_true", help="N > 1: all ranks prove ONE instance together (strong scaling) instead of one proof per GPU")
+    ap.add_argument("--concurrent", type=int, default=1, help="prover threads per GPU: a step is then that many proofs of the workload in flight at once "
+                    "(each thread has its own stream/workspace; instance, window table and witness are shared)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -69,6 +71,13 @@ def main():
     xdev = "cpu" if rehearse else "cuda"                     # where tensors handed to torch.distributed live
     shard = bool(args.shard and world > 1)
 
+    conc = 1 if shard else max(1, args.concurrent)
+    if conc > 1:
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        lws = int(os.environ.get("LOCAL_WORLD_SIZE", "1"))
+        # host threads per prover (itself + spinning helpers for the per-round sigma-protocol work): share the cores fairly
+        os.environ.setdefault("OTTI_HOST_THREADS", str(max(1, min(4, cores // max(1, lws * conc)))))
+    import threading
     import numpy as np
     import otti_amd as oa
 
@@ -124,7 +133,23 @@ def main():
     dom = max(("msm_rows", "sc_cubic", "sc_quad", "spmv"), key=lambda k: breakdown[k][1])
     # timed region: HIP events only around the dominant class (two event records per launch would otherwise tax every round)
     oa.stats_enable(True, only=dom)
+    # --concurrent B: B - 1 more prover threads (own device context each), warmed up and parked on a barrier
+    gate, others, other_proofs, errors = threading.Barrier(conc), [], [], []
+
+    def extra_prover():
+        try:
+            mine = [prove_once() for _ in range(max(1, args.warmup))]
+            gate.wait()
+            mine += [prove_once() for _ in range(args.steps)]
+            other_proofs.extend(mine)
+        except BaseException as e:                              # noqa: BLE001 - reported after the join
+            errors.append(e)
+            gate.abort()
+
+    for _ in range(conc - 1):
+        th = threading.Thread(target=extra_prover); th.start(); others.append(th)
     barrier()
+    gate.wait()
     t0 = time.perf_counter()
     stage_acc = {}
     for _ in range(args.steps):
@@ -132,8 +157,13 @@ def main():
         proofs.append(p)
         for k, v in p.stage_ms.items():
             stage_acc[k] = stage_acc.get(k, 0.0) + v
+    for th in others:
+        th.join()
     barrier()
     elapsed = time.perf_counter() - t0
+    if errors:
+        raise errors[0]
+    proofs += other_proofs
     stats = oa.stats_read()
     oa.stats_enable(False)
 
@@ -163,7 +193,7 @@ def main():
 
     steps = max(1, args.steps)
     ms_per_step = 1e3 * elapsed / steps
-    value = (1 if shard else world) * n * steps / elapsed
+    value = (1 if shard else world) * conc * n * steps / elapsed
 
     # oracle cross-check of the GPU path (checker only; small size, outside the timed region)
     import orc
@@ -215,7 +245,7 @@ def main():
                                "frac": round(rate / 1e9 / MADD_PEAK_G, 4),
                                "note": "peak = tools/mulbench.hip p10_madd throughput on this chip, all CUs busy, operands in registers"}
     whole = algorithmic_bytes(N, V, nnz)
-    proof_gbps = whole / (ms_per_step * 1e-3) / 1e9
+    proof_gbps = conc * whole / (ms_per_step * 1e-3) / 1e9
 
     cpu_baseline = None
     if not args.no_cpu_baseline:
@@ -244,7 +274,8 @@ def main():
                                 if args.dist == "uniform" else
                                 f"synthetic compiler-like R1CS, 2^{lg} constraints = variables, 10 inputs, 1..8 nnz/row/matrix, 90% of the witness < 2^64, heavy constant column ")
                                + "(SURVEY 8d); one NIZK::prove per step, witness/instance/generators resident in HBM",
-                   "parallelism": ("1 proof sharded over %d GPUs" % world if shard else "1 proof per GPU") if world > 1 else "single GPU", "msm_window_bits": cbits, "msm_table_GB": round(table_bytes / 1e9, 2)},
+                   "parallelism": (("1 proof sharded over %d GPUs" % world if shard else "1 proof per GPU") if world > 1 else "single GPU")
+                                  + ("" if conc == 1 else ", %d proofs in flight per GPU (one prover thread each)" % conc), "proofs_in_flight_per_gpu": conc, "msm_window_bits": cbits, "msm_table_GB": round(table_bytes / 1e9, 2)},
         "roofline": roofline,
         "cpu_baseline": cpu_baseline,
         "stage_ms": {k: round(v / steps, 3) for k, v in stage_acc.items()},

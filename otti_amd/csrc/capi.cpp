@@ -95,9 +95,9 @@ int32_t otti_gens_points(const otti_gens *gens, uint8_t *out32, size_t count) {
 
 int32_t otti_prepare_device(otti_instance *inst, otti_gens *gens) {
     return guarded([&] {
-        if (inst && !inst->I->dev) inst->I->dev = upload_instance(*inst->I);
+        if (inst) ensure_instance_device(*inst->I);
         if (inst && gens) ensure_device_objects(*inst->I, *gens->g);
-        else if (gens && !gens->g->dev) gens->g->dev = build_device_gens(*gens->g, device_window_bits(gens->g->R + 2));
+        else if (gens) ensure_gens_device(*gens->g);
         return OTTI_OK;
     });
 }
@@ -251,7 +251,7 @@ int32_t otti_k_fr_to_canonical(const uint8_t *in, uint8_t *out, size_t n) {
 }
 int32_t otti_k_multiply_vec(otti_instance *inst, const uint8_t *z, uint8_t *Az, uint8_t *Bz, uint8_t *Cz, float *ms) {
     return guarded([&] {
-        DevCtx &c = DevCtx::get(); Instance &I = *inst->I; if (!I.dev) I.dev = upload_instance(I);
+        DevCtx &c = DevCtx::get(); Instance &I = *inst->I; ensure_instance_device(I);
         Staged Z(c, z, 2 * I.num_vars); DevBuf<Fr> a(I.num_cons), b(I.num_cons), d(I.num_cons);
         KTimer t(c, ms); dev_spmv3(c, I.dev->by_row, Z.d.p, a.p, b.p, d.p, false, nullptr); t.stop();
         download(c, Az, a.p, I.num_cons); download(c, Bz, b.p, I.num_cons); download(c, Cz, d.p, I.num_cons); c.sync(); return OTTI_OK;
@@ -259,7 +259,7 @@ int32_t otti_k_multiply_vec(otti_instance *inst, const uint8_t *z, uint8_t *Az, 
 }
 int32_t otti_k_eval_table_sparse(otti_instance *inst, const uint8_t *eq_rx, const uint8_t *rABC, uint8_t *out, float *ms) {
     return guarded([&] {
-        DevCtx &c = DevCtx::get(); Instance &I = *inst->I; if (!I.dev) I.dev = upload_instance(I);
+        DevCtx &c = DevCtx::get(); Instance &I = *inst->I; ensure_instance_device(I);
         Staged E(c, eq_rx, I.num_cons); DevBuf<Fr> o(2 * I.num_vars);
         Fr coef[3] = {fr_load(rABC), fr_load(rABC + 32), fr_load(rABC + 64)};
         KTimer t(c, ms); dev_spmv3(c, I.dev->by_col, E.d.p, o.p, nullptr, nullptr, true, coef); t.stop();
@@ -325,7 +325,7 @@ int32_t otti_k_msm_rows(otti_gens *gens, const uint8_t *Z, size_t L, size_t R, c
     return guarded([&] {
         DevCtx &c = DevCtx::get(); Gens &g = *gens->g;
         if (R != g.R) throw Error(OTTI_ERR_BAD_ARG, "row length differs from the generator count");
-        if (!g.dev) g.dev = build_device_gens(g, device_window_bits(g.R + 2));
+        ensure_gens_device(g);
         Staged z(c, Z, L * R), bl(c, blinds, L);
         uint32_t hb = g.pc_n.h;
         const bool sparse = dev_small_fraction(c, z.d.p, L * R) > 0.25;                  // the prover takes this from the resident witness

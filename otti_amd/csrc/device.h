@@ -29,7 +29,6 @@ struct DeviceCsrSet {
     DevBuf<uint32_t> ptr[3], idx[3]; DevBuf<Fr> val[3];
     DevBuf<uint32_t> heavy;                                   // ids of rows whose longest list exceeds kHeavyRow
     DevBuf<uint32_t> seg_row, seg_no, seg_begin;              // their segments (row id, segment number), and each long row's first segment
-    DevBuf<Fr> seg_partial;                                   // 3 partial sums per segment
     size_t rows = 0, n_heavy = 0, n_seg = 0;
     DCsr3 view() const { DCsr3 v; for (int k = 0; k < 3; k++) { v.ptr[k] = ptr[k].p; v.idx[k] = idx[k].p; v.val[k] = val[k].p; } return v; }
 };
@@ -52,6 +51,7 @@ struct DevCtx {
     hipStream_t stream = nullptr;
     int device = 0, num_cu = 256;
     DevBuf<Fr> partials;                                      // [kMaxBlocks][4] per-block partial sums
+    DevBuf<Fr> spmv_partial;                                  // 3 partial sums per long-row segment of the SpMV in flight
     DevBuf<Fr> results;                                       // small device result slots
     Fr *h_results = nullptr;                                  // pinned mirror of `results`
     Fr *d_results_alias = nullptr;                            // device address of h_results (zero-copy stores)
@@ -66,7 +66,8 @@ struct DevCtx {
     DevBuf<uint8_t> d_points;
     size_t msm_partial_cap = 0, points_cap = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    static DevCtx &get();                                     // throws Error(OTTI_ERR_NO_DEVICE) when no device is usable
+    static DevCtx &get();                                     // the calling thread's context; throws Error(OTTI_ERR_NO_DEVICE) when no device is usable
+    DevCtx() {} ~DevCtx(); DevCtx(const DevCtx &) = delete; DevCtx &operator=(const DevCtx &) = delete;
     void sync();
     void wait_points(unsigned long long ticket);              // results of a dev_msm_rows launch: flag wait when fused, else stream sync
     void encode_pending();
@@ -97,7 +98,9 @@ struct DeviceWitness {
     double small_fraction = 0.0;                              // share of the variables below 2^128: picks the MSM variant of the commitment
     DeviceWitness(const Instance &I, const std::vector<Fr> &vars_padded, const std::vector<Fr> &inputs);
 };
-void ensure_device_objects(Instance &I, Gens &g);
+void ensure_device_objects(Instance &I, Gens &g);          // lazily built, shared by every prover thread (guarded)
+void ensure_instance_device(Instance &I);
+void ensure_gens_device(Gens &g);
 int device_window_bits(size_t nbases);                   // window width of the fixed-base table (prover.cpp)
 // R1CSInstance::evaluate on the device: (A,B,C)(rx,ry) = <eq(rx), M * eq(ry)> for M in {A,B,C}  (verifier's O(nnz + N + V) work)
 void instance_evaluate_gpu(Instance &I, const std::vector<Fr> &rx, const std::vector<Fr> &ry, Fr out[3]);

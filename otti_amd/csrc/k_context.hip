@@ -23,40 +23,59 @@ void hip_check(hipError_t e, const char *what, const char *file, int line) {
 }
 
 // ------------------------------------------------------------------------------------------------ context
+// One context per calling thread: its own stream, mailbox, result buffers.  Provers running on different threads of one process
+// therefore overlap on the device (one proof's latency-bound rounds leave most of the chip idle) while sharing the read-only HBM
+// objects — instance CSR, generator window table, resident witness.
 DevCtx &DevCtx::get() {
-    static std::mutex mu; static DevCtx *ctx = nullptr; static bool failed = false; static std::string why;
-    std::lock_guard<std::mutex> lk(mu);
+    static std::mutex mu; static bool probed = false, failed = false; static std::string why; static int dev = 0, num_cu = 0;
+    thread_local std::unique_ptr<DevCtx> ctx;
     if (ctx) return *ctx;
-    if (failed) throw Error(OTTI_ERR_NO_DEVICE, why);
-    try {
-        int count = 0;
-        hipError_t e = hipGetDeviceCount(&count);
-        if (e != hipSuccess || count == 0) throw Error(OTTI_ERR_NO_DEVICE, "no HIP device visible: the MI355X proving path has no CPU fallback");
-        int dev = 0;
-        const char *env = getenv("OTTI_DEVICE"); if (!env) env = getenv("LOCAL_RANK");
-        if (env) dev = atoi(env) % count;
-        OTTI_HIP(hipSetDevice(dev));
-        hipDeviceProp_t prop; OTTI_HIP(hipGetDeviceProperties(&prop, dev));
-        if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
-            char buf[256]; snprintf(buf, sizeof buf, "device %d is %s; this library carries gfx950 code objects only", dev, prop.gcnArchName);
-            throw Error(OTTI_ERR_NO_DEVICE, buf);
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (failed) throw Error(OTTI_ERR_NO_DEVICE, why);
+        if (!probed) {
+            try {
+                int count = 0;
+                hipError_t e = hipGetDeviceCount(&count);
+                if (e != hipSuccess || count == 0) throw Error(OTTI_ERR_NO_DEVICE, "no HIP device visible: the MI355X proving path has no CPU fallback");
+                const char *env = getenv("OTTI_DEVICE"); if (!env) env = getenv("LOCAL_RANK");
+                if (env) dev = atoi(env) % count;
+                OTTI_HIP(hipSetDevice(dev));
+                hipDeviceProp_t prop; OTTI_HIP(hipGetDeviceProperties(&prop, dev));
+                if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+                    char buf[256]; snprintf(buf, sizeof buf, "device %d is %s; this library carries gfx950 code objects only", dev, prop.gcnArchName);
+                    throw Error(OTTI_ERR_NO_DEVICE, buf);
+                }
+                num_cu = prop.multiProcessorCount; probed = true;
+            } catch (const Error &e) { failed = true; why = e.what(); throw; }
         }
-        DevCtx *c = new DevCtx();
-        c->device = dev; c->num_cu = prop.multiProcessorCount;
-        OTTI_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-        c->partials.alloc((size_t)kMaxBlocks * 4);
-        c->results.alloc(kResultSlots);
-        OTTI_HIP(hipHostMalloc((void **)&c->h_results, kResultSlots * sizeof(Fr), hipHostMallocDefault));
-        OTTI_HIP(hipHostGetDevicePointer((void **)&c->d_results_alias, c->h_results, 0));
-        OTTI_HIP(hipHostMalloc((void **)&c->h_flag, 64, hipHostMallocDefault));
-        *c->h_flag = 0;
-        OTTI_HIP(hipHostGetDevicePointer((void **)&c->d_flag_alias, c->h_flag, 0));
-        c->d_counter.alloc(1);
-        OTTI_HIP(hipMemset(c->d_counter.p, 0, sizeof(unsigned)));
-        OTTI_HIP(hipEventCreate(&c->ev0)); OTTI_HIP(hipEventCreate(&c->ev1));
-        ctx = c;
-        return *ctx;
-    } catch (const Error &e) { failed = true; why = e.what(); throw; }
+    }
+    OTTI_HIP(hipSetDevice(dev));                               // the current device is a per-thread setting
+    std::unique_ptr<DevCtx> c(new DevCtx());
+    c->device = dev; c->num_cu = num_cu;
+    OTTI_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->partials.alloc((size_t)kMaxBlocks * 4);
+    c->results.alloc(kResultSlots);
+    OTTI_HIP(hipHostMalloc((void **)&c->h_results, kResultSlots * sizeof(Fr), hipHostMallocDefault));
+    OTTI_HIP(hipHostGetDevicePointer((void **)&c->d_results_alias, c->h_results, 0));
+    OTTI_HIP(hipHostMalloc((void **)&c->h_flag, 64, hipHostMallocDefault));
+    *c->h_flag = 0;
+    OTTI_HIP(hipHostGetDevicePointer((void **)&c->d_flag_alias, c->h_flag, 0));
+    c->d_counter.alloc(1);
+    OTTI_HIP(hipMemset(c->d_counter.p, 0, sizeof(unsigned)));
+    OTTI_HIP(hipEventCreate(&c->ev0)); OTTI_HIP(hipEventCreate(&c->ev1));
+    ctx = std::move(c);
+    return *ctx;
+}
+DevCtx::~DevCtx() {
+    if (stream) (void)hipStreamSynchronize(stream);
+    if (ev0) (void)hipEventDestroy(ev0);
+    if (ev1) (void)hipEventDestroy(ev1);
+    if (h_results) (void)hipHostFree(h_results);
+    if (h_flag) (void)hipHostFree(h_flag);
+    if (h_points) (void)hipHostFree(h_points);
+    if (h_pts) (void)hipHostFree(h_pts);
+    if (stream) (void)hipStreamDestroy(stream);
 }
 
 void DevCtx::ensure_points(size_t rows, size_t splits) {
@@ -79,7 +98,7 @@ void DevCtx::ensure_points(size_t rows, size_t splits) {
 }
 
 // ------------------------------------------------------------------------------------------------ kernel timing
-KStats &KStats::get() { static KStats s; return s; }
+KStats &KStats::get() { thread_local KStats s; return s; }            // per calling thread, like the context it times
 int KStats::begin(DevCtx &c, int k) {
     if (!on || !((mask >> k) & 1u)) return -1;
     if (pool.empty()) { pool.resize(16384); for (auto &e : pool) OTTI_HIP(hipEventCreate(&e)); cls.resize(8192); }

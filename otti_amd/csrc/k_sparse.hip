@@ -56,9 +56,11 @@ void dev_spmv3(DevCtx &c, const DeviceCsrSet &m, const Fr *x, Fr *o0, Fr *o1, Fr
     KScope ks(c, KC_SPMV);
     hipLaunchKernelGGL(k_spmv3_light, grid_for(m.rows), kBlock, 0, c.stream, m.view(), m.rows, x, o0, o1, o2, (int)combine, c0, c1, c2);
     if (m.n_heavy) {
-        hipLaunchKernelGGL(k_spmv3_heavy_seg, (unsigned)m.n_seg, kBlock, 0, c.stream, m.view(), (const uint32_t *)m.seg_row.p, (const uint32_t *)m.seg_no.p, x, m.seg_partial.p);
+        // segment partials are scratch of the CALLER's context: the matrix object itself is shared by concurrent provers
+        if (c.spmv_partial.n < 3 * m.n_seg) { OTTI_HIP(hipStreamSynchronize(c.stream)); c.spmv_partial.alloc(3 * m.n_seg); }
+        hipLaunchKernelGGL(k_spmv3_heavy_seg, (unsigned)m.n_seg, kBlock, 0, c.stream, m.view(), (const uint32_t *)m.seg_row.p, (const uint32_t *)m.seg_no.p, x, c.spmv_partial.p);
         hipLaunchKernelGGL(k_spmv3_heavy_combine, (unsigned)((m.n_heavy + 63) / 64), 64, 0, c.stream, (const uint32_t *)m.heavy.p, (const uint32_t *)m.seg_begin.p, m.n_heavy,
-                           (const Fr *)m.seg_partial.p, o0, o1, o2, (int)combine, c0, c1, c2);
+                           (const Fr *)c.spmv_partial.p, o0, o1, o2, (int)combine, c0, c1, c2);
     }
 }
 
@@ -88,7 +90,6 @@ static void upload_csr_set(DeviceCsrSet &d, const SparseMat M[3], bool by_col) {
     if (!heavy.empty()) {
         auto up = [](DevBuf<uint32_t> &b, const std::vector<uint32_t> &v) { b.alloc(v.size()); OTTI_HIP(hipMemcpy(b.p, v.data(), v.size() * 4, hipMemcpyHostToDevice)); };
         up(d.heavy, heavy); up(d.seg_row, seg_row); up(d.seg_no, seg_no); up(d.seg_begin, seg_begin);
-        d.seg_partial.alloc(3 * seg_row.size());
     }
 }
 std::shared_ptr<DeviceInstance> upload_instance(const Instance &I) {

@@ -18,7 +18,7 @@ namespace otti {
 
 class SpinPool {
 public:
-    static SpinPool &get() { static SpinPool p; return p; }
+    static SpinPool &get() { thread_local SpinPool p; return p; }   // helpers belong to the prover thread that uses them
     int workers() const { return (int)th_.size(); }
 
     struct Session {                                  // RAII: workers spin while one is alive

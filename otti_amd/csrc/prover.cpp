@@ -35,14 +35,14 @@ int device_window_bits(size_t nbases) {
     return best;
 }
 
-void ensure_device_objects(Instance &I, Gens &g) {
-    if (!I.dev) I.dev = upload_instance(I);
-    if (!g.dev) g.dev = build_device_gens(g, device_window_bits(g.R + 2));
-}
+static std::mutex &device_objects_mu() { static std::mutex m; return m; }   // lazily built HBM objects are shared by all prover threads
+void ensure_instance_device(Instance &I) { std::lock_guard<std::mutex> lk(device_objects_mu()); if (!I.dev) I.dev = upload_instance(I); }
+void ensure_gens_device(Gens &g) { std::lock_guard<std::mutex> lk(device_objects_mu()); if (!g.dev) g.dev = build_device_gens(g, device_window_bits(g.R + 2)); }
+void ensure_device_objects(Instance &I, Gens &g) { ensure_instance_device(I); ensure_gens_device(g); }
 
 void instance_evaluate_gpu(Instance &I, const std::vector<Fr> &rx, const std::vector<Fr> &ry, Fr out[3]) {
     DevCtx &c = DevCtx::get();
-    if (!I.dev) I.dev = upload_instance(I);
+    ensure_instance_device(I);
     const size_t N = I.num_cons, V2 = 2 * I.num_vars;
     if (((size_t)1 << rx.size()) != N || ((size_t)1 << ry.size()) != V2) throw Error(OTTI_ERR_VERIFY_INTERNAL, "challenge vector lengths do not match the instance");
     DevBuf<Fr> ex(N), ey(V2), Mz[3] = {DevBuf<Fr>(N), DevBuf<Fr>(N), DevBuf<Fr>(N)}, scratch(5 * 4096);
@@ -131,7 +131,7 @@ struct Scratch {
         N = n; V = v;
     }
 };
-Scratch &workspace() { static Scratch s; return s; }
+Scratch &workspace() { thread_local Scratch s; return s; }      // one per prover thread, like the device context
 inline CPoint point_at(const DevCtx &c, size_t i) { CPoint p; memcpy(p.b, c.h_points + 32 * i, 32); return p; }
 }  // namespace
 
@@ -165,8 +165,6 @@ static void host_fold_top(std::vector<Fr> &t, const Fr &r) {
 
 std::vector<uint8_t> nizk_prove_resident(Instance &I, DeviceWitness &wit, Gens &g, const void *tlabel, size_t tlabel_len, const uint8_t *seed32,
                                          ProveTimings *tm, ShardComm *sh) {
-    static std::mutex prove_mu;                                   // one stream, one workspace: proofs of a process run one at a time
-    std::lock_guard<std::mutex> lock(prove_mu);
     DevCtx &c = DevCtx::get();
     SpinPool::Session pool_session;                               // helper threads spin for the duration of this proof
     ensure_device_objects(I, g);
@@ -182,6 +180,7 @@ std::vector<uint8_t> nizk_prove_resident(Instance &I, DeviceWitness &wit, Gens &
     const size_t Nl = N / G, V2l = 2 * V / G, Ll = Lsz / G;
     if (sh) {
         if (Nl < 2 || V2l < 2 || Ll < 1) throw Error(OTTI_ERR_BAD_ARG, "instance too small to shard over this many GPUs");
+        std::lock_guard<std::mutex> lk(device_objects_mu());
         if (!I.shard || I.shard->rank != (int)rk || I.shard->world != (int)G) I.shard = upload_instance_shard(I, (int)rk, (int)G);
     }
     const DeviceCsrSet &rows_set = sh ? I.shard->by_row : DI.by_row, &cols_set = sh ? I.shard->by_col : DI.by_col;

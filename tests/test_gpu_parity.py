@@ -355,6 +355,38 @@ def test_fresh_process_growing_instances(window):
     assert res.returncode == 0, res.stdout + res.stderr
 
 
+def test_concurrent_provers_share_instance_and_table():
+    """Several prover threads of one process (own device context each) on shared instance / generator / witness handles, plus one
+    thread on a different instance: every proof must be the oracle's, whatever the interleaving on the device."""
+    import threading
+    jobs = []
+    for gen, n, ni in ((oa.synth_r1cs, 1 << 12, 4), (oa.synth_r1cs_compiler_like, 1 << 13, 3), (oa.synth_r1cs, 300, 2)):
+        r = gen(n, ni, 11)
+        inst = oa.Instance.new(r["num_cons"], r["num_vars"], r["num_inputs"], r["A"], r["B"], r["C"])
+        gens = oa.NIZKGens.new(r["num_cons"], r["num_vars"], r["num_inputs"])
+        wit = oa.Witness(inst, oa.VarsAssignment.new(r["vars"]), oa.InputsAssignment.new(r["inputs"]))
+        oi, og = orc.OInstance(r["num_cons"], r["num_vars"], r["num_inputs"], r["A"], r["B"], r["C"]), orc.OGens(r["num_cons"], r["num_vars"], r["num_inputs"])
+        want, _ = orc.nizk_prove(oi, r["vars"], r["inputs"], og, b"mt", b"\x19" * 32)
+        jobs.append((inst, gens, wit, want))
+    results, errors = [], []
+
+    def run(job, reps):
+        try:
+            inst, gens, wit, want = job
+            for _ in range(reps):
+                results.append(oa.NIZK.prove(inst, wit, None, gens, b"mt", b"\x19" * 32).bytes == want)
+        except BaseException as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=run, args=(jobs[k % 3], 6)) for k in range(5)]      # 5 threads: jobs 0 and 1 are shared by two each
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert len(results) == 30 and all(results)
+
+
 def test_golden_proof_digests_on_gpu():
     import json
     import os
