@@ -3,8 +3,13 @@
 
   python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
 
-A "step" is one NIZK::prove of the workload with instance, generators (and their window table) and witness already resident
-in HBM; W untimed warm-up steps, then exactly K timed steps bracketed by barrier + device sync; rank 0 prints ONE JSON line.
+A "step" is one batch of B independent NIZK::prove calls of the workload in flight on a GPU at once (B prover threads of the rank's
+process, each with its own stream and workspace, sharing the instance, the generator window table and the resident witness: a single
+proof is a chain of ~50 strictly sequential Fiat-Shamir rounds that leave most of the chip idle, so a prover that serves a stream of
+proofs keeps several in flight).  B = --concurrent (default: what this rank's host cores feed, at most 6; --concurrent 1 = one proof
+at a time, whose latency is reported as single_proof_ms either way).  Instance, generators (and their window table) and witness are
+resident in HBM before timing; W untimed warm-up steps, then exactly K timed steps bracketed by barrier + device sync; rank 0 prints
+ONE JSON line; value = constraints of all proofs of all ranks / elapsed.
 metric = BASELINE.json's "R1CS constraints/sec proved" on the synthetic 2^20-constraint R1CS of SURVEY.md 8(d).
 Every timed proof is checked: all K proofs of a rank are byte-identical (fixed random-tape seed) and the product verifier
 accepts them; rank 0 additionally compares a 2^12 proof with the CPU oracle (checker only, outside the timed region).
@@ -37,18 +42,37 @@ def algorithmic_bytes(N, V, nnz):
     return 80 * nnz + 704 * N + 736 * V
 
 
+def usable_cores():
+    """cores this process may actually burn: affinity mask, capped by the cgroup CPU quota (a GPU box grants a share of the host)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(txt[0]) // int(txt[1])))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    n = min(n, max(1, q // int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())))
+        except Exception:
+            pass
+    return n
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log2-constraints", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist", choices=("uniform", "compiler"), default="uniform", help="synthetic instance distribution (SURVEY 8d); the metric is quoted on 'uniform'")
     ap.add_argument("--cpu-log2", type=int, default=None, help="size of the CPU-baseline sample (default: same workload)")
     ap.add_argument("--shard", action="store_true", help="N > 1: all ranks prove ONE instance together (strong scaling) instead of one proof per GPU")
-    ap.add_argument("--concurrent", type=int, default=1, help="prover threads per GPU: a step is then that many proofs of the workload in flight at once "
-                    "(each thread has its own stream/workspace; instance, window table and witness are shared)")
+    ap.add_argument("--concurrent", type=int, default=0, help="prover threads per GPU: a step is then that many proofs of the workload in flight at once "
+                    "(each thread has its own stream/workspace; instance, window table and witness are shared).  0 = as many as the host "
+                    "cores of this rank feed (2 host threads per prover, at most 6); 1 = one proof at a time (latency mode)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -71,12 +95,13 @@ def main():
     xdev = "cpu" if rehearse else "cuda"                     # where tensors handed to torch.distributed live
     shard = bool(args.shard and world > 1)
 
-    conc = 1 if shard else max(1, args.concurrent)
+    lws = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
+    cores_here = max(1, usable_cores() // lws)                  # host cores of this rank
+    conc = 1 if shard else (args.concurrent if args.concurrent > 0 else max(1, min(6, cores_here // 2)))
     if conc > 1:
-        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        lws = int(os.environ.get("LOCAL_WORLD_SIZE", "1"))
         # host threads per prover (itself + spinning helpers for the per-round sigma-protocol work): share the cores fairly
-        os.environ.setdefault("OTTI_HOST_THREADS", str(max(1, min(4, cores // max(1, lws * conc)))))
+        os.environ.setdefault("OTTI_HOST_THREADS", str(max(1, min(4, cores_here // conc))))
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")         # one hardware queue per prover stream (HIP's default is 4)
     import threading
     import numpy as np
     import otti_amd as oa
@@ -124,6 +149,10 @@ def main():
     proofs = []
     for _ in range(args.warmup):
         proofs.append(prove_once())
+    # latency of ONE proof with the GPU to itself (untimed region; the timed region below may keep several proofs in flight)
+    single_ms = []
+    for _ in range(3):
+        t0 = time.perf_counter(); proofs.append(prove_once()); single_ms.append(1e3 * (time.perf_counter() - t0))
     # one untimed, fully instrumented proof: per-class kernel time -> picks the dominant kernel class
     oa.stats_enable(True)
     prove_once()
@@ -237,20 +266,26 @@ def main():
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic, "launches": cnt, "avg_launch_ms": round(avg_ms, 4),
                     "algorithmic_bytes_per_launch": int(bytes_per_launch)}
+        if conc > 1 and breakdown[dom][0]:
+            # the same kernel with the GPU to itself (the instrumented single proof above): under `conc` proofs in flight a launch shares
+            # the CUs with other streams' kernels and its wall duration is no longer the kernel's own speed
+            u_ms = breakdown[dom][1] / breakdown[dom][0]
+            roofline["uncontended"] = {"avg_launch_ms": round(u_ms, 4), "achieved": round(bytes_per_launch / (u_ms * 1e-3) / 1e9, 3),
+                                       "frac": round(bytes_per_launch / (u_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 6)}
         if dom == "msm_rows":
             W = 253 // cbits + 1
             adds = V * W // (world if shard else 1)        # one mixed addition (7 multiplications in GF(2^255-19)) per scalar and window
             rate = adds / (avg_ms * 1e-3)
             roofline["alu"] = {"bound": "integer ALU (v_mad_u64_u32)", "achieved": round(rate / 1e9, 3), "peak": MADD_PEAK_G, "unit": "G mixed additions/s",
                                "frac": round(rate / 1e9 / MADD_PEAK_G, 4),
+                               "frac_uncontended": round(adds / (roofline["uncontended"]["avg_launch_ms"] * 1e-3) / 1e9 / MADD_PEAK_G, 4) if "uncontended" in roofline else None,
                                "note": "peak = tools/mulbench.hip p10_madd throughput on this chip, all CUs busy, operands in registers"}
     whole = algorithmic_bytes(N, V, nnz)
     proof_gbps = conc * whole / (ms_per_step * 1e-3) / 1e9
 
     cpu_baseline = None
     if not args.no_cpu_baseline:
-        avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        cores = int(os.environ.get("OTTI_CPU_THREADS", min(avail, 16)))       # a 1-GPU box's CPU share is 16 cores
+        cores = int(os.environ.get("OTTI_CPU_THREADS", min(usable_cores(), 16)))   # a 1-GPU box's CPU share is 16 cores
         clg = args.cpu_log2 if args.cpu_log2 is not None else lg
         cr = r if (clg == lg and rank == 0) else gen(1 << clg, ni, 1)
         ci, cg = orc.OInstance(cr["num_cons"], cr["num_vars"], cr["num_inputs"], cr["A"], cr["B"], cr["C"]), orc.OGens(cr["num_cons"], cr["num_vars"], cr["num_inputs"])
@@ -273,7 +308,8 @@ def main():
         "config": {"workload": (f"synthetic satisfiable R1CS, 2^{lg} constraints = variables, 10 inputs, 1 nnz/row/matrix, uniform GF(l) witness "
                                 if args.dist == "uniform" else
                                 f"synthetic compiler-like R1CS, 2^{lg} constraints = variables, 10 inputs, 1..8 nnz/row/matrix, 90% of the witness < 2^64, heavy constant column ")
-                               + "(SURVEY 8d); one NIZK::prove per step, witness/instance/generators resident in HBM",
+                               + "(SURVEY 8d); witness/instance/generators resident in HBM; one step = "
+                               + ("one NIZK::prove" if conc == 1 else "%d independent NIZK::prove calls of that workload in flight on the GPU (one prover thread each)" % conc),
                    "parallelism": (("1 proof sharded over %d GPUs" % world if shard else "1 proof per GPU") if world > 1 else "single GPU")
                                   + ("" if conc == 1 else ", %d proofs in flight per GPU (one prover thread each)" % conc), "proofs_in_flight_per_gpu": conc, "msm_window_bits": cbits, "msm_table_GB": round(table_bytes / 1e9, 2)},
         "roofline": roofline,
@@ -281,7 +317,7 @@ def main():
         "stage_ms": {k: round(v / steps, 3) for k, v in stage_acc.items()},
         "kernel_ms_per_step": {k: round(v[1], 3) for k, v in breakdown.items() if v[0]},
         "whole_proof_algorithmic_GBps": round(proof_gbps, 2), "whole_proof_hbm_frac": round(proof_gbps / (HBM_PEAK_GBPS * (world if shard else 1)), 6),
-        "prepare_device_ms": round(1e3 * t_prepare, 1), "witness_upload_ms": round(1e3 * t_upload, 2), "verify_ms": round(1e3 * t_verify, 2), "proof_bytes": len(proofs[-1].bytes), "proof_sha256": next(iter(digests)),
+        "prepare_device_ms": round(1e3 * t_prepare, 1), "single_proof_ms": round(min(single_ms), 3), "witness_upload_ms": round(1e3 * t_upload, 2), "verify_ms": round(1e3 * t_verify, 2), "proof_bytes": len(proofs[-1].bytes), "proof_sha256": next(iter(digests)),
         "oracle_parity_2^12": parity_ok,
     }
     print(json.dumps(out))

@@ -8,8 +8,12 @@
  * empty directory in the reference mount, /root/reference/.gitmodules:4-6]; every entry point below names the item it replaces.
  *
  * Conventions: plain pointers and sizes; int32 status (0 = ok, negatives mirror upstream's error enums); inputs are borrowed for
- * the duration of the call; outputs are owned by the library until the matching *_free; no exceptions cross the ABI; handles are
- * not thread-safe, distinct handles are.  All scalars are 32-byte canonical little-endian encodings of GF(l),
+ * the duration of the call; outputs are owned by the library until the matching *_free; no exceptions cross the ABI.
+ * Threads: creating, preparing and freeing a handle is single-threaded; once otti_prepare_device has run, instance, generator and
+ * witness handles are read-only and any number of threads may PROVE (otti_nizk_prove, otti_nizk_prove_resident) and verify with
+ * them concurrently — every calling thread gets its own device context (HIP stream, result mailbox, HBM workspace, helper threads),
+ * so their proofs overlap on the GPU; a single proof is a chain of sequential rounds that leaves most of the chip idle.  (Upstream's
+ * prover is likewise re-entrant: `NIZK::prove(&inst, .., &gens, ..)` borrows instance and generators immutably.)  All scalars are 32-byte canonical little-endian encodings of GF(l),
  * l = 2^252 + 27742317777372353535851937790883648493, unless a comment says "Montgomery" (the in-HBM layout: value*2^256 mod l).
  */
 #ifndef OTTI_SPARTAN_H
