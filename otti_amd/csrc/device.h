@@ -67,7 +67,8 @@ struct DevCtx {
     size_t msm_partial_cap = 0, points_cap = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     static DevCtx &get();                                     // the calling thread's context; throws Error(OTTI_ERR_NO_DEVICE) when no device is usable
-    DevCtx() {} ~DevCtx(); DevCtx(const DevCtx &) = delete; DevCtx &operator=(const DevCtx &) = delete;
+    DevCtx() {} DevCtx(const DevCtx &) = delete; DevCtx &operator=(const DevCtx &) = delete;
+    struct Scratch *scratch = nullptr;                        // the prover's HBM workspace (prover.cpp); travels with the context
     void sync();
     void wait_points(unsigned long long ticket);              // results of a dev_msm_rows launch: flag wait when fused, else stream sync
     void encode_pending();

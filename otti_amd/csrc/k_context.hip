@@ -26,33 +26,47 @@ void hip_check(hipError_t e, const char *what, const char *file, int line) {
 // One context per calling thread: its own stream, mailbox, result buffers.  Provers running on different threads of one process
 // therefore overlap on the device (one proof's latency-bound rounds leave most of the chip idle) while sharing the read-only HBM
 // objects — instance CSR, generator window table, resident witness.
+// Contexts live in a process-wide pool and are never destroyed: a thread leases one on its first call and hands it back when it
+// exits (no HIP call may run from a thread_local destructor — the runtime, or a profiler hooked into it, may already be gone).
+namespace {
+struct CtxPool { std::mutex mu; std::vector<DevCtx *> idle; bool probed = false, failed = false; std::string why; int dev = 0, num_cu = 0; };
+CtxPool &ctx_pool() { static CtxPool *p = new CtxPool(); return *p; }
+struct CtxLease {
+    DevCtx *c = nullptr;
+    ~CtxLease() { if (c) { CtxPool &P = ctx_pool(); std::lock_guard<std::mutex> lk(P.mu); P.idle.push_back(c); } }
+};
+}  // namespace
 DevCtx &DevCtx::get() {
-    static std::mutex mu; static bool probed = false, failed = false; static std::string why; static int dev = 0, num_cu = 0;
-    thread_local std::unique_ptr<DevCtx> ctx;
-    if (ctx) return *ctx;
+    thread_local CtxLease lease;
+    if (lease.c) return *lease.c;
+    CtxPool &P = ctx_pool();
     {
-        std::lock_guard<std::mutex> lk(mu);
-        if (failed) throw Error(OTTI_ERR_NO_DEVICE, why);
-        if (!probed) {
+        std::lock_guard<std::mutex> lk(P.mu);
+        if (P.failed) throw Error(OTTI_ERR_NO_DEVICE, P.why);
+        if (!P.probed) {
             try {
                 int count = 0;
                 hipError_t e = hipGetDeviceCount(&count);
                 if (e != hipSuccess || count == 0) throw Error(OTTI_ERR_NO_DEVICE, "no HIP device visible: the MI355X proving path has no CPU fallback");
                 const char *env = getenv("OTTI_DEVICE"); if (!env) env = getenv("LOCAL_RANK");
-                if (env) dev = atoi(env) % count;
-                OTTI_HIP(hipSetDevice(dev));
-                hipDeviceProp_t prop; OTTI_HIP(hipGetDeviceProperties(&prop, dev));
+                if (env) P.dev = atoi(env) % count;
+                OTTI_HIP(hipSetDevice(P.dev));
+                hipDeviceProp_t prop; OTTI_HIP(hipGetDeviceProperties(&prop, P.dev));
                 if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
-                    char buf[256]; snprintf(buf, sizeof buf, "device %d is %s; this library carries gfx950 code objects only", dev, prop.gcnArchName);
+                    char buf[256]; snprintf(buf, sizeof buf, "device %d is %s; this library carries gfx950 code objects only", P.dev, prop.gcnArchName);
                     throw Error(OTTI_ERR_NO_DEVICE, buf);
                 }
-                num_cu = prop.multiProcessorCount; probed = true;
-            } catch (const Error &e) { failed = true; why = e.what(); throw; }
+                P.num_cu = prop.multiProcessorCount; P.probed = true;
+            } catch (const Error &e) { P.failed = true; P.why = e.what(); throw; }
         }
     }
-    OTTI_HIP(hipSetDevice(dev));                               // the current device is a per-thread setting
+    OTTI_HIP(hipSetDevice(P.dev));                             // the current device is a per-thread setting
+    {
+        std::lock_guard<std::mutex> lk(P.mu);
+        if (!P.idle.empty()) { lease.c = P.idle.back(); P.idle.pop_back(); return *lease.c; }
+    }
     std::unique_ptr<DevCtx> c(new DevCtx());
-    c->device = dev; c->num_cu = num_cu;
+    c->device = P.dev; c->num_cu = P.num_cu;
     OTTI_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     c->partials.alloc((size_t)kMaxBlocks * 4);
     c->results.alloc(kResultSlots);
@@ -64,18 +78,8 @@ DevCtx &DevCtx::get() {
     c->d_counter.alloc(1);
     OTTI_HIP(hipMemset(c->d_counter.p, 0, sizeof(unsigned)));
     OTTI_HIP(hipEventCreate(&c->ev0)); OTTI_HIP(hipEventCreate(&c->ev1));
-    ctx = std::move(c);
-    return *ctx;
-}
-DevCtx::~DevCtx() {
-    if (stream) (void)hipStreamSynchronize(stream);
-    if (ev0) (void)hipEventDestroy(ev0);
-    if (ev1) (void)hipEventDestroy(ev1);
-    if (h_results) (void)hipHostFree(h_results);
-    if (h_flag) (void)hipHostFree(h_flag);
-    if (h_points) (void)hipHostFree(h_points);
-    if (h_pts) (void)hipHostFree(h_pts);
-    if (stream) (void)hipStreamDestroy(stream);
+    lease.c = c.release();
+    return *lease.c;
 }
 
 void DevCtx::ensure_points(size_t rows, size_t splits) {

@@ -116,7 +116,7 @@ void precompute_round_points_collect(DevCtx &c, const RoundPointsJob &job, Sumch
     pool.parallel(tasks.data(), nt);
 }
 // HBM working set of one proof; kept across proofs of the same shape (hipMalloc/hipFree of ~0.5 GB costs more than a sum-check)
-struct Scratch {
+struct ProofScratch {
     size_t N = 0, V = 0;
     DevBuf<Fr> T[4];          // eq(tau), Az, Bz, Cz  (N each)
     DevBuf<Fr> zw, ABC;       // phase-two working tables (2V each)
@@ -131,7 +131,10 @@ struct Scratch {
         N = n; V = v;
     }
 };
-Scratch &workspace() { thread_local Scratch s; return s; }      // one per prover thread, like the device context
+}  // namespace
+struct Scratch : ProofScratch {};                                // the type DevCtx::scratch points to (device.h)
+namespace {
+ProofScratch &workspace(DevCtx &c) { if (!c.scratch) c.scratch = new Scratch(); return *c.scratch; }   // one per context, kept across proofs
 inline CPoint point_at(const DevCtx &c, size_t i) { CPoint p; memcpy(p.b, c.h_points + 32 * i, 32); return p; }
 }  // namespace
 
@@ -187,7 +190,7 @@ std::vector<uint8_t> nizk_prove_resident(Instance &I, DeviceWitness &wit, Gens &
 
     double t_start = now_ms(), t0; ProveTimings T{};
     const size_t lgR = ilog2(Rsz);
-    Scratch &S = workspace();
+    ProofScratch &S = workspace(c);
     S.reserve(N, V, Lsz, Rsz, lgR);
     c.ensure_points(std::max(Lsz, 4 * (nrx + nry)), 2 * std::max<size_t>(1, Rsz / 256));   // every MSM result buffer of this proof, before the first launch
     const Fr *d_vars = wit.z.p, *my_rows = d_vars + rk * Ll * Rsz;         // this rank's block of witness-matrix rows
