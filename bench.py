@@ -163,13 +163,23 @@ def main():
     # timed region: HIP events only around the dominant class (two event records per launch would otherwise tax every round)
     oa.stats_enable(True, only=dom)
     # --concurrent B: B - 1 more prover threads (own device context each), warmed up and parked on a barrier
+    # the K steps x B proofs of the timed region are handed out from one counter, so no thread idles while another still has work
     gate, others, other_proofs, errors = threading.Barrier(conc), [], [], []
+    todo, todo_lock = [conc * args.steps], threading.Lock()
+
+    def take():
+        with todo_lock:
+            if todo[0] <= 0:
+                return False
+            todo[0] -= 1
+            return True
 
     def extra_prover():
         try:
             mine = [prove_once() for _ in range(max(1, args.warmup))]
             gate.wait()
-            mine += [prove_once() for _ in range(args.steps)]
+            while take():
+                mine.append(prove_once())
             other_proofs.extend(mine)
         except BaseException as e:                              # noqa: BLE001 - reported after the join
             errors.append(e)
@@ -180,10 +190,10 @@ def main():
     barrier()
     gate.wait()
     t0 = time.perf_counter()
-    stage_acc = {}
-    for _ in range(args.steps):
+    stage_acc, mine_n = {}, 0
+    while take():
         p = prove_once()                                       # returns after the library's stream has been synchronised
-        proofs.append(p)
+        proofs.append(p); mine_n += 1
         for k, v in p.stage_ms.items():
             stage_acc[k] = stage_acc.get(k, 0.0) + v
     for th in others:
@@ -314,7 +324,7 @@ def main():
                                   + ("" if conc == 1 else ", %d proofs in flight per GPU (one prover thread each)" % conc), "proofs_in_flight_per_gpu": conc, "msm_window_bits": cbits, "msm_table_GB": round(table_bytes / 1e9, 2)},
         "roofline": roofline,
         "cpu_baseline": cpu_baseline,
-        "stage_ms": {k: round(v / steps, 3) for k, v in stage_acc.items()},
+        "stage_ms": {k: round(v / max(1, mine_n), 3) for k, v in stage_acc.items()},
         "kernel_ms_per_step": {k: round(v[1], 3) for k, v in breakdown.items() if v[0]},
         "whole_proof_algorithmic_GBps": round(proof_gbps, 2), "whole_proof_hbm_frac": round(proof_gbps / (HBM_PEAK_GBPS * (world if shard else 1)), 6),
         "prepare_device_ms": round(1e3 * t_prepare, 1), "single_proof_ms": round(min(single_ms), 3), "witness_upload_ms": round(1e3 * t_upload, 2), "verify_ms": round(1e3 * t_verify, 2), "proof_bytes": len(proofs[-1].bytes), "proof_sha256": next(iter(digests)),
