@@ -1,8 +1,9 @@
 #!/bin/bash
-# How much aggregate throughput do B independent prover processes get out of ONE GPU?  usage: concurrent_probe.sh B [window]
+# How much aggregate throughput do B independent prover processes (each with T prover threads) get out of ONE GPU?
+# usage: concurrent_probe.sh B [window [T]]
 B=$1; W=${2:-12}
 for i in $(seq 1 $B); do
-  OTTI_MSM_WINDOW=$W python3 bench.py --no-cpu-baseline --steps 200 --warmup 5 > gpurun_out/cc_${B}_$i.json 2> gpurun_out/cc_${B}_$i.err &
+  OTTI_MSM_WINDOW=$W python3 bench.py --no-cpu-baseline --steps 100 --warmup 3 --concurrent ${3:-1} > gpurun_out/cc_${B}_$i.json 2> gpurun_out/cc_${B}_$i.err &
 done
 wait
 python3 - <<PY
