@@ -98,9 +98,9 @@ def main():
     lws = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
     cores_here = max(1, usable_cores() // lws)                  # host cores of this rank
     conc = 1 if shard else (args.concurrent if args.concurrent > 0 else max(1, min(6, cores_here // 2)))
+    # host threads per prover (itself + spinning helpers for the per-round sigma-protocol work): share this rank's cores fairly
+    os.environ.setdefault("OTTI_HOST_THREADS", str(max(1, min(4, cores_here // conc))))
     if conc > 1:
-        # host threads per prover (itself + spinning helpers for the per-round sigma-protocol work): share the cores fairly
-        os.environ.setdefault("OTTI_HOST_THREADS", str(max(1, min(4, cores_here // conc))))
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")         # one hardware queue per prover stream (HIP's default is 4)
     import threading
     import numpy as np

@@ -3,6 +3,9 @@
 // spinning host threads halves the per-round latency.  Workers spin only while a proof is in flight (Session), otherwise they sleep.
 #pragma once
 #include <sched.h>
+#include <stdio.h>
+#include <string.h>
+#include <algorithm>
 #include <stdlib.h>
 #include <atomic>
 #include <condition_variable>
@@ -65,6 +68,12 @@ private:
         unsigned hc = std::thread::hardware_concurrency();
         cpu_set_t set; CPU_ZERO(&set);
         if (sched_getaffinity(0, sizeof set, &set) == 0 && CPU_COUNT(&set) > 0) hc = (unsigned)CPU_COUNT(&set);
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {      // a container's CPU quota is usually far below its affinity mask
+            long long quota = 0, period = 0; char q[32] = {0};
+            if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0 && (quota = atoll(q)) > 0)
+                hc = std::min<unsigned>(hc, (unsigned)std::max<long long>(1, quota / period));
+            fclose(f);
+        }
         if (const char *e = getenv("LOCAL_WORLD_SIZE")) { int v = atoi(e); if (v > 1) hc = hc / (unsigned)v; }
         int n = hc >= 8 ? 3 : hc >= 4 ? 2 : hc >= 2 ? 1 : 0;
         if (const char *e = getenv("OTTI_HOST_THREADS")) { int v = atoi(e); if (v >= 1 && v <= 16) n = v - 1; }
