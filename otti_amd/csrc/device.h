@@ -10,6 +10,7 @@ namespace otti {
 
 #define OTTI_HIP(expr) ::otti::hip_check((expr), #expr, __FILE__, __LINE__)
 void hip_check(hipError_t e, const char *what, const char *file, int line);
+struct OutOfDeviceMemory : Error { using Error::Error; };   // hipErrorOutOfMemory: callers that can make do with less catch this one
 
 template <class T> struct DevBuf {
     T *p = nullptr; size_t n = 0;
@@ -19,7 +20,7 @@ template <class T> struct DevBuf {
     DevBuf(DevBuf &&o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
     DevBuf &operator=(DevBuf &&o) noexcept { if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; } return *this; }
     ~DevBuf() { release(); }
-    void alloc(size_t count) { release(); n = count; if (count) OTTI_HIP(hipMalloc((void **)&p, count * sizeof(T))); }
+    void alloc(size_t count) { release(); if (count) OTTI_HIP(hipMalloc((void **)&p, count * sizeof(T))); n = count; }
     void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
 };
 

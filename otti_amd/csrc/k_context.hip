@@ -19,6 +19,7 @@ namespace otti {
 void hip_check(hipError_t e, const char *what, const char *file, int line) {
     if (e == hipSuccess) return;
     char buf[512]; snprintf(buf, sizeof buf, "HIP error %d (%s) at %s:%d: %s", (int)e, hipGetErrorString(e), file, line, what);
+    if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); throw OutOfDeviceMemory(OTTI_ERR_NO_DEVICE, buf); }
     throw Error(OTTI_ERR_NO_DEVICE, buf);
 }
 

@@ -37,7 +37,15 @@ int device_window_bits(size_t nbases) {
 
 static std::mutex &device_objects_mu() { static std::mutex m; return m; }   // lazily built HBM objects are shared by all prover threads
 void ensure_instance_device(Instance &I) { std::lock_guard<std::mutex> lk(device_objects_mu()); if (!I.dev) I.dev = upload_instance(I); }
-void ensure_gens_device(Gens &g) { std::lock_guard<std::mutex> lk(device_objects_mu()); if (!g.dev) g.dev = build_device_gens(g, device_window_bits(g.R + 2)); }
+void ensure_gens_device(Gens &g) {
+    std::lock_guard<std::mutex> lk(device_objects_mu());
+    if (g.dev) return;
+    // the widest window the budget allows; if HBM is short right now (other tenants of the GPU, other generator sets), a narrower one
+    for (int c = device_window_bits(g.R + 2);; c -= 2) {
+        try { g.dev = build_device_gens(g, c); return; }
+        catch (const OutOfDeviceMemory &) { if (c - 2 < 8 || getenv("OTTI_MSM_WINDOW")) throw; }
+    }
+}
 void ensure_device_objects(Instance &I, Gens &g) { ensure_instance_device(I); ensure_gens_device(g); }
 
 void instance_evaluate_gpu(Instance &I, const std::vector<Fr> &rx, const std::vector<Fr> &ry, Fr out[3]) {

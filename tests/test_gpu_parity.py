@@ -162,6 +162,29 @@ def test_msm_rows_bulk_variants(rng, monkeypatch, lg, window, small_share):
     assert eq(got, orc.commit_rows(ogens, Z, L, R, blinds))
 
 
+def test_window_table_falls_back_when_hbm_is_short(rng):
+    """The widest window the budget allows needs a 51.6 GB table at 2^20; with most of the HBM taken the library must settle for a
+    narrower window instead of failing, and the commitments must not change."""
+    import torch
+    free, _ = torch.cuda.mem_get_info()
+    hog = torch.empty(max(0, free - (30 << 30)), dtype=torch.uint8, device="cuda")       # leave ~30 GB
+    try:
+        nv = 1 << 20
+        gens = oa.NIZKGens.new(nv, nv, 1)
+        gens_small, ogens = oa.NIZKGens.new(1 << 12, 1 << 12, 1), orc.OGens(nv, nv, 1)
+        oa.lib.otti_prepare_device(None, gens._h)
+        c, nbytes = gens.table_info
+        assert 8 <= c < 16 and nbytes < (30 << 30), (c, nbytes)
+        del gens_small
+        R = ogens.R; L = 8                                                               # a few rows are enough to pin the table contents
+        Z, blinds = orc.rand_fr(rng, L * R), orc.rand_fr(rng, L)
+        got, _ = K.msm_rows(gens, Z, L, R, blinds)
+        assert eq(got, orc.commit_rows(ogens, Z, L, R, blinds))
+    finally:
+        del hog
+        torch.cuda.empty_cache()
+
+
 # ------------------------------------------------------------------------------------------------ whole proof
 def _prove_both(n, ni, seed=b"\x2a" * 32, label=b"nizk_example"):
     r = oa.synth_r1cs(n, ni, 1)
