@@ -154,25 +154,28 @@ template <int K> static void finish_round(DevCtx &c, int nblocks, int slot) {
     { KScope ks(c, KC_REDUCE); hipLaunchKernelGGL(k_reduce_partials<K>, 1, kBlock, 0, c.stream, (const Fr *)c.partials.p, nblocks, c.results.p + slot); }
     dev_fetch(c, c.results.p + slot, slot, K);
 }
+// 242-VGPR kernels: two workgroups per CU are resident, so 512 workgroups already fill the chip; below ~2^21 elements a wider grid only
+// adds partials for the last workgroup to sum (measured: 2^20 evaluate 47 -> 32 us), above it the extra workgroups hide tail effects.
+static inline int sc_grid(size_t n) { return std::min(grid_for(n), n <= ((size_t)1 << 21) ? 512 : kMaxBlocks); }
 unsigned long long dev_sc_cubic_eval(DevCtx &c, const Fr *A, const Fr *B, const Fr *C, const Fr *D, size_t len, int slot) {
-    size_t half = len / 2; int g = grid_for(half); Mailbox mb = c.next_mailbox(slot);
+    size_t half = len / 2; int g = sc_grid(half); Mailbox mb = c.next_mailbox(slot);
     KScope ks(c, KC_SC_CUBIC); hipLaunchKernelGGL(k_sc_cubic_eval, g, kBlock, 0, c.stream, A, B, C, D, half, mb);
     return mb.seq;
 }
 unsigned long long dev_sc_cubic_fold_eval(DevCtx &c, Fr *A, Fr *B, Fr *C, Fr *D, size_t len, const Fr &r, int slot) {
     if (len < 4) throw Error(OTTI_ERR_INTERNAL, "fold_eval needs len >= 4");
-    size_t q = len / 4; int g = grid_for(q); Mailbox mb = c.next_mailbox(slot);
+    size_t q = len / 4; int g = sc_grid(q); Mailbox mb = c.next_mailbox(slot);
     KScope ks(c, KC_SC_CUBIC); hipLaunchKernelGGL(k_sc_cubic_fold_eval, g, kBlock, 0, c.stream, A, B, C, D, q, r, mb);
     return mb.seq;
 }
 unsigned long long dev_sc_quad_eval(DevCtx &c, const Fr *A, const Fr *B, size_t len, int slot) {
-    size_t half = len / 2; int g = grid_for(half); Mailbox mb = c.next_mailbox(slot);
+    size_t half = len / 2; int g = sc_grid(half); Mailbox mb = c.next_mailbox(slot);
     KScope ks(c, KC_SC_QUAD); hipLaunchKernelGGL(k_sc_quad_eval, g, kBlock, 0, c.stream, A, B, half, mb);
     return mb.seq;
 }
 unsigned long long dev_sc_quad_fold_eval(DevCtx &c, Fr *A, Fr *B, size_t len, const Fr &r, int slot) {
     if (len < 4) throw Error(OTTI_ERR_INTERNAL, "fold_eval needs len >= 4");
-    size_t q = len / 4; int g = grid_for(q); Mailbox mb = c.next_mailbox(slot);
+    size_t q = len / 4; int g = sc_grid(q); Mailbox mb = c.next_mailbox(slot);
     KScope ks(c, KC_SC_QUAD); hipLaunchKernelGGL(k_sc_quad_fold_eval, g, kBlock, 0, c.stream, A, B, q, r, mb);
     return mb.seq;
 }

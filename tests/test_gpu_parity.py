@@ -165,9 +165,19 @@ def test_msm_rows_bulk_variants(rng, monkeypatch, lg, window, small_share):
 def test_window_table_falls_back_when_hbm_is_short(rng):
     """The widest window the budget allows needs a 51.6 GB table at 2^20; with most of the HBM taken the library must settle for a
     narrower window instead of failing, and the commitments must not change."""
-    import torch
-    free, _ = torch.cuda.mem_get_info()
-    hog = torch.empty(max(0, free - (30 << 30)), dtype=torch.uint8, device="cuda")       # leave ~30 GB
+    import ctypes
+    oa.device_count()
+    # the HIP runtime the library itself is linked against (a second runtime in the process, e.g. torch's bundled one, may not be
+    # able to open the device once the first one has)
+    free, total, hip = ctypes.c_size_t(), ctypes.c_size_t(), None
+    for path in sorted({ln.split()[-1] for ln in open("/proc/self/maps") if "libamdhip64" in ln}):
+        cand = ctypes.CDLL(path)
+        if cand.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)) == 0:
+            hip = cand
+            break
+    assert hip is not None, "no loaded HIP runtime sees the device"
+    hog = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(hog), ctypes.c_size_t(max(1 << 20, free.value - (30 << 30)))) == 0      # leave ~30 GB
     try:
         nv = 1 << 20
         gens = oa.NIZKGens.new(nv, nv, 1)
@@ -181,8 +191,7 @@ def test_window_table_falls_back_when_hbm_is_short(rng):
         got, _ = K.msm_rows(gens, Z, L, R, blinds)
         assert eq(got, orc.commit_rows(ogens, Z, L, R, blinds))
     finally:
-        del hog
-        torch.cuda.empty_cache()
+        hip.hipFree(hog)
 
 
 # ------------------------------------------------------------------------------------------------ whole proof
