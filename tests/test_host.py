@@ -178,3 +178,59 @@ def test_product_never_links_or_imports_the_oracle():
             if f.endswith((".py", ".cpp", ".h", ".hip")):
                 src = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "liboracle" not in src and "import orc" not in src and "oracle/" not in src.replace("the CPU oracle", ""), f
+
+
+def test_zkif_reader_accepts_the_official_builders_layout(tmp_path, rng):
+    """Real zkInterface producers (flatc-generated builders) write buffers back to front: children before parents, vtable in front of
+    its table, shared vtables, several ConstraintSystem messages per file, values of any fixed width.  The product's own writer is
+    forward-laid-out, so the reader is checked here against an independent builder of the official layout (tests/fb_reverse_builder.py)."""
+    import fb_reverse_builder as fb
+    L = oa.L_ORDER
+    # a small hand-made circuit: x*y = z ; (x + 5)*1 = w ; z*w = out (public).  ids: 0 = one, 1 = out (instance), 2..5 witness
+    x, y = 3, 4
+    z, w = x * y, x + 5
+    cons = [([(2, 1)], [(3, 1)], [(4, 1)]), ([(2, 1), (0, 5)], [(0, 1)], [(5, 1)]), ([(4, 1)], [(5, 1)], [(1, 1)])]
+    c, i, wt = (str(tmp_path / n) for n in ("c.zkif", "c.inp.zkif", "c.wit.zkif"))
+    open(c, "wb").write(fb.circuit_header([1], None, 6, L - 1) + fb.constraint_system(cons[:2], width=32) + fb.constraint_system(cons[2:], width=4))
+    open(i, "wb").write(fb.circuit_header([1], [z * w], 6, L - 1))
+    open(wt, "wb").write(fb.witness([2, 3, 4, 5], [x, y, z, w], width=8))
+    r = oa.zkif_load(c, i, wt)
+    assert (r["num_cons"], r["num_vars"], r["num_inputs"]) == (3, 4, 1)
+    assert list(r["A"]["row"]) == [0, 1, 1, 2] and list(r["A"]["col"]) == [0, 0, 4, 2]          # one -> column num_vars, out -> num_vars + 1
+    assert [int.from_bytes(v.tobytes(), "little") for v in r["A"]["val"]] == [1, 1, 5, 1]
+    assert list(r["C"]["col"]) == [2, 3, 5]
+    inst = oa.Instance.new(r["num_cons"], r["num_vars"], r["num_inputs"], r["A"], r["B"], r["C"])
+    assert inst.is_sat(oa.VarsAssignment.new(r["vars"]), oa.InputsAssignment.new(r["inputs"]))
+    oi, og = orc.OInstance(3, 4, 1, r["A"], r["B"], r["C"]), orc.OGens(3, 4, 1)
+    proof, _ = orc.nizk_prove(oi, r["vars"], r["inputs"], og)
+    oa.NIZK(proof).verify(inst, oa.InputsAssignment.new(r["inputs"]), oa.NIZKGens.new(3, 4, 1))
+    # a wrong public value must not satisfy
+    open(i, "wb").write(fb.circuit_header([1], [z * w + 1], 6, L - 1))
+    r2 = oa.zkif_load(c, i, wt)
+    assert not inst.is_sat(oa.VarsAssignment.new(r2["vars"]), oa.InputsAssignment.new(r2["inputs"]))
+
+    # the same random instance through both layouts must load identically
+    s = oa.synth_r1cs_compiler_like(200, 3, 9)
+    nv, ni = s["num_vars"], s["num_inputs"]
+
+    def vid(col):                                   # product column -> zkInterface variable id (instance ids first, as the writer does)
+        return 1 + ni + col if col < nv else (0 if col == nv else col - nv)
+
+    rows = [([], [], []) for _ in range(s["num_cons"])]
+    for k, name in enumerate("ABC"):
+        for e in s[name]:
+            rows[int(e["row"])][k].append((vid(int(e["col"])), int.from_bytes(e["val"].tobytes(), "little")))
+    c2, i2, w2 = (str(tmp_path / n) for n in ("r.zkif", "r.inp.zkif", "r.wit.zkif"))
+    half = len(rows) // 2
+    inst_ids = list(range(1, ni + 1))
+    open(c2, "wb").write(fb.circuit_header(inst_ids, None, 1 + ni + nv, L - 1) + fb.constraint_system(rows[:half]) + fb.constraint_system(rows[half:]))
+    open(i2, "wb").write(fb.circuit_header(inst_ids, [int.from_bytes(v.tobytes(), "little") for v in s["inputs"]], 1 + ni + nv, L - 1))
+    open(w2, "wb").write(fb.witness(list(range(1 + ni, 1 + ni + nv)), [int.from_bytes(v.tobytes(), "little") for v in s["vars"]]))
+    got = oa.zkif_load(c2, i2, w2)
+    f1, f2, f3 = (str(tmp_path / n) for n in ("f.zkif", "f.inp.zkif", "f.wit.zkif"))
+    oa.zkif_write(s, f1, f2, f3)
+    want = oa.zkif_load(f1, f2, f3)
+    for k in ("num_cons", "num_vars", "num_inputs"):
+        assert got[k] == want[k]
+    for k in ("A", "B", "C", "vars", "inputs"):
+        assert np.array_equal(got[k], want[k]), k
