@@ -234,3 +234,14 @@ def test_zkif_reader_accepts_the_official_builders_layout(tmp_path, rng):
         assert got[k] == want[k]
     for k in ("A", "B", "C", "vars", "inputs"):
         assert np.array_equal(got[k], want[k]), k
+
+
+def test_untrusted_input_parsers_survive_mutation_fuzzing(tmp_path):
+    """.zkif files and proof bytes come from outside: every mutant must load/verify or be refused with an error code (child
+    process: a crash or a hang fails the test)."""
+    import subprocess
+    import sys
+    res = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "fuzz_worker.py"), str(tmp_path), "1500"],
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    assert "refused" in res.stdout and "rejected" in res.stdout
