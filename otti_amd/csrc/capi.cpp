@@ -44,7 +44,11 @@ size_t otti_last_error(char *buf, size_t cap) {
 }
 void otti_buf_free(void *p) { free(p); }
 
-int32_t otti_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+int32_t otti_device_count(void) {
+    // asked once: on a host without a GPU every hipGetDeviceCount call re-probes the driver (~0.2 s of system time)
+    static const int count = [] { int n = 0; return hipGetDeviceCount(&n) == hipSuccess ? n : 0; }();
+    return count;
+}
 
 int32_t otti_instance_new(uint64_t nc, uint64_t nv, uint64_t ni, const otti_entry *A, size_t nA, const otti_entry *B, size_t nB,
                           const otti_entry *C, size_t nC, otti_instance **out) {
@@ -183,7 +187,7 @@ int32_t otti_nizk_verify(const otti_instance *inst, const uint8_t *inputs32, siz
         // The verifier is host code (as in the reference); only its O(nnz + N + V) step — evaluating A, B, C at (rx, ry) — goes to the
         // device when one is present.  (Verification is not the proving hot path: without a device it simply stays on the host.)
         Fr evals[3]; const Fr *ev = nullptr;
-        if (otti_device_count() > 0 && inst->I->num_cons >= 4096) {
+        if (inst->I->num_cons >= 4096 && otti_device_count() > 0) {
             try {
                 NizkProof P = NizkProof::parse(proof, proof_len);
                 instance_evaluate_gpu(*const_cast<Instance *>(inst->I.get()), P.rx, P.ry, evals); ev = evals;

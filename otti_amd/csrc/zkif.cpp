@@ -266,8 +266,9 @@ otti_r1cs *zkif_load_impl(const char *circuit_path, const char *inputs_path, con
     Messages m;
     FileView circuit(circuit_path);
     parse_headers(circuit, m);
-    if (inputs_path) { FileView f(inputs_path); parse_headers(f, m); }
-    if (witness_path) { FileView f(witness_path); parse_headers(f, m); }
+    size_t file_bytes = circuit.size();
+    if (inputs_path) { FileView f(inputs_path); parse_headers(f, m); file_bytes += f.size(); }
+    if (witness_path) { FileView f(witness_path); parse_headers(f, m); file_bytes += f.size(); }
     if (!m.have_header) throw Error(OTTI_ERR_IO, "zkif: no CircuitHeader message");
     if (!m.field_maximum.empty()) {
         static const uint8_t lm1[32] = {0xec, 0xd3, 0xf5, 0x5c, 0x1a, 0x63, 0x12, 0x58, 0xd6, 0x9c, 0xf7, 0xa2, 0xde, 0xf9, 0xde, 0x14,
@@ -280,7 +281,11 @@ otti_r1cs *zkif_load_impl(const char *circuit_path, const char *inputs_path, con
     uint64_t free_id = std::max<uint64_t>(m.free_variable_id, 1);
     for (auto id : m.witness.ids) free_id = std::max(free_id, id + 1);
     for (auto id : m.instance.ids) free_id = std::max(free_id, id + 1);
+    // Untrusted header: every variable id a file declares occupies at least eight bytes somewhere in the files (its assignment, or its
+    // uses in constraints), so a free_variable_id beyond that is either garbage or an attempt to make the loader allocate gigabytes.
+    if (free_id > file_bytes / 8 + 2) throw Error(OTTI_ERR_IO, "zkif: free_variable_id is larger than the files can account for");
     IdMap map; map.build(m.instance.ids, free_id);
+    if (m.have_witness && m.witness.ids.size() != map.num_vars) throw Error(OTTI_ERR_IO, "zkif: witness does not assign every variable exactly once");
     // pass 2: constraints of the circuit file, message by message
     std::vector<otti_entry> M[3]; uint64_t row = 0;
     for_each_message(circuit, [&](uint8_t type, const Table &msg, const Buf &b) {
@@ -291,7 +296,7 @@ otti_r1cs *zkif_load_impl(const char *circuit_path, const char *inputs_path, con
             for (int t = 0; t < 3; t++) append_lc(M[t], bc.sub(t), row, map);
         }
     });
-    std::vector<uint8_t> vars(32 * map.num_vars, 0), inputs(32 * map.num_inputs, 0);
+    std::vector<uint8_t> vars(m.have_witness ? 32 * map.num_vars : 0, 0), inputs(32 * map.num_inputs, 0);   // no witness file (verifier): no assignment
     if (m.instance.has_vals) for (size_t i = 0; i < map.num_inputs; i++) memcpy(&inputs[32 * i], m.instance.vals[i].data(), 32);
     else if (map.num_inputs && inputs_path) throw Error(OTTI_ERR_IO, "zkif: inputs file carries no instance values");
     if (m.have_witness) {

@@ -241,7 +241,7 @@ def test_untrusted_input_parsers_survive_mutation_fuzzing(tmp_path):
     process: a crash or a hang fails the test)."""
     import subprocess
     import sys
-    res = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "fuzz_worker.py"), str(tmp_path), "500"],
+    res = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "fuzz_worker.py"), str(tmp_path), "1500"],
                          capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     assert "refused" in res.stdout and "rejected" in res.stdout
