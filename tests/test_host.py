@@ -245,3 +245,22 @@ def test_untrusted_input_parsers_survive_mutation_fuzzing(tmp_path):
                          capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     assert "refused" in res.stdout and "rejected" in res.stdout
+
+
+def test_host_parsers_under_address_and_ub_sanitizers(tmp_path):
+    """The host sources (zkif reader, proof parser, verifier, group/field code) rebuilt for the CPU with -fsanitize=address,undefined
+    and driven with mutated files and proofs (tests/san/): any out-of-bounds access, overflow or misaligned load aborts the run."""
+    import subprocess
+    san = os.path.join(os.path.dirname(os.path.abspath(__file__)), "san")
+    build = subprocess.run(["make", "-C", san, "-s"], capture_output=True, text=True)
+    assert build.returncode == 0, build.stderr[-3000:]
+    s = oa.synth_r1cs_compiler_like(48, 3, 4)
+    paths = [str(tmp_path / n) for n in ("s.zkif", "s.inp.zkif", "s.wit.zkif")]
+    oa.zkif_write(s, *paths)
+    oi, og = orc.OInstance(s["num_cons"], s["num_vars"], s["num_inputs"], s["A"], s["B"], s["C"]), orc.OGens(s["num_cons"], s["num_vars"], s["num_inputs"])
+    proof, _ = orc.nizk_prove(oi, s["vars"], s["inputs"], og, b"san", b"\x05" * 32)
+    open(tmp_path / "proof.bin", "wb").write(proof)
+    res = subprocess.run([os.path.join(san, "_build", "san_harness"), *paths, str(tmp_path / "proof.bin"), "san", str(tmp_path), "600"],
+                         capture_output=True, text=True, timeout=900, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0"))
+    assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-3000:]
+    assert "sanitized run" in res.stdout
