@@ -82,6 +82,15 @@ def main():
     if rehearse:
         local_rank = 0
     os.environ.setdefault("OTTI_DEVICE", str(local_rank))
+    shard = bool(args.shard and world > 1)
+    # how many proofs this rank keeps in flight, and the environment that goes with it — before anything initialises the HIP runtime
+    lws = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
+    cores_here = max(1, usable_cores() // lws)                  # host cores of this rank
+    conc = 1 if shard else (args.concurrent if args.concurrent > 0 else max(1, min(6, cores_here // 2)))
+    # host threads per prover (itself + spinning helpers for the per-round sigma-protocol work): share this rank's cores fairly
+    os.environ.setdefault("OTTI_HOST_THREADS", str(max(1, min(4, cores_here // conc))))
+    if conc > 1:
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")         # one hardware queue per prover stream (HIP's default is 4)
     dist = None
     if world > 1 or os.environ.get("OTTI_FORCE_DIST"):      # OTTI_FORCE_DIST: exercise the RCCL path on a one-GPU box
         import torch
@@ -93,15 +102,6 @@ def main():
         else:
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     xdev = "cpu" if rehearse else "cuda"                     # where tensors handed to torch.distributed live
-    shard = bool(args.shard and world > 1)
-
-    lws = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
-    cores_here = max(1, usable_cores() // lws)                  # host cores of this rank
-    conc = 1 if shard else (args.concurrent if args.concurrent > 0 else max(1, min(6, cores_here // 2)))
-    # host threads per prover (itself + spinning helpers for the per-round sigma-protocol work): share this rank's cores fairly
-    os.environ.setdefault("OTTI_HOST_THREADS", str(max(1, min(4, cores_here // conc))))
-    if conc > 1:
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")         # one hardware queue per prover stream (HIP's default is 4)
     import threading
     import numpy as np
     import otti_amd as oa
