@@ -131,6 +131,11 @@ void dev_eq_evals(DevCtx &c, const Fr *r_host, size_t ell, Fr *out, Fr *scratch 
 // each returns a ticket: c.wait_ticket(ticket) returns once h_results[slot..] hold that launch's sums (no stream synchronise)
 unsigned long long dev_sc_cubic_eval(DevCtx &c, const Fr *A, const Fr *B, const Fr *C, const Fr *D, size_t len, int slot);
 unsigned long long dev_sc_cubic_fold_eval(DevCtx &c, Fr *A, Fr *B, Fr *C, Fr *D, size_t len, const Fr &r, int slot);   // len >= 4; folds to len/2, sums over the folded tables
+// phase one with the eq table factored out (see k_sumcheck.hip): E[i] = hi ? hi[i >> lo_bits] * lo[i & (2^lo_bits - 1)] : lo[i]
+struct EqSrc { const Fr *hi, *lo; int lo_bits; };
+void dev_eq_pyramid(DevCtx &c, const Fr *r_host, size_t n, Fr *out /* 2^(n+1) - 1 elements: level k at out + 2^k - 1 */);
+unsigned long long dev_sc_cubic3_eval(DevCtx &c, const Fr *B, const Fr *C, const Fr *D, size_t len, const EqSrc &E, int slot);
+unsigned long long dev_sc_cubic3_fold_eval(DevCtx &c, Fr *B, Fr *C, Fr *D, size_t len, const Fr &r, const EqSrc &E, int slot);
 unsigned long long dev_sc_quad_eval(DevCtx &c, const Fr *A, const Fr *B, size_t len, int slot);
 unsigned long long dev_sc_quad_fold_eval(DevCtx &c, Fr *A, Fr *B, size_t len, const Fr &r, int slot);
 void dev_fold_top(DevCtx &c, Fr *Z, size_t len, const Fr &r);

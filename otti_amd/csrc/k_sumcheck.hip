@@ -118,6 +118,63 @@ __global__ __launch_bounds__(kBlock) void k_sc_cubic_fold_eval(Fr *A, Fr *B, Fr 
     }
     finish_in_kernel<3>(acc, mb);
 }
+// ---- phase one without the eq table.  eq(tau, .) is a tensor product, so after j rounds the fourth table of the cubic sum-check is
+// D_j[(b, i)] = c_j * (b ? tau_j : 1 - tau_j) * E_j[i]  with  E_j = eq(tau_{j+1..}, .)  and  c_j = prod_{k<j} eq(tau_k, r_k):
+// it never has to be stored, folded or streamed.  The round sums become  e_t = c_j * ((1 - tau_j) + t (2 tau_j - 1)) * S_t  with
+// S_t = sum_i E_j[i] * (A_t[i] B_t[i] - C_t[i]); the kernels below return S_t (three tables instead of four: a quarter less HBM
+// traffic and register pressure), the host applies the two scalar factors.  E_j[i] itself is hi[i >> lo_bits] * lo[i & mask] from the
+// two small "pyramids" of k_eq_pyramid (L2-resident), or lo[i] once at most lo_bits variables are left.
+__device__ __forceinline__ Fr eq_at(const EqSrc &e, size_t i) {
+    if (!e.hi) return e.lo[i];
+    return fr_mul(e.hi[i >> e.lo_bits], e.lo[i & (((size_t)1 << e.lo_bits) - 1)]);
+}
+__device__ __forceinline__ void cubic3_accum(Fr (&acc)[3], const Fr &e, const Pair &b, const Pair &c, const Pair &d) {
+    acc[0] = fr_add(acc[0], fr_mul(e, fr_sub(fr_mul(b.lo, c.lo), d.lo)));
+    Fr db = fr_sub(b.hi, b.lo), dc = fr_sub(c.hi, c.lo), dd = fr_sub(d.hi, d.lo);
+    Fr b2 = fr_add(b.hi, db), c2 = fr_add(c.hi, dc), d2 = fr_add(d.hi, dd);
+    acc[1] = fr_add(acc[1], fr_mul(e, fr_sub(fr_mul(b2, c2), d2)));
+    Fr b3 = fr_add(b2, db), c3 = fr_add(c2, dc), d3 = fr_add(d2, dd);
+    acc[2] = fr_add(acc[2], fr_mul(e, fr_sub(fr_mul(b3, c3), d3)));
+}
+__global__ __launch_bounds__(kBlock, 4) void k_sc_cubic3_eval(const Fr *B, const Fr *C, const Fr *D, size_t half, EqSrc E, Mailbox mb) {
+    Fr acc[3] = {fr_zero(), fr_zero(), fr_zero()};
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x) {
+        Pair b, c, d;
+        b.lo = B[i]; b.hi = B[i + half]; c.lo = C[i]; c.hi = C[i + half]; d.lo = D[i]; d.hi = D[i + half];
+        Fr e = eq_at(E, i);
+        __builtin_amdgcn_sched_barrier(0);
+        cubic3_accum(acc, e, b, c, d);
+    }
+    finish_in_kernel<3>(acc, mb);
+}
+__global__ __launch_bounds__(kBlock) void k_sc_cubic3_fold_eval(Fr *B, Fr *C, Fr *D, size_t q, Fr r, EqSrc E, Mailbox mb) {
+    Fr acc[3] = {fr_zero(), fr_zero(), fr_zero()};
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < q; i += (size_t)gridDim.x * blockDim.x) {
+        Fr b0 = B[i], b1 = B[i + q], b2 = B[i + 2 * q], b3 = B[i + 3 * q];
+        Fr c0 = C[i], c1 = C[i + q], c2 = C[i + 2 * q], c3 = C[i + 3 * q];
+        __builtin_amdgcn_sched_barrier(0);
+        Pair b = fold_regs(b0, b1, b2, b3, r); B[i] = b.lo; B[i + q] = b.hi;
+        Fr d0 = D[i], d1 = D[i + q], d2 = D[i + 2 * q], d3 = D[i + 3 * q];
+        Fr e = eq_at(E, i);
+        __builtin_amdgcn_sched_barrier(0);
+        Pair c = fold_regs(c0, c1, c2, c3, r); C[i] = c.lo; C[i + q] = c.hi;
+        Pair d = fold_regs(d0, d1, d2, d3, r); D[i] = d.lo; D[i + q] = d.hi;
+        cubic3_accum(acc, e, b, c, d);
+    }
+    finish_in_kernel<3>(acc, mb);
+}
+// "Pyramid" of eq tables over the LAST k of n variables, k = 0..n: level k (2^k entries) sits at out + 2^k - 1.  Level k prepends
+// variable v = r[n-k] as the new most significant index bit: new[i] = old[i] * (1 - v), new[2^(k-1) + i] = old[i] * v.
+__global__ __launch_bounds__(1024) void k_eq_pyramid(FrArgs r, int n, Fr *out) {
+    if (threadIdx.x == 0) out[0] = fr_one();
+    __syncthreads();
+    for (int k = 1; k <= n; k++) {
+        const Fr v = r.v[n - k]; const size_t half = (size_t)1 << (k - 1);
+        const Fr *old = out + (half - 1); Fr *nw = out + (2 * half - 1);
+        for (size_t i = threadIdx.x; i < half; i += blockDim.x) { Fr o = old[i], hi = fr_mul(o, v); nw[half + i] = hi; nw[i] = fr_sub(o, hi); }
+        __syncthreads();
+    }
+}
 __global__ __launch_bounds__(kBlock) void k_sc_quad_eval(const Fr *A, const Fr *B, size_t half, Mailbox mb) {
     Fr acc[2] = {fr_zero(), fr_zero()};
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x) {
@@ -166,6 +223,23 @@ unsigned long long dev_sc_cubic_fold_eval(DevCtx &c, Fr *A, Fr *B, Fr *C, Fr *D,
     if (len < 4) throw Error(OTTI_ERR_INTERNAL, "fold_eval needs len >= 4");
     size_t q = len / 4; int g = sc_grid(q); Mailbox mb = c.next_mailbox(slot);
     KScope ks(c, KC_SC_CUBIC); hipLaunchKernelGGL(k_sc_cubic_fold_eval, g, kBlock, 0, c.stream, A, B, C, D, q, r, mb);
+    return mb.seq;
+}
+void dev_eq_pyramid(DevCtx &c, const Fr *r_host, size_t n, Fr *out) {
+    if (n > 13) throw Error(OTTI_ERR_BAD_ARG, "eq pyramid over more than 13 variables");
+    FrArgs a; for (size_t i = 0; i < 13; i++) a.v[i] = i < n ? r_host[i] : fr_zero();
+    KScope ks(c, KC_EQ);
+    hipLaunchKernelGGL(k_eq_pyramid, 1, 1024, 0, c.stream, a, (int)n, out);
+}
+unsigned long long dev_sc_cubic3_eval(DevCtx &c, const Fr *B, const Fr *C, const Fr *D, size_t len, const EqSrc &E, int slot) {
+    size_t half = len / 2; int g = sc_grid(half); Mailbox mb = c.next_mailbox(slot);
+    KScope ks(c, KC_SC_CUBIC); hipLaunchKernelGGL(k_sc_cubic3_eval, g, kBlock, 0, c.stream, B, C, D, half, E, mb);
+    return mb.seq;
+}
+unsigned long long dev_sc_cubic3_fold_eval(DevCtx &c, Fr *B, Fr *C, Fr *D, size_t len, const Fr &r, const EqSrc &E, int slot) {
+    if (len < 4) throw Error(OTTI_ERR_INTERNAL, "fold_eval needs len >= 4");
+    size_t q = len / 4; int g = sc_grid(q); Mailbox mb = c.next_mailbox(slot);
+    KScope ks(c, KC_SC_CUBIC); hipLaunchKernelGGL(k_sc_cubic3_fold_eval, g, kBlock, 0, c.stream, B, C, D, q, r, E, mb);
     return mb.seq;
 }
 unsigned long long dev_sc_quad_eval(DevCtx &c, const Fr *A, const Fr *B, size_t len, int slot) {

@@ -129,11 +129,12 @@ struct ProofScratch {
     DevBuf<Fr> T[4];          // eq(tau), Az, Bz, Cz  (N each)
     DevBuf<Fr> zw, ABC;       // phase-two working tables (2V each)
     DevBuf<Fr> eqs;           // eq-table scratch (3 * 4096)
+    DevBuf<Fr> pyr;           // the two eq pyramids of phase one: lo at [0, 8191), hi at [8192, 8192 + 16383)
     DevBuf<Fr> blinds, Lv, Rv, LZ, a, s, b2, s2, rows, extras, bound_scratch, pre;
     void reserve(size_t n, size_t v, size_t Lsz, size_t Rsz, size_t lgR) {
         if (n == N && v == V) return;
         for (auto &t : T) t.alloc(n);
-        zw.alloc(2 * v); ABC.alloc(2 * v); eqs.alloc(3 * 4096);
+        zw.alloc(2 * v); ABC.alloc(2 * v); eqs.alloc(3 * 4096); pyr.alloc(8192 + 16384);
         blinds.alloc(Lsz); Lv.alloc(Lsz); Rv.alloc(Rsz); LZ.alloc(Rsz); a.alloc(Rsz); s.alloc(Rsz); b2.alloc(Rsz); s2.alloc(Rsz); rows.alloc(2 * Rsz);
         extras.alloc(4 * (lgR + 1)); bound_scratch.alloc(64 * Rsz);
         N = n; V = v;
@@ -256,16 +257,27 @@ std::vector<uint8_t> nizk_prove_resident(Instance &I, DeviceWitness &wit, Gens &
     // ---- tau, eq(tau), Az/Bz/Cz (K2, K1)
     t0 = now_ms();
     std::vector<Fr> tau = tr.challenge_vector("challenge_tau", nrx);
-    // local eq table: eq(tau, i'*G + rk) = eq(tau_hi, i') * eq(tau_lo, rk)  (index bits are MSB-first over tau)
-    dev_eq_evals(c, tau.data(), nrx - lgG, S.T[0].p, S.eqs.p);
-    if (sh) dev_scale(c, S.T[0].p, eq_evals_host(tau.data() + (nrx - lgG), lgG)[rk], S.T[0].p, Nl);
+    // eq(tau, .) is never materialised (k_sumcheck.hip, "phase one without the eq table"): two small pyramids of eq tables over the
+    // local variables tau[0 .. s_loc) — the last n_lo of them, and the n_hi before those — give every round's E_j = eq(tau_{j+1..}, .).
+    // Sharded: eq(tau, i'*G + rk) = eq(tau[0..s_loc), i') * eq(tau[s_loc..), rk)  (index bits are MSB-first), the second factor a scalar.
+    const size_t s_loc = nrx - lgG, n_lo = std::min<size_t>(s_loc, 12), n_hi = s_loc - n_lo;
+    Fr *pyr_lo = S.pyr.p, *pyr_hi = S.pyr.p + 8192;
+    dev_eq_pyramid(c, tau.data() + n_hi, n_lo, pyr_lo);
+    if (n_hi) dev_eq_pyramid(c, tau.data(), n_hi, pyr_hi);
+    auto eq_src = [&](size_t m) {                                     // E = eq over the last m local variables
+        EqSrc e;
+        if (m <= n_lo) { e.hi = nullptr; e.lo = pyr_lo + (((size_t)1 << m) - 1); e.lo_bits = 0; }
+        else { e.hi = pyr_hi + (((size_t)1 << (m - n_lo)) - 1); e.lo = pyr_lo + (((size_t)1 << n_lo) - 1); e.lo_bits = (int)n_lo; }
+        return e;
+    };
+    const std::vector<Fr> eq_ranks = eq_evals_host(tau.data() + s_loc, lgG);   // eq(tau[s_loc..), rank) — {1} on one GPU
     c.sync();                                                         // multiply_vec was queued during polycommit; this stage is what is left of it
     T.ms[1] = now_ms() - t0;
 
     // ---- sum-check phase one (K3 + K4): comb = eq * (Az * Bz - Cz), claim 0
     t0 = now_ms();
     P.rx.resize(nrx);
-    Fr blind_claim_postsc1;
+    Fr blind_claim_postsc1, cj = fr_one();                            // cj = prod_{k<j} eq(tau_k, r_k): the eq table's scalar part so far
     {
         SumcheckState st;
         sumcheck_draw_tape(st, tape, nrx, 4);
@@ -275,7 +287,8 @@ std::vector<uint8_t> nizk_prove_resident(Instance &I, DeviceWitness &wit, Gens &
         { Term t2[2] = {{g.sc_1.G[0], fr_zero()}, {g.sc_1.h, fr_zero()}}; g.commit_terms_c(st.comm_claim.b, t2, 2); }
         P.sc1.comm_polys.resize(nrx); P.sc1.comm_evals.resize(nrx); P.sc1.proofs.resize(nrx);
         std::vector<Fr> tail1[4];
-        unsigned long long ticket = dev_sc_cubic_eval(c, S.T[0].p, S.T[1].p, S.T[2].p, S.T[3].p, Nl, 0);
+        unsigned long long ticket = dev_sc_cubic3_eval(c, S.T[1].p, S.T[2].p, S.T[3].p, Nl, eq_src(s_loc - 1), 0);
+        const Fr one = fr_one();
         double tw = 0, tb = 0, tl = 0, tf = 0, ta;
         const size_t ndev = nrx - lgG;                                           // rounds played on the device tables
         for (size_t j = 0; j < nrx; j++) {
@@ -283,8 +296,11 @@ std::vector<uint8_t> nizk_prove_resident(Instance &I, DeviceWitness &wit, Gens &
             ta = now_ms();
             if (j < ndev) {
                 c.wait_ticket(ticket);
-                e[0] = c.h_results[0]; e[1] = c.h_results[1]; e[2] = c.h_results[2];
-                if (sh) sh->allreduce_fr(e, 3);                                  // per-round exchange: 96 bytes per rank
+                e[0] = c.h_results[0]; e[1] = c.h_results[1]; e[2] = c.h_results[2];       // S_t = sum_i E_j[i] (Az_t Bz_t - Cz_t)[i], t = 0, 2, 3
+                if (sh) { for (auto &x : e) x = fr_mul(x, eq_ranks[rk]); sh->allreduce_fr(e, 3); }   // per-round exchange: 96 bytes per rank
+                // e_t = c_j * w_t * S_t with w_t = (1 - tau_j) + t (2 tau_j - 1): the eq factor of the variable bound in this round
+                const Fr w0 = fr_sub(one, tau[j]), dw = fr_sub(fr_add(tau[j], tau[j]), one), w2 = fr_add(w0, fr_add(dw, dw)), w3 = fr_add(w2, dw);
+                e[0] = fr_mul(fr_mul(cj, w0), e[0]); e[1] = fr_mul(fr_mul(cj, w2), e[1]); e[2] = fr_mul(fr_mul(cj, w3), e[2]);
             } else host_cubic_evals(tail1, e);
             tw += now_ms() - ta;
             Fr ev[4] = {e[0], fr_sub(st.claim, e[0]), e[1], e[2]};
@@ -294,31 +310,34 @@ std::vector<uint8_t> nizk_prove_resident(Instance &I, DeviceWitness &wit, Gens &
             P.rx[j] = p1.r_j;
             if (j < ndev) {
                 size_t len = Nl >> j;
-                if (len >= 4) ticket = dev_sc_cubic_fold_eval(c, S.T[0].p, S.T[1].p, S.T[2].p, S.T[3].p, len, p1.r_j, 0);
-                else for (auto &t : S.T) dev_fold_top(c, t.p, len, p1.r_j);
+                if (len >= 4) ticket = dev_sc_cubic3_fold_eval(c, S.T[1].p, S.T[2].p, S.T[3].p, len, p1.r_j, eq_src(s_loc - j - 2), 0);
+                else for (int k = 1; k < 4; k++) dev_fold_top(c, S.T[k].p, len, p1.r_j);
+                // eq(tau_j, r_j) = tau_j r_j + (1 - tau_j)(1 - r_j)
+                cj = fr_mul(cj, fr_add(fr_mul(tau[j], p1.r_j), fr_mul(fr_sub(one, tau[j]), fr_sub(one, p1.r_j))));
             } else for (auto &t : tail1) host_fold_top(t, p1.r_j);
             tl += now_ms() - ta; ta = now_ms();
             sumcheck_round_finish(P.sc1, j, p1, st, g, g.sc_4, tr);             // overlaps the device fold
             tf += now_ms() - ta;
             if (sh && j + 1 == ndev) {                                           // one element per table and rank is left: collect them
-                for (int k = 0; k < 4; k++) dev_fetch(c, S.T[k].p, 8 + k, 1);
+                for (int k = 1; k < 4; k++) dev_fetch(c, S.T[k].p, 8 + k, 1);
                 c.sync();
-                std::vector<Fr> all(4 * G);
-                sh->allgather(&c.h_results[8], 4 * sizeof(Fr), all.data());
-                for (int k = 0; k < 4; k++) { tail1[k].resize(G); for (size_t r = 0; r < G; r++) tail1[k][r] = all[4 * r + k]; }
+                std::vector<Fr> all(3 * G);
+                sh->allgather(&c.h_results[9], 3 * sizeof(Fr), all.data());
+                for (int k = 1; k < 4; k++) { tail1[k].resize(G); for (size_t r = 0; r < G; r++) tail1[k][r] = all[3 * r + (k - 1)]; }
+                tail1[0].resize(G); for (size_t r = 0; r < G; r++) tail1[0][r] = fr_mul(cj, eq_ranks[r]);   // the eq table's G remaining entries
             }
         }
         if (getenv("OTTI_TRACE")) fprintf(stderr, "[otti] phase1 rounds=%zu wait %.3f begin %.3f launch %.3f finish %.3f ms\n", nrx, tw, tb, tl, tf);
         blind_claim_postsc1 = st.blinds_evals[nrx - 1];
         if (sh) for (int k = 0; k < 4; k++) c.h_results[8 + k] = tail1[k][0];
     }
-    if (!sh) { for (int k = 0; k < 4; k++) dev_fetch(c, S.T[k].p, 8 + k, 1); OTTI_HIP(hipEventRecord(c.ev0, c.stream)); }
+    if (!sh) { for (int k = 1; k < 4; k++) dev_fetch(c, S.T[k].p, 8 + k, 1); OTTI_HIP(hipEventRecord(c.ev0, c.stream)); }
     // what phase two needs from rx alone — eq(rx, .) (the full table on every rank: a column needs every row) and the working copy of
     // z — is queued now, so the device builds it while the host runs the sigma protocols between the phases
     dev_eq_evals(c, P.rx.data(), nrx, S.T[0].p, S.eqs.p);
     if (sh) dev_gather_strided(c, wit.z.p, G, rk, S.zw.p, V2l);
     else OTTI_HIP(hipMemcpyAsync(S.zw.p, wit.z.p, 2 * V * sizeof(Fr), hipMemcpyDeviceToDevice, c.stream));
-    if (!sh) OTTI_HIP(hipEventSynchronize(c.ev0));
+    if (!sh) { OTTI_HIP(hipEventSynchronize(c.ev0)); c.h_results[8] = cj; }   // eq(tau, rx) is the scalar the rounds accumulated
     const Fr tau_claim = c.h_results[8], Az_claim = c.h_results[9], Bz_claim = c.h_results[10], Cz_claim = c.h_results[11];
     T.ms[2] = now_ms() - t0;
 
