@@ -255,7 +255,7 @@ def main():
             # (96 B per mixed addition) are not compulsory traffic and are not counted
             bytes_per_launch = F * V
         elif dom == "sc_cubic":
-            bytes_per_launch = 512 * N / max(1, (N.bit_length() - 1))          # phase one 512*N over log2(N) launches
+            bytes_per_launch = 384 * N / max(1, (N.bit_length() - 1))          # phase one streams three tables (eq factored out): 384*N over log2(N) launches
         elif dom == "sc_quad":
             bytes_per_launch = 512 * V / max(1, ((2 * V).bit_length() - 1))
         elif dom == "spmv":
