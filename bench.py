@@ -268,7 +268,7 @@ def main():
         traffic = None
         try:   # HBM traffic of the dominant kernel's largest launch, from a separate rocprofv3 --pmc pass (profiles/, see its note)
             pm = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
-            kname = {"msm_rows": "k_msm_rows<0>", "sc_cubic": "k_sc_cubic_fold_eval", "sc_quad": "k_sc_quad_fold_eval", "spmv": "k_spmv3_light"}.get(dom)
+            kname = {"msm_rows": "k_msm_rows<0>", "sc_cubic": "k_sc_cubic3_fold_eval", "sc_quad": "k_sc_quad_fold_eval", "spmv": "k_spmv3_light"}.get(dom)
             if kname and lg == pm.get("log2_constraints", 20) and cbits == pm.get("msm_window_bits", 12):
                 traffic = pm["kernels"][kname]["traffic_bytes_corrected"]
         except Exception:

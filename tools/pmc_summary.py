@@ -7,7 +7,7 @@ import csv
 import json
 import sys
 
-KERNELS = ("k_msm_rows<0>", "k_msm_rows<1>", "k_sc_cubic_fold_eval", "k_sc_quad_fold_eval", "k_sc_cubic_eval", "k_sc_quad_eval", "k_spmv3_light", "k_eq_expand",
+KERNELS = ("k_msm_rows<0>", "k_msm_rows<1>", "k_sc_cubic3_fold_eval", "k_sc_quad_fold_eval", "k_sc_cubic3_eval", "k_sc_quad_eval", "k_spmv3_light", "k_eq_expand",
            "k_poly_bound_slab", "k_gather_strided")
 
 
