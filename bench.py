@@ -63,7 +63,7 @@ def usable_cores():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log2-constraints", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
