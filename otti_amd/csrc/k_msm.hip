@@ -30,6 +30,12 @@ struct MsmArgs {
 };
 __device__ __forceinline__ Fr bullet_fold_a(const BulletArgs &U, size_t x) { return U.fold ? fr_add(fr_mul(U.a_in[x], U.u), fr_mul(U.uinv, U.a_in[U.n + x])) : U.a_in[x]; }
 __device__ __forceinline__ Fr bullet_fold_b(const BulletArgs &U, size_t x) { return U.fold ? fr_add(fr_mul(U.b_in[x], U.uinv), fr_mul(U.u, U.b_in[U.n + x])) : U.b_in[x]; }
+// Row L only has non-zero scalars on the generator slots of the upper half of every length-n block, row R on the lower half: a
+// bullet launch therefore walks R/2 "active" terms per row; term t of row `row` sits on generator j = (t / h) * n + (t mod h) + (row == 0 ? h : 0).
+__device__ __forceinline__ size_t bullet_slot(const BulletArgs &U, size_t row, size_t t) {
+    const size_t n = U.n, h = n / 2;
+    return (t / h) * n + (t % h) + (row == 0 ? h : 0);
+}
 __device__ __forceinline__ Fr bullet_fold_s(const BulletArgs &U, size_t j) { return U.fold ? fr_mul(U.s_in[j], ((j & (2 * (size_t)U.n - 1)) < U.n) ? U.uinv : U.u) : U.s_in[j]; }
 // kKind = MSM_BULK: the bulk launches (a commitment: many rows, every workgroup a full chunk) — no bullet bookkeeping, no fused finish.
 // kKind = MSM_BULK_SPARSE: the same for scalars that are mostly small numbers (compacted work list, see phase 2).
@@ -53,11 +59,13 @@ template <int kKind> __global__ __launch_bounds__(kBlock) void k_msm_rows(MsmArg
     const bool bullet = kSmall && A.bul.on;
     if (bullet) {
         const BulletArgs &U = A.bul; const size_t n = U.n, h = n / 2;
-        if (row == 0) {                                        // persist the folded state for the next round (each element written once)
+        // persist the folded state for the next round, each element written once: a and b by the row-0 workgroups, s by whichever
+        // row walks that generator slot
+        if (row == 0) {
             const size_t cx = (n + gridDim.x - 1) / gridDim.x, x0 = (size_t)chunk_id * cx;
             for (size_t x = x0 + threadIdx.x; x < min(n, x0 + cx); x += blockDim.x) { U.a_out[x] = bullet_fold_a(U, x); U.b_out[x] = bullet_fold_b(U, x); }
-            for (uint32_t t = threadIdx.x; t < n_here; t += blockDim.x) U.s_out[j0 + t] = bullet_fold_s(U, j0 + t);
         }
+        for (uint32_t t = threadIdx.x; t < n_here; t += blockDim.x) { const size_t j = bullet_slot(U, row, j0 + t); U.s_out[j] = bullet_fold_s(U, j); }
         if (chunk_id == 0) {                                   // c_L = <a_L, b_R> (row 0), c_R = <a_R, b_L> (row 1)
             Fr acc[1] = {fr_zero()};
             for (size_t x = threadIdx.x; x < h; x += blockDim.x)
@@ -71,10 +79,9 @@ template <int kKind> __global__ __launch_bounds__(kBlock) void k_msm_rows(MsmArg
         Fr sc;
         if (t >= n_here) sc = (bullet && t == n_here) ? s_dot : A.extra_s[row * A.n_extra + (t - n_here)];
         else if (bullet) {
-            const BulletArgs &U = A.bul; const size_t j = j0 + t, n = U.n, h = n / 2, i = j & (n - 1);
+            const BulletArgs &U = A.bul; const size_t j = bullet_slot(U, row, j0 + t), n = U.n, h = n / 2, i = j & (n - 1);
             // L = <a_L, G_R>: generator slots of the upper half, paired with a[i - h];  R = <a_R, G_L>: lower half with a[i + h]
-            if (row == 0) sc = i >= h ? fr_mul(bullet_fold_a(U, i - h), bullet_fold_s(U, j)) : fr_zero();
-            else sc = i < h ? fr_mul(bullet_fold_a(U, i + h), bullet_fold_s(U, j)) : fr_zero();
+            sc = fr_mul(bullet_fold_a(U, row == 0 ? i - h : i + h), bullet_fold_s(U, j));
         } else sc = A.dense[row * A.stride + j0 + t];
         Fr raw = fr_to_raw(sc);
         uint64_t cy = 0;
@@ -139,7 +146,7 @@ template <int kKind> __global__ __launch_bounds__(kBlock) void k_msm_rows(MsmArg
             if (limb < 8) x |= (uint64_t)s_raw[t * 9 + limb + 1] << 32;
             int d = (int)((uint32_t)(x >> off) & mask) - half;
             if (d == 0) continue;
-            size_t base = t < n_here ? j0 + t : (size_t)s_base[t - n_here];
+            size_t base = t < n_here ? (bullet ? bullet_slot(A.bul, row, j0 + t) : j0 + t) : (size_t)s_base[t - n_here];
             uint32_t mag = (uint32_t)(d < 0 ? -d : d);
             N10 e = n10_unpack(A.table[base * WE + (size_t)w * A.E + (mag - 1)]);
             if (d < 0) e = n10_negate(e);
@@ -231,7 +238,7 @@ unsigned long long dev_bullet_round(DevCtx &c, const DeviceGens &g, size_t R, si
                                     const Fr *b_in, const Fr *s_in, Fr *a_out, Fr *b_out, Fr *s_out, const Fr *extra_s, const uint32_t *extra_base) {
     BulletArgs U; U.on = 1; U.fold = fold ? 1 : 0; U.n = (uint32_t)n_cur; U.a_in = a_in; U.b_in = b_in; U.s_in = s_in;
     U.a_out = a_out; U.b_out = b_out; U.s_out = s_out; U.u = u; U.uinv = u_inv;
-    return msm_launch(c, g, nullptr, 0, R, 2, extra_s, extra_base, 2, MSM_COMPRESSED, nullptr, &U, false);
+    return msm_launch(c, g, nullptr, 0, R / 2, 2, extra_s, extra_base, 2, MSM_COMPRESSED, nullptr, &U, false);   // R/2 active terms per row
 }
 static unsigned long long msm_launch(DevCtx &c, const DeviceGens &g, const Fr *dense, size_t stride, size_t n_dense, size_t rows, const Fr *extra_s,
                                      const uint32_t *extra_base, size_t n_extra, int mode, const Pt *addend, const BulletArgs *bul, bool sparse_hint) {
