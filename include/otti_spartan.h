@@ -70,7 +70,7 @@ void    otti_gens_free(otti_gens *gens);
 /* compressed generator stream P[0 .. count) (tests pin it against SURVEY App. B) */
 int32_t otti_gens_points(const otti_gens *gens, uint8_t *out32, size_t count);
 /* the device-side fixed-base window table of these generators, once built (otti_prepare_device or the first proof): window width c
-   (OTTI_MSM_WINDOW pins it; otherwise the widest whose table fits OTTI_MSM_TABLE_GB, default 64) and its size; zeros before that.
+   (OTTI_MSM_WINDOW pins it; otherwise the widest whose table fits OTTI_MSM_TABLE_GB, default 128) and its size; zeros before that.
    No reference counterpart: dalek's vartime MSM builds per-call tables. */
 int32_t otti_gens_table_info(const otti_gens *gens, uint32_t *window_bits, uint64_t *table_bytes);
 

@@ -20,11 +20,11 @@ static double now_ms() { return std::chrono::duration<double, std::milli>(std::c
 
 // Window width c of the fixed-base table.  Every bit of c removes additions from every MSM of every proof (W = floor(253/c)+1 per
 // scalar) and doubles the table; the table is built once per generator set and HBM is 288 GB, so take the widest window whose table
-// fits a budget (default 64 GiB: c = 16 for R = 1024, 15 for R = 2048, 14 for R = 4096).  OTTI_MSM_WINDOW pins c;
+// fits a budget (default 128 GiB: c = 16 for R = 1024 (51.6 GB) and R = 2048 (103 GB), 15 for R = 4096 (110 GB)).  OTTI_MSM_WINDOW pins c;
 // OTTI_MSM_TABLE_GB changes the budget (one-shot callers such as spzk pick a small table: building it costs more than it saves).
 int device_window_bits(size_t nbases) {
     if (const char *e = getenv("OTTI_MSM_WINDOW")) { int c = atoi(e); if (c >= 4 && c <= 16) return c; }
-    double budget_gb = 64.0;
+    double budget_gb = 128.0;
     if (const char *e = getenv("OTTI_MSM_TABLE_GB")) { double v = atof(e); if (v > 0) budget_gb = v; }
     int best = 8;
     const int widest = nbases < 256 ? 12 : 16;             // tiny instances (R < 256) are launch-bound whatever the window: keep their tables small
