@@ -27,9 +27,26 @@ def exchange(seg, rank, world, out):
     np.savez(out, **got)
 
 
-def prove(seg, rank, world, out, lg, dist, ni):
+def make_r1cs(lg, dist, ni):
+    """uniform / compiler: square synthetic instances; many_cons / many_vars: rectangular ones derived from a 2^lg square instance"""
     n = 1 << lg
-    r = (oa.synth_r1cs_compiler_like if dist == "compiler" else oa.synth_r1cs)(n, ni, 5)
+    if dist in ("uniform", "compiler"):
+        return (oa.synth_r1cs_compiler_like if dist == "compiler" else oa.synth_r1cs)(n, ni, 5)
+    r = oa.synth_r1cs(n, ni, 5)
+    A, B, C = r["A"].copy(), r["B"].copy(), r["C"].copy()
+    if dist == "many_cons":                                     # every constraint 16 times: 16 n constraints over n variables
+        def rep(M):
+            out = np.tile(M, 16); out["row"] = np.concatenate([M["row"] + k * n for k in range(16)]); return out
+        return dict(r, A=rep(A), B=rep(B), C=rep(C), num_cons=16 * n)
+    extra = 15 * n                                              # many_vars: n constraints over 16 n variables (the new ones unused)
+    for M in (A, B, C):
+        M["col"] = np.where(M["col"] >= n, M["col"] + extra, M["col"])
+    pad = np.random.default_rng(77).integers(0, 256, size=(extra, 32), dtype=np.uint8); pad[:, 31] &= 0x0f
+    return dict(r, A=A, B=B, C=C, vars=np.concatenate([r["vars"], pad]), num_vars=n + extra)
+
+
+def prove(seg, rank, world, out, lg, dist, ni):
+    r = make_r1cs(lg, dist, ni)
     inst = oa.Instance.new(r["num_cons"], r["num_vars"], r["num_inputs"], r["A"], r["B"], r["C"])
     gens = oa.NIZKGens.new(r["num_cons"], r["num_vars"], r["num_inputs"])
     wit = oa.Witness(inst, oa.VarsAssignment.new(r["vars"]), oa.InputsAssignment.new(r["inputs"]))

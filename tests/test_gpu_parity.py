@@ -419,6 +419,37 @@ def test_concurrent_provers_share_instance_and_table():
     assert len(results) == 30 and all(results)
 
 
+@pytest.mark.parametrize("shape", ["many_vars", "many_cons", "one_var_block"])
+def test_rectangular_instances(rng, shape):
+    """num_cons != num_vars: the two sum-checks then run over tables of different lengths, and the commitment matrix is not the
+    square of the constraint count.  Built from a satisfiable square instance by adding unused variables or repeating constraints."""
+    n, ni = 64, 3
+    r = oa.synth_r1cs(n, ni, 21)
+    A, B, C, vars_, inputs = r["A"].copy(), r["B"].copy(), r["C"].copy(), r["vars"], r["inputs"]
+    if shape == "many_vars":                                   # 64 constraints over 2048 + 64 variables
+        extra = 2048
+        for M in (A, B, C):
+            M["col"] = np.where(M["col"] >= n, M["col"] + extra, M["col"])
+        canon = rng.integers(0, 256, size=(extra, 32), dtype=np.uint8); canon[:, 31] &= 0x0f
+        vars_ = np.concatenate([vars_, canon]); nc, nv = n, n + extra
+    elif shape == "many_cons":                                 # 4096 constraints (each original one 64 times) over 64 variables
+        reps = 64
+        def rep(M):
+            out = np.tile(M, reps); out["row"] = np.concatenate([M["row"] + k * n for k in range(reps)]); return out
+        A, B, C = rep(A), rep(B), rep(C); nc, nv = n * reps, n
+    else:                                                      # 2 constraints, 64 variables: num_cons is padded to the minimum of 2
+        keep = lambda M: M[M["row"] < 2]
+        A, B, C = keep(A), keep(B), keep(C); nc, nv = 2, n
+    inst, gens = oa.Instance.new(nc, nv, ni, A, B, C), oa.NIZKGens.new(nc, nv, ni)
+    assert inst.is_sat(oa.VarsAssignment.new(vars_), oa.InputsAssignment.new(inputs))
+    proof = oa.NIZK.prove(inst, oa.VarsAssignment.new(vars_), oa.InputsAssignment.new(inputs), gens, b"rect", b"\x11" * 32)
+    oi, og = orc.OInstance(nc, nv, ni, A, B, C), orc.OGens(nc, nv, ni)
+    want, _ = orc.nizk_prove(oi, vars_, inputs, og, b"rect", b"\x11" * 32)
+    assert proof.bytes == want
+    proof.verify(inst, oa.InputsAssignment.new(inputs), gens, b"rect")
+    assert orc.nizk_verify(oi, inputs, og, proof.bytes, b"rect") == 0
+
+
 def test_golden_proof_digests_on_gpu():
     import json
     import os

@@ -16,8 +16,8 @@ pytestmark = pytest.mark.gpu
 
 
 def _reference_proofs(lg, dist, ni):
-    n = 1 << lg
-    r = (oa.synth_r1cs_compiler_like if dist == "compiler" else oa.synth_r1cs)(n, ni, 5)
+    from shard_worker import make_r1cs
+    r = make_r1cs(lg, dist, ni)
     inst = oa.Instance.new(r["num_cons"], r["num_vars"], r["num_inputs"], r["A"], r["B"], r["C"])
     gens = oa.NIZKGens.new(r["num_cons"], r["num_vars"], r["num_inputs"])
     single = oa.NIZK.prove(inst, oa.VarsAssignment.new(r["vars"]), oa.InputsAssignment.new(r["inputs"]), gens, LABEL, SEED)
@@ -29,7 +29,7 @@ def _reference_proofs(lg, dist, ni):
 
 
 @pytest.mark.parametrize("world,lg,dist,ni", [(2, 10, "uniform", 4), (4, 12, "uniform", 10), (4, 11, "compiler", 3), (2, 4, "uniform", 2),
-                                               (4, 6, "uniform", 1)])
+                                               (4, 6, "uniform", 1), (4, 8, "many_cons", 3), (2, 7, "many_vars", 2), (4, 5, "many_vars", 1)])
 def test_sharded_proof_is_byte_identical(tmp_path, world, lg, dist, ni):
     single, oracle = _reference_proofs(lg, dist, ni)
     assert single == oracle
