@@ -4,6 +4,8 @@
 #include "pool.h"
 #include <algorithm>
 #include <numeric>
+#include <thread>
+#include <functional>
 
 namespace otti {
 
@@ -354,54 +356,78 @@ struct VerifyFail { int code; };
 Pt dec(const CPoint &c) { Pt p; if (!pt_decode(p, c.b)) throw VerifyFail{OTTI_ERR_VERIFY_DECOMPRESS}; return p; }
 void require(bool ok) { if (!ok) throw VerifyFail{OTTI_ERR_VERIFY_INTERNAL}; }
 Pt commit_scalar_pt(const Gens &g, const GensView &g1, const Fr &x, const Fr &blind) { return g.commit_generic(&x, 1, blind, g1); }
+// Group equations that do not feed the transcript (most of the verifier's work: two scalar multiplications and a small MSM per
+// sum-check round) are collected here and checked at the end, spread over the host cores.  Each entry throws VerifyFail on failure.
+// a sum over many points, split over the host cores (the verifier's two sqrt(V)-sized multi-scalar multiplications)
+Pt host_msm_wide(const Fr *sc, const Pt *pts, size_t n) {
+    const size_t nt = std::min<size_t>({n / 128, (size_t)8, (size_t)std::max(1u, std::thread::hardware_concurrency())});
+    if (nt < 2) return host_msm(sc, pts, n);
+    std::vector<Pt> part(nt); std::vector<std::thread> th;
+    auto work = [&](size_t t) { size_t lo = n * t / nt, hi = n * (t + 1) / nt; part[t] = host_msm(sc + lo, pts + lo, hi - lo); };
+    for (size_t t = 1; t < nt; t++) th.emplace_back(work, t);
+    work(0);
+    for (auto &x : th) x.join();
+    Pt acc = part[0]; for (size_t t = 1; t < nt; t++) acc = pt_add(acc, part[t]);
+    return acc;
+}
+using Deferred = std::vector<std::function<void()>>;
+void run_deferred(Deferred &d) {
+    if (d.empty()) return;
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const size_t nt = std::min<size_t>({d.size(), (size_t)8, (size_t)hw});
+    std::vector<int> codes(nt, 0); std::vector<std::thread> th;
+    auto work = [&](size_t t) { try { for (size_t i = t; i < d.size(); i += nt) d[i](); } catch (const VerifyFail &f) { codes[t] = f.code; } catch (...) { codes[t] = OTTI_ERR_VERIFY_INTERNAL; } };
+    for (size_t t = 1; t < nt; t++) th.emplace_back(work, t);
+    work(0);
+    for (auto &x : th) x.join();
+    for (int c : codes) if (c) throw VerifyFail{c};
+}
 
-void knowledge_verify(const KnowledgeProof &pf, const Gens &g, Transcript &tr, const CPoint &C) {
+void knowledge_verify(const KnowledgeProof &pf, const Gens &g, Transcript &tr, const CPoint &C, Deferred &later) {
     tr.append_protocol_name("knowledge proof");
     tr.append_point("C", C.b); tr.append_point("alpha", pf.alpha.b);
     Fr c = tr.challenge_scalar("c");
-    Pt lhs = commit_scalar_pt(g, g.sc_1, pf.z1, pf.z2);
-    Pt rhs = pt_add(host_scalarmul(dec(C), c), dec(pf.alpha));
-    require(pt_eq(lhs, rhs));
+    const KnowledgeProof *p = &pf; const Gens *gp = &g;
+    later.push_back([=] { require(pt_eq(commit_scalar_pt(*gp, gp->sc_1, p->z1, p->z2), pt_add(host_scalarmul(dec(C), c), dec(p->alpha)))); });
 }
-void equality_verify(const EqualityProof &pf, const Gens &g, Transcript &tr, const CPoint &C1, const CPoint &C2) {
+void equality_verify(const EqualityProof &pf, const Gens &g, Transcript &tr, const CPoint &C1, const CPoint &C2, Deferred &later) {
     tr.append_protocol_name("equality proof");
     tr.append_point("C1", C1.b); tr.append_point("C2", C2.b); tr.append_point("alpha", pf.alpha.b);
     Fr c = tr.challenge_scalar("c");
-    Pt rhs = pt_add(host_scalarmul(pt_sub(dec(C1), dec(C2)), c), dec(pf.alpha));
-    Pt lhs = host_scalarmul(g.P[g.sc_1.h], pf.z);
-    require(pt_eq(lhs, rhs));
+    const EqualityProof *p = &pf; const Gens *gp = &g;
+    later.push_back([=] { require(pt_eq(host_scalarmul(gp->P[gp->sc_1.h], p->z), pt_add(host_scalarmul(pt_sub(dec(C1), dec(C2)), c), dec(p->alpha)))); });
 }
 bool product_check(const CPoint &P, const Pt &X, const Fr &c, const Pt &G, const Pt &h, const Fr &z1, const Fr &z2) {
     Pt lhs = pt_add(dec(P), host_scalarmul(X, c));
     Pt rhs = pt_add(host_scalarmul(G, z1), host_scalarmul(h, z2));
     return pt_eq(lhs, rhs);
 }
-void product_verify(const ProductProof &pf, const Gens &g, Transcript &tr, const CPoint &X, const CPoint &Y, const CPoint &Z) {
+void product_verify(const ProductProof &pf, const Gens &g, Transcript &tr, const CPoint &X, const CPoint &Y, const CPoint &Z, Deferred &later) {
     tr.append_protocol_name("product proof");
     tr.append_point("X", X.b); tr.append_point("Y", Y.b); tr.append_point("Z", Z.b);
     tr.append_point("alpha", pf.alpha.b); tr.append_point("beta", pf.beta.b); tr.append_point("delta", pf.delta.b);
     Fr c = tr.challenge_scalar("c");
-    const Pt &G = g.P[g.sc_1.G[0]], &h = g.P[g.sc_1.h];
-    Pt Xp = dec(X), Yp = dec(Y), Zp = dec(Z);
-    require(product_check(pf.alpha, Xp, c, G, h, pf.z[0], pf.z[1]) && product_check(pf.beta, Yp, c, G, h, pf.z[2], pf.z[3]) &&
-            product_check(pf.delta, Zp, c, Xp, h, pf.z[2], pf.z[4]));
+    const ProductProof *p = &pf; const Gens *gp = &g;
+    later.push_back([=] { const Pt &G = gp->P[gp->sc_1.G[0]], &h = gp->P[gp->sc_1.h]; require(product_check(p->alpha, dec(X), c, G, h, p->z[0], p->z[1])); });
+    later.push_back([=] { const Pt &G = gp->P[gp->sc_1.G[0]], &h = gp->P[gp->sc_1.h]; require(product_check(p->beta, dec(Y), c, G, h, p->z[2], p->z[3])); });
+    later.push_back([=] { const Pt &h = gp->P[gp->sc_1.h]; require(product_check(p->delta, dec(Z), c, dec(X), h, p->z[2], p->z[4])); });
 }
 void dotproduct_verify(const DotProductProof &pf, const Gens &g, const GensView &gn, Transcript &tr, const Fr *a, size_t n,
-                       const CPoint &Cx, const CPoint &Cy) {
+                       const CPoint &Cx, const CPoint &Cy, Deferred &later) {
     require(pf.z.size() == n && gn.G.size() == n);
     tr.append_protocol_name("dot product proof");
     tr.append_point("Cx", Cx.b); tr.append_point("Cy", Cy.b);
     tr.append_scalars("a", a, n);
     tr.append_point("delta", pf.delta.b); tr.append_point("beta", pf.beta.b);
     Fr c = tr.challenge_scalar("c");
-    bool ok = pt_eq(pt_add(host_scalarmul(dec(Cx), c), dec(pf.delta)), g.commit_generic(pf.z.data(), n, pf.z_delta, gn));
     Fr za = fr_zero(); for (size_t i = 0; i < n; i++) za = fr_add(za, fr_mul(pf.z[i], a[i]));
-    ok = ok && pt_eq(pt_add(host_scalarmul(dec(Cy), c), dec(pf.beta)), commit_scalar_pt(g, g.sc_1, za, pf.z_beta));
-    require(ok);
+    const DotProductProof *p = &pf; const Gens *gp = &g; const GensView *gv = &gn;       // all outlive the deferred run (owned by nizk_verify's frame)
+    later.push_back([=] { require(pt_eq(pt_add(host_scalarmul(dec(Cx), c), dec(p->delta)), gp->commit_generic(p->z.data(), n, p->z_delta, *gv))); });
+    later.push_back([=] { require(pt_eq(pt_add(host_scalarmul(dec(Cy), c), dec(p->beta)), commit_scalar_pt(*gp, gp->sc_1, za, p->z_beta))); });
 }
 // ZKSumcheckInstanceProof::verify
 CPoint sumcheck_verify(const ZKSumcheckProof &pf, const CPoint &comm_claim, size_t num_rounds, size_t degree, const Gens &g,
-                       const GensView &gn, Transcript &tr, std::vector<Fr> &r) {
+                       const GensView &gn, Transcript &tr, std::vector<Fr> &r, Deferred &later) {
     require(gn.G.size() == degree + 1 && pf.comm_polys.size() == num_rounds && pf.comm_evals.size() == num_rounds &&
             pf.proofs.size() == num_rounds);
     size_t ne = degree + 1; r.clear();
@@ -411,10 +437,17 @@ CPoint sumcheck_verify(const ZKSumcheckProof &pf, const CPoint &comm_claim, size
         const CPoint &ccpr = i == 0 ? comm_claim : pf.comm_evals[i - 1];
         tr.append_point("comm_claim_per_round", ccpr.b); tr.append_point("comm_eval", pf.comm_evals[i].b);
         std::vector<Fr> w = tr.challenge_vector("combine_two_claims_to_one", 2);
-        CPoint comm_target; pt_encode(comm_target.b, pt_add(host_scalarmul(dec(ccpr), w[0]), host_scalarmul(dec(pf.comm_evals[i]), w[1])));
+        // the combined claim's commitment is hashed ("Cy" below), so it stays on the sequential path: its two halves on two threads
+        Pt half[2]; int bad[2] = {0, 0};
+        std::function<void()> halves[2] = {
+            [&] { try { half[0] = host_scalarmul(dec(ccpr), w[0]); } catch (const VerifyFail &f) { bad[0] = f.code; } },
+            [&] { try { half[1] = host_scalarmul(dec(pf.comm_evals[i]), w[1]); } catch (const VerifyFail &f) { bad[1] = f.code; } }};
+        SpinPool::get().parallel(halves, 2);
+        if (bad[0] || bad[1]) throw VerifyFail{bad[0] ? bad[0] : bad[1]};
+        CPoint comm_target; pt_encode(comm_target.b, pt_add(half[0], half[1]));
         Fr a[4], pw = fr_one(), two = fr_from_u64(2);
         for (size_t k = 0; k < ne; k++) { a[k] = fr_add(fr_mul(w[0], k == 0 ? two : fr_one()), fr_mul(w[1], pw)); pw = fr_mul(pw, r_i); }
-        dotproduct_verify(pf.proofs[i], g, gn, tr, a, ne, pf.comm_polys[i], comm_target);
+        dotproduct_verify(pf.proofs[i], g, gn, tr, a, ne, pf.comm_polys[i], comm_target, later);
         r.push_back(r_i);
     }
     return pf.comm_evals[num_rounds - 1];
@@ -432,7 +465,7 @@ void bullet_verify(const DotProductProofLog &pf, size_t n, const Fr *a, Transcri
     std::vector<Fr> s(n); s[0] = allinv;
     for (size_t i = 1; i < n; i++) { size_t lg_i = ilog2(i + 1) - 1; size_t k = (size_t)1 << lg_i; s[i] = fr_mul(s[i - k], ch[(lg - 1) - lg_i]); }
     std::vector<Pt> G(n); for (size_t i = 0; i < n; i++) G[i] = g.P[g.pc_n.G[i]];
-    g_hat = host_msm(s.data(), G.data(), n);
+    g_hat = host_msm_wide(s.data(), G.data(), n);
     a_hat = fr_zero(); for (size_t i = 0; i < n; i++) a_hat = fr_add(a_hat, fr_mul(a[i], s[i]));
     std::vector<Fr> sc; std::vector<Pt> pts;
     for (size_t i = 0; i < lg; i++) { sc.push_back(ch[i]); pts.push_back(dec(pf.L_vec[i])); }
@@ -474,27 +507,38 @@ int nizk_verify(const Instance &I, const std::vector<Fr> &inputs, const Gens &g,
         tr.append_message("poly_commitment", "poly_commitment_end", 19);
         std::vector<Fr> tau = tr.challenge_vector("challenge_tau", nrx), rx, ry;
         CPoint claim_phase1; pt_encode(claim_phase1.b, commit_scalar_pt(g, g.sc_1, fr_zero(), fr_zero()));
-        CPoint comm_post1 = sumcheck_verify(P.sc1, claim_phase1, nrx, 3, g, g.sc_4, tr, rx);
+        Deferred later;                                                   // P, g and the CPoints it captures live until run_deferred below
+        SpinPool::Session pool_session;
+        CPoint comm_post1 = sumcheck_verify(P.sc1, claim_phase1, nrx, 3, g, g.sc_4, tr, rx, later);
         const CPoint &cAz = P.claims_phase2[0], &cBz = P.claims_phase2[1], &cCz = P.claims_phase2[2], &cPr = P.claims_phase2[3];
-        knowledge_verify(P.pok, g, tr, cCz);
-        product_verify(P.prod, g, tr, cAz, cBz, cPr);
+        knowledge_verify(P.pok, g, tr, cCz, later);
+        product_verify(P.prod, g, tr, cAz, cBz, cPr, later);
         tr.append_point("comm_Az_claim", cAz.b); tr.append_point("comm_Bz_claim", cBz.b);
         tr.append_point("comm_Cz_claim", cCz.b); tr.append_point("comm_prod_Az_Bz_claims", cPr.b);
         Fr taus_bound = fr_one(), one = fr_one();
         for (size_t i = 0; i < nrx; i++) taus_bound = fr_mul(taus_bound, fr_add(fr_mul(rx[i], tau[i]), fr_mul(fr_sub(one, rx[i]), fr_sub(one, tau[i]))));
         CPoint expected1; pt_encode(expected1.b, host_scalarmul(pt_sub(dec(cPr), dec(cCz)), taus_bound));
-        equality_verify(P.eq1, g, tr, expected1, comm_post1);
+        equality_verify(P.eq1, g, tr, expected1, comm_post1, later);
         Fr rA = tr.challenge_scalar("challenege_Az"), rB = tr.challenge_scalar("challenege_Bz"), rC = tr.challenge_scalar("challenege_Cz");
         CPoint comm_claim2;
         pt_encode(comm_claim2.b, pt_add(pt_add(host_scalarmul(dec(cAz), rA), host_scalarmul(dec(cBz), rB)), host_scalarmul(dec(cCz), rC)));
-        CPoint comm_post2 = sumcheck_verify(P.sc2, comm_claim2, nry, 2, g, g.sc_3, tr, ry);
+        CPoint comm_post2 = sumcheck_verify(P.sc2, comm_claim2, nry, 2, g, g.sc_3, tr, ry, later);
         // PolyEvalProof::verify
         {
             tr.append_protocol_name("polynomial evaluation proof");
             size_t rl = nry - 1, lv = rl / 2;
             std::vector<Fr> Lv = eq_evals_host(ry.data() + 1, lv), Rv = eq_evals_host(ry.data() + 1 + lv, rl - lv);
-            std::vector<Pt> Cs(Lsz); for (size_t i = 0; i < Lsz; i++) Cs[i] = dec(P.comm_vars[i]);
-            CPoint C_LZ; pt_encode(C_LZ.b, host_msm(Lv.data(), Cs.data(), Lsz));
+            std::vector<Pt> Cs(Lsz);
+            {   // decompression of the row commitments (an inverse square root each), striped over the host cores
+                const size_t nt = std::min<size_t>({Lsz / 64 + 1, (size_t)8, (size_t)std::max(1u, std::thread::hardware_concurrency())});
+                std::vector<int> bad(nt, 0); std::vector<std::thread> th;
+                auto work = [&](size_t t) { try { for (size_t i = t; i < Lsz; i += nt) Cs[i] = dec(P.comm_vars[i]); } catch (const VerifyFail &f) { bad[t] = f.code; } };
+                for (size_t t = 1; t < nt; t++) th.emplace_back(work, t);
+                work(0);
+                for (auto &x : th) x.join();
+                for (int b : bad) if (b) throw VerifyFail{b};
+            }
+            CPoint C_LZ; pt_encode(C_LZ.b, host_msm_wide(Lv.data(), Cs.data(), Lsz));
             require(P.polyeval.L_vec.size() == ilog2(Rsz));
             dotproductlog_verify(P.polyeval, Rsz, g, tr, Rv.data(), C_LZ, P.comm_vars_at_ry);
         }
@@ -509,7 +553,8 @@ int nizk_verify(const Instance &I, const std::vector<Fr> &inputs, const Gens &g,
                                 host_scalarmul(commit_scalar_pt(g, g.pc_1, poly_input_eval, fr_zero()), ry[0]));
         Fr comb = fr_add(fr_add(fr_mul(rA, inst_evals[0]), fr_mul(rB, inst_evals[1])), fr_mul(rC, inst_evals[2]));
         CPoint expected2; pt_encode(expected2.b, host_scalarmul(comm_eval_Z, comb));
-        equality_verify(P.eq2, g, tr, expected2, comm_post2);
+        equality_verify(P.eq2, g, tr, expected2, comm_post2, later);
+        run_deferred(later);
         for (size_t i = 0; i < nrx; i++) require(fr_eq(rx[i], P.rx[i]));
         for (size_t i = 0; i < nry; i++) require(fr_eq(ry[i], P.ry[i]));
         return OTTI_OK;
