@@ -116,9 +116,11 @@ int32_t otti_nizk_prove(otti_instance *inst, const uint8_t *vars32, size_t nvars
     return guarded([&] {
         if (!inst || !gens || !proof || !proof_len) throw Error(OTTI_ERR_BAD_ARG, "null argument");
         if (!(flags & OTTI_FLAG_GPU)) throw Error(OTTI_ERR_BAD_ARG, "OTTI_FLAG_GPU is the only proving backend; there is no CPU path");
-        std::vector<Fr> vars, inputs; load_assignment(*inst->I, vars32, nvars, inputs32, ninputs, vars, inputs);
+        if (ninputs != inst->I->num_inputs) throw Error(OTTI_ERR_INVALID_NUM_INPUTS, "wrong number of inputs");
+        std::vector<Fr> inputs = scalars_from_bytes(inputs32, ninputs);
         ProveTimings tm{};
-        std::vector<uint8_t> pf = nizk_prove_gpu(*inst->I, vars, inputs, *gens->g, tlabel, tlabel_len, seed32, &tm);
+        DeviceWitness w(*inst->I, vars32, nvars, inputs);          // VarsAssignment::new (InvalidScalar) is checked on the device
+        std::vector<uint8_t> pf = nizk_prove_resident(*inst->I, w, *gens->g, tlabel, tlabel_len, seed32, &tm);
         if (stage_ms) memcpy(stage_ms, tm.ms, sizeof tm.ms);
         *proof = to_malloc(pf, proof_len); return OTTI_OK;
     });
@@ -126,8 +128,9 @@ int32_t otti_nizk_prove(otti_instance *inst, const uint8_t *vars32, size_t nvars
 int32_t otti_witness_upload(otti_instance *inst, const uint8_t *vars32, size_t nvars, const uint8_t *inputs32, size_t ninputs, otti_witness **out) {
     return guarded([&] {
         if (!inst || !out) throw Error(OTTI_ERR_BAD_ARG, "null argument");
-        std::vector<Fr> vars, inputs; load_assignment(*inst->I, vars32, nvars, inputs32, ninputs, vars, inputs);
-        auto h = std::make_unique<otti_witness>(); h->w = std::make_unique<DeviceWitness>(*inst->I, vars, inputs);
+        if (ninputs != inst->I->num_inputs) throw Error(OTTI_ERR_INVALID_NUM_INPUTS, "wrong number of inputs");
+        std::vector<Fr> inputs = scalars_from_bytes(inputs32, ninputs);
+        auto h = std::make_unique<otti_witness>(); h->w = std::make_unique<DeviceWitness>(*inst->I, vars32, nvars, inputs);
         *out = h.release(); return OTTI_OK;
     });
 }

@@ -99,6 +99,8 @@ struct DeviceWitness {
     DevBuf<Fr> z; std::vector<Fr> inputs;
     double small_fraction = 0.0;                              // share of the variables below 2^128: picks the MSM variant of the commitment
     DeviceWitness(const Instance &I, const std::vector<Fr> &vars_padded, const std::vector<Fr> &inputs);
+    // straight from the caller's canonical bytes: validation (InvalidScalar) and the conversion to Montgomery form happen on the device
+    DeviceWitness(const Instance &I, const uint8_t *vars32, size_t nvars, const std::vector<Fr> &inputs);
 };
 void ensure_device_objects(Instance &I, Gens &g);          // lazily built, shared by every prover thread (guarded)
 void ensure_instance_device(Instance &I);
@@ -113,6 +115,7 @@ class ShardComm;
 std::vector<uint8_t> nizk_prove_resident(Instance &I, DeviceWitness &wit, Gens &g, const void *tlabel, size_t tlabel_len, const uint8_t *seed32,
                                          ProveTimings *tm, ShardComm *sh = nullptr);
 std::shared_ptr<DeviceShard> upload_instance_shard(const Instance &I, int rank, int world);
+size_t dev_witness_ingest(DevCtx &c, Fr *z, size_t n);                     // returns the number of non-canonical scalars (zeroed)
 void dev_gather_strided(DevCtx &c, const Fr *in, size_t stride, size_t offset, Fr *out, size_t n);   // out[i] = in[i*stride + offset]
 
 std::shared_ptr<DeviceInstance> upload_instance(const Instance &I);

@@ -24,6 +24,26 @@ void dev_fill_zero(DevCtx &c, Fr *p, size_t n) { if (n) OTTI_HIP(hipMemsetAsync(
 void dev_fill_one(DevCtx &c, Fr *p, size_t n) { if (n) hipLaunchKernelGGL(k_fr_fill, grid_for(n), kBlock, 0, c.stream, p, fr_one(), n); }
 void dev_fetch(DevCtx &c, const Fr *src, int slot, size_t n) { OTTI_HIP(hipMemcpyAsync(c.h_results + slot, src, n * sizeof(Fr), hipMemcpyDeviceToHost, c.stream)); }
 
+// VarsAssignment::new on the device: canonical little-endian scalars (the caller's bytes, uploaded as they are) -> Montgomery form in
+// place; values >= l are counted (upstream: R1CSError::InvalidScalar) and left as zero.
+__global__ __launch_bounds__(kBlock) void k_witness_ingest(Fr *z, size_t n, unsigned long long *bad) {
+    unsigned mine = 0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        Fr raw = z[i];
+        if (fr_raw_is_canonical(raw.v)) z[i] = fr_mul(raw, fr_R2()); else { z[i] = fr_zero(); mine++; }
+    }
+    if (mine) atomicAdd(bad, (unsigned long long)mine);
+}
+size_t dev_witness_ingest(DevCtx &c, Fr *z, size_t n) {
+    if (!n) return 0;
+    DevBuf<unsigned long long> bad(1);
+    OTTI_HIP(hipMemsetAsync(bad.p, 0, sizeof(unsigned long long), c.stream));
+    hipLaunchKernelGGL(k_witness_ingest, grid_for(n), kBlock, 0, c.stream, z, n, bad.p);
+    unsigned long long h = 0;
+    OTTI_HIP(hipMemcpyAsync(&h, bad.p, sizeof h, hipMemcpyDeviceToHost, c.stream));
+    OTTI_HIP(hipStreamSynchronize(c.stream));
+    return (size_t)h;
+}
 __global__ __launch_bounds__(kBlock) void k_gather_strided(const Fr *in, size_t stride, size_t offset, Fr *out, size_t n) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = in[i * stride + offset];
 }

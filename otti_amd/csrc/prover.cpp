@@ -76,6 +76,21 @@ DeviceWitness::DeviceWitness(const Instance &I, const std::vector<Fr> &vars_padd
     small_fraction = dev_small_fraction(c, z.p, I.num_vars);
 }
 
+DeviceWitness::DeviceWitness(const Instance &I, const uint8_t *vars32, size_t nvars, const std::vector<Fr> &inputs_) : inputs(inputs_) {
+    DevCtx &c = DevCtx::get();
+    const size_t V = I.num_vars;
+    if (nvars > V) throw Error(OTTI_ERR_INVALID_NUM_VARS, "more variables than the instance has");
+    if (inputs.size() != I.num_inputs) throw Error(OTTI_ERR_INVALID_NUM_INPUTS, "wrong number of inputs");
+    z.alloc(2 * V);
+    OTTI_HIP(hipMemsetAsync(z.p, 0, 2 * V * sizeof(Fr), c.stream));
+    if (nvars) OTTI_HIP(hipMemcpyAsync(z.p, vars32, nvars * 32, hipMemcpyHostToDevice, c.stream));
+    std::vector<Fr> tail(1 + inputs.size()); tail[0] = fr_one();
+    for (size_t i = 0; i < inputs.size(); i++) tail[1 + i] = inputs[i];
+    OTTI_HIP(hipMemcpyAsync(z.p + V, tail.data(), tail.size() * sizeof(Fr), hipMemcpyHostToDevice, c.stream));
+    if (dev_witness_ingest(c, z.p, nvars)) throw Error(OTTI_ERR_INVALID_SCALAR, "non-canonical scalar in assignment");   // synchronises: `tail` and the caller's buffer are free again
+    small_fraction = dev_small_fraction(c, z.p, V);
+}
+
 namespace {
 // Everything the rounds of BOTH sum-checks need that depends on the random tape alone, as ONE batched fixed-base MSM: for each round
 // the four points delta_j = commit(d_vec_j, r_delta_j), blinds_poly[j]*h_n, blinds_evals[j]*h_1, r_beta_j*h_1 (extended, not

@@ -5,6 +5,7 @@
 // Additive options: --seed <hex32>, --proof-out <file>, --label <transcript label>, `spzk synth <n> <prefix>` to emit a
 // synthetic zkif triple.
 #include <stdio.h>
+#include <thread>
 #include <stdlib.h>
 #include <string.h>
 #include <string>
@@ -63,6 +64,9 @@ int main(int argc, char **argv) {
         for (int i = 0; i < 32; i++) { unsigned v; if (sscanf(seed_hex + 2 * i, "%2x", &v) != 1) return usage(); seed[i] = (uint8_t)v; }
         seedp = seed;
     }
+    // the HIP runtime takes a noticeable fraction of a second to come up: let it do so while the files are being parsed
+    std::thread warm([&] { if (!verify_only) (void)otti_device_count(); });
+    struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{warm};
     double t0 = now_ms();
     otti_r1cs *r = nullptr; int rc = otti_zkif_load(files[0], files[1], verify_only ? nullptr : files[2], &r); if (rc) return fail("zkif load", rc);
     double t_load = now_ms() - t0; t0 = now_ms();
