@@ -288,6 +288,7 @@ otti_r1cs *zkif_load_impl(const char *circuit_path, const char *inputs_path, con
     if (m.have_witness && m.witness.ids.size() != map.num_vars) throw Error(OTTI_ERR_IO, "zkif: witness does not assign every variable exactly once");
     // pass 2: constraints of the circuit file, message by message
     std::vector<otti_entry> M[3]; uint64_t row = 0;
+    for (auto &v : M) v.reserve(circuit.size() / 96);                   // about one entry per 80-90 file bytes per matrix: avoids most regrowth copies
     for_each_message(circuit, [&](uint8_t type, const Table &msg, const Buf &b) {
         if (type != 2) return;
         size_t s, n; msg.vec(0, s, n); b.chk(s, n * 4);
