@@ -23,7 +23,7 @@ static double now_ms() { return std::chrono::duration<double, std::milli>(std::c
 // fits a budget (default 128 GiB: c = 16 for R = 1024 (51.6 GB) and R = 2048 (103 GB), 15 for R = 4096 (110 GB)).  OTTI_MSM_WINDOW pins c;
 // OTTI_MSM_TABLE_GB changes the budget (one-shot callers such as spzk pick a small table: building it costs more than it saves).
 int device_window_bits(size_t nbases) {
-    if (const char *e = getenv("OTTI_MSM_WINDOW")) { int c = atoi(e); if (c >= 4 && c <= 16) return c; }
+    if (const char *e = getenv("OTTI_MSM_WINDOW")) { int c = atoi(e); if (c >= 4 && c <= 17) return c; }
     double budget_gb = 128.0;
     if (const char *e = getenv("OTTI_MSM_TABLE_GB")) { double v = atof(e); if (v > 0) budget_gb = v; }
     int best = 8;
