@@ -164,7 +164,7 @@ def main():
     oa.stats_enable(True, only=dom)
     # --concurrent B: B - 1 more prover threads (own device context each), warmed up and parked on a barrier
     # the K steps x B proofs of the timed region are handed out from one counter, so no thread idles while another still has work
-    gate, others, other_proofs, errors = threading.Barrier(conc), [], [], []
+    gate, others, other_proofs, other_stats, errors = threading.Barrier(conc), [], [], [], []
     todo, todo_lock = [conc * args.steps], threading.Lock()
 
     def take():
@@ -176,10 +176,14 @@ def main():
 
     def extra_prover():
         try:
+            oa.stats_enable(True, only=dom)                     # kernel timing state is per prover thread; its event pool is built on first use
             mine = [prove_once() for _ in range(max(1, args.warmup))]
+            oa.stats_enable(True, only=dom)                     # again: resets the counters for the timed region
             gate.wait()
             while take():
                 mine.append(prove_once())
+            other_stats.append(oa.stats_read()[dom])
+            oa.stats_enable(False)
             other_proofs.extend(mine)
         except BaseException as e:                              # noqa: BLE001 - reported after the join
             errors.append(e)
@@ -203,8 +207,10 @@ def main():
     if errors:
         raise errors[0]
     proofs += other_proofs
-    stats = oa.stats_read()
+    stats = dict(oa.stats_read())
     oa.stats_enable(False)
+    for cnt_, ms_ in other_stats:                               # the dominant kernel's launches of every prover thread in the timed region
+        stats[dom] = (stats[dom][0] + cnt_, stats[dom][1] + ms_)
 
     # correctness of what was timed
     digests = {hashlib.sha256(p.bytes).hexdigest() for p in proofs}
