@@ -391,7 +391,7 @@ def test_concurrent_provers_share_instance_and_table():
     """Several prover threads of one process (own device context each) on shared instance / generator / witness handles, plus one
     thread on a different instance: every proof must be the oracle's, whatever the interleaving on the device."""
     import threading
-    jobs = []
+    jobs, inputs_of = [], []
     for gen, n, ni in ((oa.synth_r1cs, 1 << 12, 4), (oa.synth_r1cs_compiler_like, 1 << 13, 3), (oa.synth_r1cs, 300, 2)):
         r = gen(n, ni, 11)
         inst = oa.Instance.new(r["num_cons"], r["num_vars"], r["num_inputs"], r["A"], r["B"], r["C"])
@@ -399,7 +399,7 @@ def test_concurrent_provers_share_instance_and_table():
         wit = oa.Witness(inst, oa.VarsAssignment.new(r["vars"]), oa.InputsAssignment.new(r["inputs"]))
         oi, og = orc.OInstance(r["num_cons"], r["num_vars"], r["num_inputs"], r["A"], r["B"], r["C"]), orc.OGens(r["num_cons"], r["num_vars"], r["num_inputs"])
         want, _ = orc.nizk_prove(oi, r["vars"], r["inputs"], og, b"mt", b"\x19" * 32)
-        jobs.append((inst, gens, wit, want))
+        jobs.append((inst, gens, wit, want)); inputs_of.append(oa.InputsAssignment.new(r["inputs"]))
     results, errors = [], []
 
     def run(job, reps):
@@ -417,6 +417,30 @@ def test_concurrent_provers_share_instance_and_table():
         t.join()
     assert not errors, errors
     assert len(results) == 30 and all(results)
+    # verification from several threads at once (each call fans its deferred checks out over host threads of its own)
+    verdicts = []
+
+    def check(job, tamper):
+        try:
+            inst, gens, wit, want = job
+            pf = bytearray(want)
+            if tamper:
+                pf[len(pf) // 3] ^= 1
+            try:
+                oa.NIZK(bytes(pf)).verify(inst, job_inputs[id(inst)], gens, b"mt"); verdicts.append(not tamper)
+            except oa.ProofVerifyError:
+                verdicts.append(tamper)
+        except BaseException as e:  # noqa: BLE001
+            errors.append(e)
+
+    job_inputs = {id(j[0]): inp for j, inp in zip(jobs, inputs_of)}
+    threads = [threading.Thread(target=check, args=(jobs[k % 3], k % 2 == 1)) for k in range(8)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert len(verdicts) == 8 and all(verdicts)
 
 
 @pytest.mark.parametrize("shape", ["many_vars", "many_cons", "one_var_block"])
