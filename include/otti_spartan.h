@@ -160,6 +160,49 @@ int32_t otti_k_sc_quad_fold_round(const uint8_t *h_A, const uint8_t *h_B, size_t
 /* DensePolynomial::commit_inner: L rows of R scalars -> L compressed points C_i = sum_j Z[iR+j] P[j] + blinds[i] P[R+1] */
 int32_t otti_k_msm_rows(otti_gens *gens, const uint8_t *h_Z, size_t L, size_t R, const uint8_t *h_blinds, uint8_t *h_out32, float *kernel_ms);
 
+/* ---- the kernels the prover actually launches for phase one, the evaluation proof and the bullet reduction (host pointers, as above).
+        No reference counterpart beyond the upstream functions named; these exist so that a failing proof points at a kernel. ---- */
+/* eq "pyramid": level k (eq over the LAST k of the n variables, 2^k entries) at out + 2^k - 1; n <= 13; out has 2^(n+1) - 1 entries */
+int32_t otti_k_eq_pyramid(const uint8_t *h_r, size_t n, uint8_t *h_out);
+/* prove_cubic_with_additive_term with the eq table factored out: S_t = sum_i E[i] (B_t C_t - D_t)[i], t = 0, 2, 3, over tables of
+   length len, E = EqPolynomial(h_tau[0 .. log2(len) - 1)).evals() supplied as the challenge suffix it is built from */
+int32_t otti_k_sc_cubic3_round(const uint8_t *h_B, const uint8_t *h_C, const uint8_t *h_D, size_t len, const uint8_t *h_tau, uint8_t *h_e3, float *kernel_ms);
+/* fused bound_poly_var_top(r) + the next round's S_t: tables of length len (>= 4) fold to len/2 (h_out3: 3 * len/2 elements);
+   h_tau holds the log2(len) - 2 variables E of the folded round is built from */
+int32_t otti_k_sc_cubic3_fold_round(const uint8_t *h_B, const uint8_t *h_C, const uint8_t *h_D, size_t len, const uint8_t *h_r, const uint8_t *h_tau,
+                                    uint8_t *h_out3, uint8_t *h_e3, float *kernel_ms);
+/* DensePolynomial::bound: out[j] = sum_i Lv[i] * Z[i*R + j] */
+int32_t otti_k_poly_bound(const uint8_t *h_Z, size_t L, size_t R, const uint8_t *h_Lv, uint8_t *h_out, float *kernel_ms);
+/* One BulletReductionProof::prove round on the ORIGINAL generators (k_msm.hip): state (a, b: 2*n_cur elements if fold else n_cur; s: R
+   coefficients of the original generators).  If fold, the previous challenge (u, u^-1) is applied first.  Returns compressed L, R
+   (64 bytes; blinds h_blinds2 = {blind_L, blind_R}) and the state the next round starts from (a, b: n_cur elements; s: R). */
+int32_t otti_k_bullet_round(otti_gens *gens, size_t n_cur, int32_t fold, const uint8_t *h_u, const uint8_t *h_uinv, const uint8_t *h_a, const uint8_t *h_b,
+                            const uint8_t *h_s, const uint8_t *h_blinds2, uint8_t *h_a_out, uint8_t *h_b_out, uint8_t *h_s_out, uint8_t *h_LR64, float *kernel_ms);
+/* the closing fold of the reduction (length 2 -> 1): a, b of 2 elements and s of R are folded in place by (u, u^-1) */
+int32_t otti_k_bullet_last_fold(size_t R, const uint8_t *h_u, const uint8_t *h_uinv, uint8_t *h_a2, uint8_t *h_b2, uint8_t *h_s);
+
+/* ---- the same kernels on DEVICE pointers and a caller-chosen HIP stream ("host or device pointers + a stream
+        handle"): nothing is staged through PCIe, so a kernel can be benchmarked or composed from outside the library.
+        stream: a hipStream_t passed as void* (NULL = the calling thread's library stream).  d_* = device memory holding 32-byte
+        Montgomery-form elements; h_* = small host arrays (challenges come from the transcript).  Calls that return round sums
+        (h_e*) wait for that launch's result; the others only enqueue. ---- */
+int32_t otti_kd_multiply_vec(otti_instance *inst, const void *d_z, void *d_Az, void *d_Bz, void *d_Cz, void *stream);
+int32_t otti_kd_eval_table_sparse(otti_instance *inst, const void *d_eq_rx, const uint8_t *h_rABC, void *d_out, void *stream);
+int32_t otti_kd_eq_evals(const uint8_t *h_r, size_t ell, void *d_out, void *stream);
+int32_t otti_kd_fold_top(void *d_Z, size_t len, const uint8_t *h_r, void *stream);                    /* in place: len -> len/2 */
+int32_t otti_kd_fold_bot(const void *d_Z, void *d_out, size_t len, const uint8_t *h_r, void *stream);
+int32_t otti_kd_sc_cubic_round(const void *d_A, const void *d_B, const void *d_C, const void *d_D, size_t len, uint8_t *h_e3, void *stream);
+int32_t otti_kd_sc_cubic_fold_round(void *d_A, void *d_B, void *d_C, void *d_D, size_t len, const uint8_t *h_r, uint8_t *h_e3, void *stream);   /* in place */
+int32_t otti_kd_sc_quad_round(const void *d_A, const void *d_B, size_t len, uint8_t *h_e2, void *stream);
+int32_t otti_kd_sc_quad_fold_round(void *d_A, void *d_B, size_t len, const uint8_t *h_r, uint8_t *h_e2, void *stream);                            /* in place */
+/* compressed row commitments land in d_out32 (32 * L bytes of device memory) */
+int32_t otti_kd_msm_rows(otti_gens *gens, const void *d_Z, size_t L, size_t R, const void *d_blinds, void *d_out32, void *stream);
+/* plain device memory for callers without a HIP runtime of their own (ctypes tests); hipMalloc'ed buffers of any origin work as well */
+int32_t otti_dev_alloc(size_t nbytes, void **d_out);
+int32_t otti_dev_free(void *d);
+int32_t otti_dev_upload(void *d_dst, const void *h_src, size_t nbytes);
+int32_t otti_dev_download(void *h_dst, const void *d_src, size_t nbytes);
+
 /* per-kernel-class timing with HIP events recorded on the library's own stream around every launch of that class.
    classes: msm_rows (>= 2^16 scalars per launch: the witness commitment) msm_small msm_finish sc_cubic sc_quad spmv eq reduce poly_bound bullet other.  enable(1) also resets the counters. */
 int32_t otti_stats_enable(int32_t on);

@@ -571,6 +571,38 @@ static void bullet_prove(dplog_t *pf, transcript_t *tr, const ge_t *Q, const ge_
     free(G); free(a); free(b); free(s); free(P);
 }
 
+/* The same reduction with the round challenges supplied by the caller and stopped after `rounds` rounds: what the kernel-level
+   tests compare one GPU bullet round against (L, R of every round; the folded a, b; the folded generators, compressed). */
+void orc_bullet_reduce(const orc_gens *g, const fr_t *a_in, const fr_t *b_in, size_t n, const fr_t *blinds /* (bL, bR) per round */,
+                       const fr_t *us, size_t rounds, uint8_t *LR /* 64 * rounds */, fr_t *a_out, fr_t *b_out, uint8_t *G_out32 /* n >> rounds each */) {
+    const ge_t *Q = &g->pc_1.G[0], *H = &g->pc_n.h;
+    ge_t *G = (ge_t *)malloc(n * sizeof(ge_t)); memcpy(G, g->pc_n.G, n * sizeof(ge_t));
+    fr_t *a = (fr_t *)malloc(n * sizeof(fr_t)), *b = (fr_t *)malloc(n * sizeof(fr_t));
+    memcpy(a, a_in, n * sizeof(fr_t)); memcpy(b, b_in, n * sizeof(fr_t));
+    fr_t *s = (fr_t *)malloc((n / 2 + 3) * sizeof(fr_t)); ge_t *P = (ge_t *)malloc((n / 2 + 3) * sizeof(ge_t));
+    for (size_t round = 0; round < rounds && n != 1; round++) {
+        n /= 2;
+        fr_t cL, cR, u = us[round], ui;
+        dot(&cL, a, b + n, n); dot(&cR, a + n, b, n);
+        ge_t Lp, Rp;
+        memcpy(s, a, n * sizeof(fr_t)); s[n] = cL; s[n + 1] = blinds[2 * round]; memcpy(P, G + n, n * sizeof(ge_t)); P[n] = *Q; P[n + 1] = *H;
+        ge_msm(&Lp, s, P, n + 2);
+        memcpy(s, a + n, n * sizeof(fr_t)); s[n] = cR; s[n + 1] = blinds[2 * round + 1]; memcpy(P, G, n * sizeof(ge_t)); P[n] = *Q; P[n + 1] = *H;
+        ge_msm(&Rp, s, P, n + 2);
+        ge_encode(LR + 64 * round, &Lp); ge_encode(LR + 64 * round + 32, &Rp);
+        fr_inv(&ui, &u);
+        for (size_t i = 0; i < n; i++) {
+            fr_t p, q; ge_t g0, g1;
+            fr_mul(&p, &a[i], &u); fr_mul(&q, &ui, &a[n + i]); fr_add(&a[i], &p, &q);
+            fr_mul(&p, &b[i], &ui); fr_mul(&q, &u, &b[n + i]); fr_add(&b[i], &p, &q);
+            ge_scalarmul(&g0, &G[i], &ui); ge_scalarmul(&g1, &G[n + i], &u); ge_add(&G[i], &g0, &g1);
+        }
+    }
+    memcpy(a_out, a, n * sizeof(fr_t)); memcpy(b_out, b, n * sizeof(fr_t));
+    for (size_t i = 0; i < n; i++) ge_encode(G_out32 + 32 * i, &G[i]);
+    free(G); free(a); free(b); free(s); free(P);
+}
+
 /* BulletReductionProof::verify (with verification_scalars) */
 static int bullet_verify(const dplog_t *pf, size_t n, const fr_t *a, transcript_t *tr, const ge_t *Gamma, const ge_t *G,
                          ge_t *g_hat, ge_t *Gamma_hat, fr_t *a_hat) {

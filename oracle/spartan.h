@@ -71,6 +71,9 @@ void orc_sc_cubic_evals(const fr_t *A, const fr_t *B, const fr_t *C, const fr_t 
 void orc_sc_quad_evals(const fr_t *A, const fr_t *B, size_t len, fr_t e[2]);                   /* e0,e2 of A*B */
 void orc_commit_rows(const fr_t *Z, size_t L, size_t R, const fr_t *blinds, const orc_mcgens *g, uint8_t *out /* L*32 */);
 void orc_poly_bound(const fr_t *Z, size_t L, size_t R, const fr_t *Lvec, fr_t *out /* R */);   /* DensePolynomial::bound */
+/* nizk/bullet.rs BulletReductionProof::prove, challenges given, first `rounds` rounds: (L, R) per round, folded a, b, generators */
+void orc_bullet_reduce(const orc_gens *, const fr_t *a, const fr_t *b, size_t n, const fr_t *blinds /* 2 * rounds */, const fr_t *us /* rounds */,
+                       size_t rounds, uint8_t *LR /* 64 * rounds */, fr_t *a_out, fr_t *b_out, uint8_t *G_out32 /* (n >> rounds) * 32 */);
 void orc_gens_points(const orc_gens *, uint8_t *out /* (pc_n.n + 2) * 32: G_0..G_{R-1}, gens_1.G, h */);
 
 /* byte-level helpers for ctypes tests */

@@ -108,6 +108,26 @@ _sig("otti_k_sc_cubic_fold_round", _i32, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp,
 _sig("otti_k_sc_quad_round", _i32, _vp, _vp, _sz, _vp, _fp)
 _sig("otti_k_sc_quad_fold_round", _i32, _vp, _vp, _sz, _vp, _vp, _vp, _fp)
 _sig("otti_k_msm_rows", _i32, _vp, _vp, _sz, _sz, _vp, _vp, _fp)
+_sig("otti_k_eq_pyramid", _i32, _vp, _sz, _vp)
+_sig("otti_k_sc_cubic3_round", _i32, _vp, _vp, _vp, _sz, _vp, _vp, _fp)
+_sig("otti_k_sc_cubic3_fold_round", _i32, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _fp)
+_sig("otti_k_poly_bound", _i32, _vp, _sz, _sz, _vp, _vp, _fp)
+_sig("otti_k_bullet_round", _i32, _vp, _sz, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _fp)
+_sig("otti_k_bullet_last_fold", _i32, _sz, _vp, _vp, _vp, _vp, _vp)
+_sig("otti_kd_multiply_vec", _i32, _vp, _vp, _vp, _vp, _vp, _vp)
+_sig("otti_kd_eval_table_sparse", _i32, _vp, _vp, _vp, _vp, _vp)
+_sig("otti_kd_eq_evals", _i32, _vp, _sz, _vp, _vp)
+_sig("otti_kd_fold_top", _i32, _vp, _sz, _vp, _vp)
+_sig("otti_kd_fold_bot", _i32, _vp, _vp, _sz, _vp, _vp)
+_sig("otti_kd_sc_cubic_round", _i32, _vp, _vp, _vp, _vp, _sz, _vp, _vp)
+_sig("otti_kd_sc_cubic_fold_round", _i32, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp)
+_sig("otti_kd_sc_quad_round", _i32, _vp, _vp, _sz, _vp, _vp)
+_sig("otti_kd_sc_quad_fold_round", _i32, _vp, _vp, _sz, _vp, _vp, _vp)
+_sig("otti_kd_msm_rows", _i32, _vp, _vp, _sz, _sz, _vp, _vp, _vp)
+_sig("otti_dev_alloc", _i32, _sz, ctypes.POINTER(_vp))
+_sig("otti_dev_free", _i32, _vp)
+_sig("otti_dev_upload", _i32, _vp, _vp, _sz)
+_sig("otti_dev_download", _i32, _vp, _vp, _sz)
 
 
 def _last_error():
@@ -532,3 +552,122 @@ class kernels:
         out = np.zeros((L, 32), dtype=np.uint8); ms = ctypes.c_float(0)
         _check(lib.otti_k_msm_rows(gens._h, _ptr(Z), L, R, _ptr(blinds), _ptr(out), ctypes.byref(ms)))
         return out, ms.value
+
+    # ---- the kernels the prover itself launches (phase one without the eq table, evaluation proof, bullet reduction)
+    @staticmethod
+    def eq_pyramid(r):
+        r = _scalars(r, "r"); n = r.shape[0]
+        out = np.zeros(((2 << n) - 1, 32), dtype=np.uint8)
+        _check(lib.otti_k_eq_pyramid(_ptr(r), n, _ptr(out)))
+        return out
+
+    @staticmethod
+    def sc_cubic3_round(B, C, D, tau):
+        B, C, D, tau = (_scalars(x, "t") for x in (B, C, D, tau)); e = np.zeros((3, 32), dtype=np.uint8); ms = ctypes.c_float(0)
+        assert (1 << (tau.shape[0] + 1)) == B.shape[0]
+        _check(lib.otti_k_sc_cubic3_round(_ptr(B), _ptr(C), _ptr(D), B.shape[0], _ptr(tau), _ptr(e), ctypes.byref(ms)))
+        return e, ms.value
+
+    @staticmethod
+    def sc_cubic3_fold_round(B, C, D, r, tau):
+        B, C, D, r, tau = (_scalars(x, "t") for x in (B, C, D, r, tau)); n = B.shape[0]
+        assert (1 << (tau.shape[0] + 2)) == n
+        out = np.zeros((3, n // 2, 32), dtype=np.uint8); e = np.zeros((3, 32), dtype=np.uint8); ms = ctypes.c_float(0)
+        _check(lib.otti_k_sc_cubic3_fold_round(_ptr(B), _ptr(C), _ptr(D), n, _ptr(r), _ptr(tau), _ptr(out), _ptr(e), ctypes.byref(ms)))
+        return out, e, ms.value
+
+    @staticmethod
+    def poly_bound(Z, L, R, Lv):
+        Z, Lv = _scalars(Z, "Z"), _scalars(Lv, "Lv"); assert Z.shape[0] == L * R and Lv.shape[0] == L
+        out = np.zeros((R, 32), dtype=np.uint8); ms = ctypes.c_float(0)
+        _check(lib.otti_k_poly_bound(_ptr(Z), L, R, _ptr(Lv), _ptr(out), ctypes.byref(ms)))
+        return out, ms.value
+
+    @staticmethod
+    def bullet_round(gens, n_cur, a, b, s, blinds2, u=None, uinv=None):
+        """one bullet-reduction round on the original generators; (u, uinv) given => the previous challenge is applied first"""
+        a, b, s, blinds2 = (_scalars(x, "t") for x in (a, b, s, blinds2)); R = s.shape[0]
+        fold = u is not None
+        uu = _scalars(u, "u") if fold else None; ui = _scalars(uinv, "uinv") if fold else None
+        ao, bo, so = (np.zeros((k, 32), dtype=np.uint8) for k in (n_cur, n_cur, R)); LR = np.zeros((2, 32), dtype=np.uint8); ms = ctypes.c_float(0)
+        _check(lib.otti_k_bullet_round(gens._h, n_cur, 1 if fold else 0, _ptr(uu), _ptr(ui), _ptr(a), _ptr(b), _ptr(s), _ptr(blinds2), _ptr(ao), _ptr(bo), _ptr(so),
+                                       _ptr(LR), ctypes.byref(ms)))
+        return LR, ao, bo, so, ms.value
+
+    @staticmethod
+    def bullet_last_fold(a2, b2, s, u, uinv):
+        a2, b2, s, u, uinv = (_scalars(x, "t").copy() for x in (a2, b2, s, u, uinv))
+        _check(lib.otti_k_bullet_last_fold(s.shape[0], _ptr(u), _ptr(uinv), _ptr(a2), _ptr(b2), _ptr(s)))
+        return a2[:1], b2[:1], s
+
+
+class DeviceArray:
+    """(n, 32) field elements in HBM (otti_dev_alloc): operand of the device-pointer kernel entry points (otti_kd_*)"""
+
+    def __init__(self, n, nbytes_each=32):
+        self.n, self.each = n, nbytes_each
+        p = _vp()
+        _check(lib.otti_dev_alloc(max(1, n * nbytes_each), ctypes.byref(p)))
+        self.ptr = p
+
+    @classmethod
+    def from_host(cls, a):
+        a = _scalars(a, "a"); d = cls(a.shape[0])
+        _check(lib.otti_dev_upload(d.ptr, _ptr(a), a.nbytes))
+        return d
+
+    def to_host(self, n=None):
+        n = self.n if n is None else n
+        out = np.zeros((n, self.each), dtype=np.uint8)
+        _check(lib.otti_dev_download(_ptr(out), self.ptr, out.nbytes))
+        return out
+
+    def __del__(self):
+        if getattr(self, "ptr", None):
+            lib.otti_dev_free(self.ptr); self.ptr = None
+
+
+class kernels_dev:
+    """otti_kd_*: the same kernels on device pointers and a caller's stream (None = the library's stream of this thread)"""
+
+    @staticmethod
+    def multiply_vec(inst, z, Az, Bz, Cz, stream=None):
+        _check(lib.otti_kd_multiply_vec(inst._h, z.ptr, Az.ptr, Bz.ptr, Cz.ptr, stream))
+
+    @staticmethod
+    def eval_table_sparse(inst, eq_rx, rABC, out, stream=None):
+        rABC = _scalars(rABC, "rABC"); _check(lib.otti_kd_eval_table_sparse(inst._h, eq_rx.ptr, _ptr(rABC), out.ptr, stream))
+
+    @staticmethod
+    def eq_evals(r, out, stream=None):
+        r = _scalars(r, "r"); _check(lib.otti_kd_eq_evals(_ptr(r), r.shape[0], out.ptr, stream))
+
+    @staticmethod
+    def fold_top(Z, length, r, stream=None):
+        r = _scalars(r, "r"); _check(lib.otti_kd_fold_top(Z.ptr, length, _ptr(r), stream))
+
+    @staticmethod
+    def fold_bot(Z, out, length, r, stream=None):
+        r = _scalars(r, "r"); _check(lib.otti_kd_fold_bot(Z.ptr, out.ptr, length, _ptr(r), stream))
+
+    @staticmethod
+    def sc_cubic_round(A, B, C, D, length, stream=None):
+        e = np.zeros((3, 32), dtype=np.uint8); _check(lib.otti_kd_sc_cubic_round(A.ptr, B.ptr, C.ptr, D.ptr, length, _ptr(e), stream)); return e
+
+    @staticmethod
+    def sc_cubic_fold_round(A, B, C, D, length, r, stream=None):
+        r = _scalars(r, "r"); e = np.zeros((3, 32), dtype=np.uint8)
+        _check(lib.otti_kd_sc_cubic_fold_round(A.ptr, B.ptr, C.ptr, D.ptr, length, _ptr(r), _ptr(e), stream)); return e
+
+    @staticmethod
+    def sc_quad_round(A, B, length, stream=None):
+        e = np.zeros((2, 32), dtype=np.uint8); _check(lib.otti_kd_sc_quad_round(A.ptr, B.ptr, length, _ptr(e), stream)); return e
+
+    @staticmethod
+    def sc_quad_fold_round(A, B, length, r, stream=None):
+        r = _scalars(r, "r"); e = np.zeros((2, 32), dtype=np.uint8)
+        _check(lib.otti_kd_sc_quad_fold_round(A.ptr, B.ptr, length, _ptr(r), _ptr(e), stream)); return e
+
+    @staticmethod
+    def msm_rows(gens, Z, L, R, blinds, out32, stream=None):
+        _check(lib.otti_kd_msm_rows(gens._h, Z.ptr, L, R, blinds.ptr, out32.ptr, stream))

@@ -341,6 +341,177 @@ int32_t otti_k_msm_rows(otti_gens *gens, const uint8_t *Z, size_t L, size_t R, c
     });
 }
 
+
+// ---- the prover's own kernels for phase one / evaluation proof / bullet reduction
+extern "C++" {
+namespace {
+// the two eq pyramids over m variables exactly as nizk_prove_resident lays them out (lo: last min(m,12) variables, hi: the ones before)
+struct EqPyramids {
+    DevBuf<Fr> buf; size_t n_lo = 0, n_hi = 0;
+    EqPyramids(DevCtx &c, const Fr *tau, size_t m) : buf(8192 + 16384) {
+        n_lo = std::min<size_t>(m, 12); n_hi = m - n_lo;
+        dev_eq_pyramid(c, tau + n_hi, n_lo, buf.p);
+        if (n_hi) dev_eq_pyramid(c, tau, n_hi, buf.p + 8192);
+    }
+    EqSrc top() const {                                      // E over all m variables
+        EqSrc e; const size_t m = n_lo + n_hi;
+        if (m <= n_lo) { e.hi = nullptr; e.lo = buf.p + (((size_t)1 << m) - 1); e.lo_bits = 0; }
+        else { e.hi = buf.p + 8192 + (((size_t)1 << n_hi) - 1); e.lo = buf.p + (((size_t)1 << n_lo) - 1); e.lo_bits = (int)n_lo; }
+        return e;
+    }
+};
+std::vector<Fr> fr_load_vec(const uint8_t *p, size_t n) { std::vector<Fr> v(n + 1); for (size_t i = 0; i < n; i++) v[i] = fr_load(p + 32 * i); return v; }
+struct StreamScope {                     // run the library's launch functions on a caller's stream for the duration of one call
+    DevCtx &c; hipStream_t old;
+    StreamScope(DevCtx &c_, void *s) : c(c_), old(c_.stream) { if (s) c.stream = (hipStream_t)s; }
+    ~StreamScope() { c.stream = old; }
+};
+}  // namespace
+}  // extern "C++"
+
+int32_t otti_k_eq_pyramid(const uint8_t *r, size_t n, uint8_t *out) {
+    return guarded([&] {
+        if (n > 13) throw Error(OTTI_ERR_BAD_ARG, "n > 13");
+        DevCtx &c = DevCtx::get(); std::vector<Fr> rr = fr_load_vec(r, n); const size_t total = ((size_t)2 << n) - 1;
+        DevBuf<Fr> o(total); dev_eq_pyramid(c, rr.data(), n, o.p); download(c, out, o.p, total); c.sync(); return OTTI_OK;
+    });
+}
+int32_t otti_k_sc_cubic3_round(const uint8_t *B, const uint8_t *C, const uint8_t *D, size_t len, const uint8_t *tau, uint8_t *e3, float *ms) {
+    return guarded([&] {
+        if (len < 2 || (len & (len - 1))) throw Error(OTTI_ERR_BAD_ARG, "len must be a power of two >= 2");
+        DevCtx &c = DevCtx::get(); Staged b(c, B, len), cc(c, C, len), d(c, D, len);
+        const size_t m = ilog2(len) - 1; std::vector<Fr> t = fr_load_vec(tau, m); EqPyramids py(c, t.data(), m);
+        KTimer tm(c, ms); auto tk = dev_sc_cubic3_eval(c, b.d.p, cc.d.p, d.d.p, len, py.top(), 0); tm.stop();
+        c.wait_ticket(tk); memcpy(e3, c.h_results, 96); c.sync(); return OTTI_OK;
+    });
+}
+int32_t otti_k_sc_cubic3_fold_round(const uint8_t *B, const uint8_t *C, const uint8_t *D, size_t len, const uint8_t *r, const uint8_t *tau,
+                                    uint8_t *out3, uint8_t *e3, float *ms) {
+    return guarded([&] {
+        if (len < 4 || (len & (len - 1))) throw Error(OTTI_ERR_BAD_ARG, "len must be a power of two >= 4");
+        DevCtx &c = DevCtx::get(); Staged b(c, B, len), cc(c, C, len), d(c, D, len);
+        const size_t m = ilog2(len) - 2; std::vector<Fr> t = fr_load_vec(tau, m); EqPyramids py(c, t.data(), m);
+        KTimer tm(c, ms); auto tk = dev_sc_cubic3_fold_eval(c, b.d.p, cc.d.p, d.d.p, len, fr_load(r), py.top(), 0); tm.stop();
+        const size_t h = len / 2;
+        download(c, out3, b.d.p, h); download(c, out3 + 32 * h, cc.d.p, h); download(c, out3 + 64 * h, d.d.p, h);
+        c.sync(); c.wait_ticket(tk); memcpy(e3, c.h_results, 96); return OTTI_OK;
+    });
+}
+int32_t otti_k_poly_bound(const uint8_t *Z, size_t L, size_t R, const uint8_t *Lv, uint8_t *out, float *ms) {
+    return guarded([&] {
+        if (!L || !R) throw Error(OTTI_ERR_BAD_ARG, "empty matrix");
+        DevCtx &c = DevCtx::get(); Staged z(c, Z, L * R), lv(c, Lv, L); DevBuf<Fr> o(R), scratch(64 * R);
+        KTimer tm(c, ms); dev_poly_bound(c, z.d.p, L, R, lv.d.p, o.p, scratch.p); tm.stop();
+        download(c, out, o.p, R); c.sync(); return OTTI_OK;
+    });
+}
+int32_t otti_k_bullet_round(otti_gens *gens, size_t n_cur, int32_t fold, const uint8_t *u, const uint8_t *uinv, const uint8_t *a, const uint8_t *b,
+                            const uint8_t *s, const uint8_t *blinds2, uint8_t *a_out, uint8_t *b_out, uint8_t *s_out, uint8_t *LR64, float *ms) {
+    return guarded([&] {
+        DevCtx &c = DevCtx::get(); Gens &g = *gens->g; ensure_gens_device(g);
+        const size_t R = g.R;
+        if (n_cur < 2 || n_cur > R || (n_cur & (n_cur - 1))) throw Error(OTTI_ERR_BAD_ARG, "n_cur must be a power of two in [2, R]");
+        const size_t n_in = fold ? 2 * n_cur : n_cur;
+        if (n_in > R) throw Error(OTTI_ERR_BAD_ARG, "folding needs 2 * n_cur <= R");
+        Staged A(c, a, n_in), B(c, b, n_in), S(c, s, R); DevBuf<Fr> Ao(R), Bo(R), So(R), ex(4);
+        Fr exh[4] = {fr_zero(), fr_load(blinds2), fr_zero(), fr_load(blinds2 + 32)};
+        OTTI_HIP(hipMemcpyAsync(ex.p, exh, sizeof exh, hipMemcpyHostToDevice, c.stream));
+        OTTI_HIP(hipMemcpyAsync(So.p, S.d.p, R * sizeof(Fr), hipMemcpyDeviceToDevice, c.stream));   // slots this round does not walk keep their value
+        c.ensure_points(2, 128);
+        const uint32_t qh[2] = {g.pc_1.G[0], g.pc_n.h};
+        const Fr uu = fold ? fr_load(u) : fr_zero(), ui = fold ? fr_load(uinv) : fr_zero();
+        KTimer tm(c, ms);
+        auto tk = dev_bullet_round(c, *g.dev, R, n_cur, fold != 0, uu, ui, A.d.p, B.d.p, S.d.p, Ao.p, Bo.p, So.p, ex.p, qh);
+        tm.stop();
+        c.wait_points(tk); memcpy(LR64, c.h_points, 64);
+        download(c, a_out, Ao.p, n_cur); download(c, b_out, Bo.p, n_cur); download(c, s_out, So.p, R); c.sync(); return OTTI_OK;
+    });
+}
+int32_t otti_k_bullet_last_fold(size_t R, const uint8_t *u, const uint8_t *uinv, uint8_t *a2, uint8_t *b2, uint8_t *s) {
+    return guarded([&] {
+        if (R < 2) throw Error(OTTI_ERR_BAD_ARG, "R < 2");
+        DevCtx &c = DevCtx::get(); Staged A(c, a2, 2), B(c, b2, 2), S(c, s, R); DevBuf<Fr> rows(2 * R), ex(4);
+        dev_bullet_step(c, A.d.p, B.d.p, S.d.p, R, 1, true, fr_load(u), fr_load(uinv), rows.p, ex.p);
+        download(c, a2, A.d.p, 1); download(c, b2, B.d.p, 1); download(c, s, S.d.p, R); c.sync(); return OTTI_OK;
+    });
+}
+
+// ---- device pointers + caller's stream
+static const Fr *dfr(const void *p) { return reinterpret_cast<const Fr *>(p); }
+static Fr *dfr(void *p) { return reinterpret_cast<Fr *>(p); }
+int32_t otti_dev_alloc(size_t nbytes, void **out) { return guarded([&] { if (!out) throw Error(OTTI_ERR_BAD_ARG, "null argument"); DevCtx::get(); OTTI_HIP(hipMalloc(out, std::max<size_t>(nbytes, 1))); return OTTI_OK; }); }
+int32_t otti_dev_free(void *d) { return guarded([&] { if (d) OTTI_HIP(hipFree(d)); return OTTI_OK; }); }
+int32_t otti_dev_upload(void *d, const void *h, size_t n) { return guarded([&] { DevCtx::get(); if (n) OTTI_HIP(hipMemcpy(d, h, n, hipMemcpyHostToDevice)); return OTTI_OK; }); }
+int32_t otti_dev_download(void *h, const void *d, size_t n) { return guarded([&] { DevCtx::get(); if (n) OTTI_HIP(hipMemcpy(h, d, n, hipMemcpyDeviceToHost)); return OTTI_OK; }); }
+int32_t otti_kd_multiply_vec(otti_instance *inst, const void *z, void *Az, void *Bz, void *Cz, void *stream) {
+    return guarded([&] {
+        if (!inst || !z || !Az || !Bz || !Cz) throw Error(OTTI_ERR_BAD_ARG, "null argument");
+        DevCtx &c = DevCtx::get(); Instance &I = *inst->I; ensure_instance_device(I); StreamScope ss(c, stream);
+        dev_spmv3(c, I.dev->by_row, dfr(z), dfr(Az), dfr(Bz), dfr(Cz), false, nullptr); return OTTI_OK;
+    });
+}
+int32_t otti_kd_eval_table_sparse(otti_instance *inst, const void *eq_rx, const uint8_t *rABC, void *out, void *stream) {
+    return guarded([&] {
+        if (!inst || !eq_rx || !rABC || !out) throw Error(OTTI_ERR_BAD_ARG, "null argument");
+        DevCtx &c = DevCtx::get(); Instance &I = *inst->I; ensure_instance_device(I); StreamScope ss(c, stream);
+        Fr coef[3] = {fr_load(rABC), fr_load(rABC + 32), fr_load(rABC + 64)};
+        dev_spmv3(c, I.dev->by_col, dfr(eq_rx), dfr(out), nullptr, nullptr, true, coef); return OTTI_OK;
+    });
+}
+int32_t otti_kd_eq_evals(const uint8_t *r, size_t ell, void *out, void *stream) {
+    return guarded([&] {
+        if (ell > 25 || !out) throw Error(OTTI_ERR_BAD_ARG, "ell > 25 or null output");
+        DevCtx &c = DevCtx::get(); StreamScope ss(c, stream); std::vector<Fr> rr = fr_load_vec(r, ell);
+        DevBuf<Fr> s(5 * 4096);
+        dev_eq_evals(c, rr.data(), ell, dfr(out), s.p);
+        OTTI_HIP(hipStreamSynchronize(c.stream));                // the scratch tables are freed on return
+        return OTTI_OK;
+    });
+}
+int32_t otti_kd_fold_top(void *Z, size_t len, const uint8_t *r, void *stream) {
+    return guarded([&] { DevCtx &c = DevCtx::get(); StreamScope ss(c, stream); dev_fold_top(c, dfr(Z), len, fr_load(r)); return OTTI_OK; });
+}
+int32_t otti_kd_fold_bot(const void *Z, void *out, size_t len, const uint8_t *r, void *stream) {
+    return guarded([&] { DevCtx &c = DevCtx::get(); StreamScope ss(c, stream); dev_fold_bot(c, dfr(Z), dfr(out), len, fr_load(r)); return OTTI_OK; });
+}
+int32_t otti_kd_sc_cubic_round(const void *A, const void *B, const void *C, const void *D, size_t len, uint8_t *e3, void *stream) {
+    return guarded([&] {
+        DevCtx &c = DevCtx::get(); StreamScope ss(c, stream);
+        auto tk = dev_sc_cubic_eval(c, dfr(A), dfr(B), dfr(C), dfr(D), len, 0); c.wait_ticket(tk); memcpy(e3, c.h_results, 96); return OTTI_OK;
+    });
+}
+int32_t otti_kd_sc_cubic_fold_round(void *A, void *B, void *C, void *D, size_t len, const uint8_t *r, uint8_t *e3, void *stream) {
+    return guarded([&] {
+        DevCtx &c = DevCtx::get(); StreamScope ss(c, stream);
+        auto tk = dev_sc_cubic_fold_eval(c, dfr(A), dfr(B), dfr(C), dfr(D), len, fr_load(r), 0); c.wait_ticket(tk); memcpy(e3, c.h_results, 96); return OTTI_OK;
+    });
+}
+int32_t otti_kd_sc_quad_round(const void *A, const void *B, size_t len, uint8_t *e2, void *stream) {
+    return guarded([&] {
+        DevCtx &c = DevCtx::get(); StreamScope ss(c, stream);
+        auto tk = dev_sc_quad_eval(c, dfr(A), dfr(B), len, 0); c.wait_ticket(tk); memcpy(e2, c.h_results, 64); return OTTI_OK;
+    });
+}
+int32_t otti_kd_sc_quad_fold_round(void *A, void *B, size_t len, const uint8_t *r, uint8_t *e2, void *stream) {
+    return guarded([&] {
+        DevCtx &c = DevCtx::get(); StreamScope ss(c, stream);
+        auto tk = dev_sc_quad_fold_eval(c, dfr(A), dfr(B), len, fr_load(r), 0); c.wait_ticket(tk); memcpy(e2, c.h_results, 64); return OTTI_OK;
+    });
+}
+int32_t otti_kd_msm_rows(otti_gens *gens, const void *Z, size_t L, size_t R, const void *blinds, void *out32, void *stream) {
+    return guarded([&] {
+        if (!gens || !Z || !blinds || !out32 || !L) throw Error(OTTI_ERR_BAD_ARG, "null argument");
+        DevCtx &c = DevCtx::get(); Gens &g = *gens->g;
+        if (R != g.R) throw Error(OTTI_ERR_BAD_ARG, "row length differs from the generator count");
+        ensure_gens_device(g); StreamScope ss(c, stream);
+        uint32_t hb = g.pc_n.h;
+        dev_msm_rows(c, *g.dev, dfr(Z), R, R, L, dfr(blinds), &hb, 1, MSM_COMPRESSED, nullptr, false);
+        if (L > kHostEncodeRows) OTTI_HIP(hipMemcpyAsync(out32, c.d_points.p, 32 * L, hipMemcpyDeviceToDevice, c.stream));
+        else { c.sync(); OTTI_HIP(hipMemcpyAsync(out32, c.h_points, 32 * L, hipMemcpyHostToDevice, c.stream)); OTTI_HIP(hipStreamSynchronize(c.stream)); }
+        return OTTI_OK;
+    });
+}
+
 // ------------------------------------------------------------------------------------------------ kernel timing (HIP events on the library stream)
 static const char *kClassNames[KC_COUNT] = {"msm_rows", "msm_small", "msm_finish", "sc_cubic", "sc_quad", "spmv", "eq", "reduce", "poly_bound", "bullet", "other"};
 int32_t otti_stats_enable(int32_t on) { KStats::get().on = on != 0; KStats::get().mask = 0xffffffffu; KStats::get().reset(); return OTTI_OK; }

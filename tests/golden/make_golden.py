@@ -97,7 +97,17 @@ def main():
     import otti_amd as oa
     import orc
     proofs = []
-    for n, ni in ((2, 0), (4, 1), (16, 3), (64, 10), (1 << 10, 10), (1 << 12, 10), (1 << 14, 10)):
+    sizes = [(2, 0), (4, 1), (16, 3), (64, 10), (1 << 10, 10), (1 << 12, 10), (1 << 14, 10)]
+    # BASELINE.json's sweep sizes (configs[1], the 2^20 headline, 2^22, and configs[4]'s 2^24): minutes of oracle time and ~20 GB of
+    # host memory at 2^24, so only with --large; without it the entries already in proofs.json are kept as they are
+    large = [(1 << 16, 10), (1 << 18, 10), (1 << 20, 10), (1 << 22, 10), (1 << 24, 10)]
+    path = os.path.join(HERE, "proofs.json")
+    keep = []
+    if "--large" in sys.argv:
+        sizes += large
+    elif os.path.exists(path):
+        keep = [e for e in json.load(open(path)) if (e["n"], e["num_inputs"]) in large]
+    for n, ni in sizes:
         r = oa.synth_r1cs(n, ni, 1)
         oinst = orc.OInstance(r["num_cons"], r["num_vars"], r["num_inputs"], r["A"], r["B"], r["C"])
         ogens = orc.OGens(r["num_cons"], r["num_vars"], r["num_inputs"])
@@ -107,8 +117,10 @@ def main():
                        "proof_sha256": hashlib.sha256(pf).hexdigest(),
                        "witness_sha256": hashlib.sha256(r["vars"].tobytes() + r["inputs"].tobytes()).hexdigest(),
                        "matrices_sha256": hashlib.sha256(r["A"].tobytes() + r["B"].tobytes() + r["C"].tobytes()).hexdigest()})
-    with open(os.path.join(HERE, "proofs.json"), "w") as f:
-        json.dump(proofs, f, indent=1)
+        print("oracle proof 2^%d done" % (n.bit_length() - 1), flush=True)
+        del r, oinst, ogens, pf
+    with open(path, "w") as f:
+        json.dump(proofs + keep, f, indent=1)
     print("wrote primitives.json, proofs.json")
 
 

@@ -50,6 +50,7 @@ lib.orc_sc_quad_evals.argtypes = [_vp, _vp, _sz, _vp]
 lib.orc_commit_rows.argtypes = [_vp, _sz, _sz, _vp, _vp, _vp]
 lib.orc_poly_bound.argtypes = [_vp, _sz, _sz, _vp, _vp]
 lib.orc_set_threads.argtypes = [ctypes.c_int]
+lib.orc_bullet_reduce.argtypes = [_vp, _vp, _vp, _sz, _vp, _vp, _sz, _vp, _vp, _vp, _vp]
 
 
 def _p(a):
@@ -167,6 +168,16 @@ def commit_rows(gens, Z, L, R, blinds):
 def poly_bound(Z, L, R, Lv):
     Z, Lv = _c(Z), _c(Lv); out = np.zeros((R, 32), dtype=np.uint8)
     lib.orc_poly_bound(_p(Z), L, R, _p(Lv), _p(out)); return out
+
+
+def bullet_reduce(gens, a, b, blinds, us):
+    """nizk/bullet.rs reduction with the challenges `us` given; blinds: (2 * rounds, 32) as (bL, bR) per round.
+    Returns (LR (rounds, 2, 32), a', b', compressed folded generators)."""
+    a, b, blinds, us = _c(a), _c(b), _c(blinds), _c(us); n, rounds = a.shape[0], us.shape[0]
+    LR = np.zeros((rounds, 2, 32), dtype=np.uint8); m = n >> rounds
+    ao, bo, G = (np.zeros((m, 32), dtype=np.uint8) for _ in range(3))
+    lib.orc_bullet_reduce(gens.h, _p(a), _p(b), n, _p(blinds), _p(us), rounds, _p(LR), _p(ao), _p(bo), _p(G))
+    return LR, ao, bo, G
 
 
 def fr_from_ints(xs):

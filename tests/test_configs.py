@@ -112,3 +112,36 @@ def test_config4_large_instance_sharded_with_per_round_exchange(tmp_path):
     orc.set_threads(min(16, os.cpu_count() or 1))
     _, _, want = _oracle(oa.synth_r1cs(1 << 22, 10, 5), WLABEL, WSEED)
     assert proofs[0] == want
+
+
+def _golden(n):
+    import json
+    for e in json.load(open(os.path.join(HERE, "golden", "proofs.json"))):
+        if e["n"] == n and e["num_inputs"] == 10:
+            return e
+    raise KeyError(n)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lg", [16, 18, 20, 22, 24])
+def test_sweep_sizes_on_one_gpu_match_the_oracles_committed_digests(lg):
+    """BASELINE.json's sweep (2^18 .. 2^24; configs[1] and configs[4]'s size) at FULL size on one MI355X.  The oracle's proof of
+    each size was made once in the build container (tests/golden/make_golden.py --large; minutes of CPU time at 2^24) and is pinned
+    by length + SHA-256; the instance generator is pinned the same way, so a digest mismatch cannot hide behind a different input."""
+    import gc
+    want = _golden(1 << lg)
+    r = oa.synth_r1cs(1 << lg, 10, 1)
+    assert hashlib.sha256(r["vars"].tobytes() + r["inputs"].tobytes()).hexdigest() == want["witness_sha256"]
+    assert hashlib.sha256(r["A"].tobytes() + r["B"].tobytes() + r["C"].tobytes()).hexdigest() == want["matrices_sha256"]
+    inst = oa.Instance.new(r["num_cons"], r["num_vars"], r["num_inputs"], r["A"], r["B"], r["C"])
+    gens = oa.NIZKGens.new(r["num_cons"], r["num_vars"], r["num_inputs"])
+    inputs = oa.InputsAssignment.new(r["inputs"])
+    p = oa.NIZK.prove(inst, oa.VarsAssignment.new(r["vars"]), inputs, gens, LABEL, SEED)
+    assert len(p.bytes) == want["proof_len"]
+    assert hashlib.sha256(p.bytes).hexdigest() == want["proof_sha256"]
+    p.verify(inst, inputs, gens, LABEL)
+    bad = bytearray(p.bytes); bad[len(bad) // 3] ^= 1
+    with pytest.raises(oa.ProofVerifyError):
+        oa.NIZK(bytes(bad)).verify(inst, inputs, gens, LABEL)
+    del inst, gens, p, r                                        # the generator window table of the large sizes is ~100 GB of HBM
+    gc.collect()
