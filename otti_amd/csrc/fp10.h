@@ -168,6 +168,59 @@ __device__ __forceinline__ P10 p10_add(const P10 &p, const P10 &q, const F10 &d2
 }
 __device__ __forceinline__ N10 n10_negate(const N10 &q) { N10 r; r.yplusx = q.yminusx; r.yminusx = q.yplusx; r.xy2d = f10_carry(f10_neg(q.xy2d)); return r; }
 
+// ------------------------------------------------------------------------------------------------ quad-parallel point arithmetic
+// The latency-bound launches (one/two-row MSMs of the evaluation proof, blinding commitments) have far fewer point additions in
+// flight than the chip has lanes, and a dependent chain of full additions on one lane costs ~3 us per tree level (nine f10_mul,
+// issue-bound at ~0.28 us each for a lone wave).  Here the FOUR lanes of a quad (lane & 3) hold X, Y, Z, T of ONE point and share
+// every addition: each of the formula's two rounds of four independent multiplications becomes ONE f10_mul wave instruction stream
+// (lane k computes product k), with the operands exchanged by DPP quad permutes.  A unified addition is then 2 multiplication
+// depths (mixed: the table's Niels entry is already in "cached" form) or 3 (the cached form of the right operand first), instead
+// of 7 / 9.  Same formulas as p10_madd / p10_add (add-2008-hwcd-3, a = -1), so the same group element comes out.
+//   u(P)  = (Y - X, Y + X, T, Z)                on lanes (0, 1, 2, 3)
+//   v(P)  = (Y - X, Y + X, 2d T, 2 Z)           the cached form; a Niels entry (yminusx, yplusx, xy2d) with 2 on lane 3 is v of an affine point
+//   P + Q = stage2(u(P) * v(Q))                 lane-wise product = (A, B, C, D);  E = B - A, H = B + A, F = D - C, G = D + C;
+//                                               X = E F, Y = G H, Z = F G, T = E H
+#define F10_QP(a, b, c, d) ((a) | ((b) << 2) | ((c) << 4) | ((d) << 6))
+template <int kCtrl> __device__ __forceinline__ F10 f10_quad_perm(const F10 &a) {
+    F10 r;
+#pragma unroll
+    for (int i = 0; i < 10; i++) r.v[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a.v[i], kCtrl, 0xf, 0xf, true);
+    return r;
+}
+__device__ __forceinline__ F10 f10_select(bool c, const F10 &a, const F10 &b) { F10 r; for (int i = 0; i < 10; i++) r.v[i] = c ? a.v[i] : b.v[i]; return r; }
+// q = lane & 3 throughout.  Identity: (0, 1, 1, 0).
+__device__ __forceinline__ F10 q10_identity(int q) { F10 r = f10_zero(); r.v[0] = (q == 1 || q == 2) ? 1u : 0u; return r; }
+__device__ __forceinline__ F10 q10_u(const F10 &own, int q) {
+    const F10 s = f10_quad_perm<F10_QP(1, 0, 3, 2)>(own);                        // lanes 0/1 swap X and Y, lanes 2/3 swap Z and T
+    const F10 sum = f10_add(own, s), diff = f10_sub(s, own);                     // lane 0: Y - X (own = X is reduced); lane 1: Y + X
+    return q < 2 ? f10_select(q & 1, sum, diff) : s;
+}
+__device__ __forceinline__ F10 q10_cached(const F10 &u, int q, const F10 &d2) {  // u(P) -> v(P): lane 2 times 2d, lane 3 doubled
+    const F10 w = f10_mul(u, d2), dbl = f10_add(u, u);
+    return q == 2 ? w : (q == 3 ? dbl : u);
+}
+// acc + (the point whose cached form is v), given ua = q10_u(acc) (so that a caller can form it before it waits for v);
+// acc coordinates reduced, v limbs < 2^27.7.  Output reduced.
+__device__ __forceinline__ F10 q10_add_cached_u(const F10 &ua, const F10 &v, int q) {
+    const F10 prod = f10_mul(ua, v);                                             // lanes: A, B, C, D
+    const F10 s = f10_quad_perm<F10_QP(1, 0, 3, 2)>(prod);
+    const F10 r = f10_select(q & 1, f10_add(prod, s), f10_sub(s, prod));         // lanes: E = B - A, H = B + A, F = D - C, G = D + C
+    const F10 fa = f10_quad_perm<F10_QP(2, 3, 3, 0)>(r);                         // lanes get: F, G, G, E
+    const F10 fb = f10_quad_perm<F10_QP(0, 1, 2, 1)>(r);                         // lanes get: E, H, F, H
+    // X = F E, Y = G H, Z = F G, T = H E   (first operand may reach 2^28, second stays below 2^27.7)
+    return f10_mul(q < 2 ? fa : fb, q < 2 ? r : fa);
+}
+__device__ __forceinline__ F10 q10_add_cached(const F10 &acc, const F10 &v, int q) { return q10_add_cached_u(q10_u(acc, q), v, q); }
+// the lane's share of a table entry in cached form, negated when the digit is negative: lane 0 yminusx, lane 1 yplusx (swapped for
+// a negative digit), lane 2 xy2d (negated), lane 3 the constant 2
+__device__ __forceinline__ F10 q10_load_niels(const Niels *e, bool neg, int q) {
+    if (q == 3) { F10 two = f10_zero(); two.v[0] = 2; return two; }
+    const Fp *comp = reinterpret_cast<const Fp *>(e) + (q == 2 ? 2 : (((q == 0) != neg) ? 1 : 0));   // Niels = {yplusx, yminusx, xy2d}
+    F10 v = f10_unpack(*comp);
+    if (q == 2 && neg) v = f10_carry(f10_neg(v));
+    return v;
+}
+
 // a^(2^252-3), the (p-5)/8 power of RFC 9496's SQRT_RATIO_M1
 __device__ __forceinline__ F10 f10_pow22523(const F10 &a) {
     F10 z2 = f10_sqr(a), z9 = f10_mul(f10_sqr_n(z2, 2), a), z11 = f10_mul(z9, z2);

@@ -16,7 +16,10 @@ static_assert(kMsmMaxChunk + 8 <= 2048, "work-list entries pack the term index i
 // Bullet-reduction round fused into the MSM launch: the scalars of rows L (0) and R (1) are not read from memory but derived in phase 1
 // from the round state (a, b: the two folded vectors; s: coefficients of the original generators), after applying the previous
 // round's challenge.  State is ping-ponged (read *_in, write *_out) so that no workgroup of the launch reads what another one writes.
-struct BulletArgs { int on, fold; uint32_t n; const Fr *a_in, *b_in, *s_in; Fr *a_out, *b_out, *s_out; Fr u, uinv; };
+// The latency-bound kernel runs its scalar preparation exactly once per launch, from a cold instruction cache: two dozen inlined
+// copies of the 250-instruction Montgomery product cost more in instruction fetch than in arithmetic.  One shared copy instead.
+__device__ __attribute__((noinline)) Fr fr_mul_shared(Fr a, Fr b) { return fr_mul(a, b); }
+struct BulletArgs { int on, fold; uint32_t n; const Fr *a_in, *b_in, *s_in; Fr *a_out, *b_out, *s_out; Fr u, uinv, u_raw, uinv_raw; };
 struct MsmArgs {
     const Niels *table; int c, W; uint32_t E; int lanes;            // lanes = 256 / W term lanes
     const Fr *dense; size_t stride, n_dense; uint32_t chunk, nchunks;
@@ -27,23 +30,38 @@ struct MsmArgs {
     // row sums to pinned host memory, then raises the host flag — no finish launch, no copy, no stream synchronise
     int fuse; uint32_t rows; unsigned *counter; Pt *host_pts; unsigned long long *host_flag; unsigned long long seq;
     BulletArgs bul;
+    unsigned long long *stamps;                                     // OTTI_MSM_STAMPS: s_memrealtime (100 MHz) at the phase boundaries of k_msm_small
 };
-__device__ __forceinline__ Fr bullet_fold_a(const BulletArgs &U, size_t x) { return U.fold ? fr_add(fr_mul(U.a_in[x], U.u), fr_mul(U.uinv, U.a_in[U.n + x])) : U.a_in[x]; }
-__device__ __forceinline__ Fr bullet_fold_b(const BulletArgs &U, size_t x) { return U.fold ? fr_add(fr_mul(U.b_in[x], U.uinv), fr_mul(U.u, U.b_in[U.n + x])) : U.b_in[x]; }
+__device__ __forceinline__ Fr bullet_fold_a(const BulletArgs &U, size_t x) { return U.fold ? fr_add(fr_mul_shared(U.a_in[x], U.u), fr_mul_shared(U.uinv, U.a_in[U.n + x])) : U.a_in[x]; }
+__device__ __forceinline__ Fr bullet_fold_b(const BulletArgs &U, size_t x) { return U.fold ? fr_add(fr_mul_shared(U.b_in[x], U.uinv), fr_mul_shared(U.u, U.b_in[U.n + x])) : U.b_in[x]; }
 // Row L only has non-zero scalars on the generator slots of the upper half of every length-n block, row R on the lower half: a
 // bullet launch therefore walks R/2 "active" terms per row; term t of row `row` sits on generator j = (t / h) * n + (t mod h) + (row == 0 ? h : 0).
 __device__ __forceinline__ size_t bullet_slot(const BulletArgs &U, size_t row, size_t t) {
     const size_t n = U.n, h = n / 2;
     return (t / h) * n + (t % h) + (row == 0 ? h : 0);
 }
-__device__ __forceinline__ Fr bullet_fold_s(const BulletArgs &U, size_t j) { return U.fold ? fr_mul(U.s_in[j], ((j & (2 * (size_t)U.n - 1)) < U.n) ? U.uinv : U.u) : U.s_in[j]; }
-// kKind = MSM_BULK: the bulk launches (a commitment: many rows, every workgroup a full chunk) — no bullet bookkeeping, no fused finish.
+__device__ __forceinline__ Fr bullet_fold_s(const BulletArgs &U, size_t j) { return U.fold ? fr_mul_shared(U.s_in[j], ((j & (2 * (size_t)U.n - 1)) < U.n) ? U.uinv : U.u) : U.s_in[j]; }
+// s' = raw(s) + K with K = sum_w 2^(c-1+cw): nine words per scalar; window w of s' minus 2^(c-1) is the signed digit of window w
+__device__ __forceinline__ void recode_scalar(uint32_t *dst9, const Fr &sc, const uint32_t (&K)[9]) {
+    const Fr raw = fr_to_raw(sc);
+    uint64_t cy = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { cy += (uint64_t)raw.v[i] + K[i]; dst9[i] = (uint32_t)cy; cy >>= 32; }
+    dst9[8] = (uint32_t)cy + K[8];
+}
+__device__ __forceinline__ int recoded_digit(const uint32_t *src9, int w, int c) {
+    const int pos = w * c, limb = pos >> 5, off = pos & 31;
+    uint64_t x = src9[limb];
+    if (limb < 8) x |= (uint64_t)src9[limb + 1] << 32;
+    return (int)((uint32_t)(x >> off) & ((1u << c) - 1u)) - (1 << (c - 1));
+}
+// kKind = MSM_BULK: the bulk launches (a commitment: many rows, every workgroup a full chunk).
 // kKind = MSM_BULK_SPARSE: the same for scalars that are mostly small numbers (compacted work list, see phase 2).
-// kKind = MSM_SMALL: the one/two-row launches of the evaluation proof, latency-bound, with both.  Separate instantiations also keep them
-// apart in profiles (k_msm_rows<false> is the kernel bench.py's roofline object is about).
+// The one/two-row and tiny-row launches (evaluation proof, blinding commitments) go to k_msm_small below: they are latency-bound and
+// organised differently.  Separate kernels also keep them apart in profiles (k_msm_rows<0> is the witness commitment).
 enum { MSM_BULK = 0, MSM_SMALL = 1, MSM_BULK_SPARSE = 2 };
 template <int kKind> __global__ __launch_bounds__(kBlock) void k_msm_rows(MsmArgs A) {
-    constexpr bool kSmall = kKind == MSM_SMALL;
+    static_assert(kKind == MSM_BULK || kKind == MSM_BULK_SPARSE, "small launches use k_msm_small");
     // the recoded scalars (phases 1-2) and the reduction tree (phase 3) never live at the same time: one LDS region for both
     constexpr size_t kRawBytes = ((kKind == MSM_BULK_SPARSE ? kMsmBulkChunk : kMsmMaxChunk) + 8) * 9 * sizeof(uint32_t), kTreeBytes = (kBlock / 2) * sizeof(P10);
     __shared__ __attribute__((aligned(16))) unsigned char s_mem[kRawBytes > kTreeBytes ? kRawBytes : kTreeBytes];
@@ -55,39 +73,9 @@ template <int kKind> __global__ __launch_bounds__(kBlock) void k_msm_rows(MsmArg
     const uint32_t n_here = (uint32_t)min((size_t)A.chunk, A.n_dense - j0);
     const uint32_t n_ex = chunk_id == 0 ? (uint32_t)A.n_extra : 0u;
     // ---- phase 1: recoded scalars into LDS
-    __shared__ Fr s_dot;                                       // bullet mode: c_L / c_R of this row (chunk 0 only)
-    const bool bullet = kSmall && A.bul.on;
-    if (bullet) {
-        const BulletArgs &U = A.bul; const size_t n = U.n, h = n / 2;
-        // persist the folded state for the next round, each element written once: a and b by the row-0 workgroups, s by whichever
-        // row walks that generator slot
-        if (row == 0) {
-            const size_t cx = (n + gridDim.x - 1) / gridDim.x, x0 = (size_t)chunk_id * cx;
-            for (size_t x = x0 + threadIdx.x; x < min(n, x0 + cx); x += blockDim.x) { U.a_out[x] = bullet_fold_a(U, x); U.b_out[x] = bullet_fold_b(U, x); }
-        }
-        for (uint32_t t = threadIdx.x; t < n_here; t += blockDim.x) { const size_t j = bullet_slot(U, row, j0 + t); U.s_out[j] = bullet_fold_s(U, j); }
-        if (chunk_id == 0) {                                   // c_L = <a_L, b_R> (row 0), c_R = <a_R, b_L> (row 1)
-            Fr acc[1] = {fr_zero()};
-            for (size_t x = threadIdx.x; x < h; x += blockDim.x)
-                acc[0] = fr_add(acc[0], row == 0 ? fr_mul(bullet_fold_a(U, x), bullet_fold_b(U, h + x)) : fr_mul(bullet_fold_a(U, h + x), bullet_fold_b(U, x)));
-            block_reduce<1>(acc);
-            if (threadIdx.x == 0) s_dot = acc[0];
-            __syncthreads();
-        }
-    }
     for (uint32_t t = threadIdx.x; t < n_here + n_ex; t += blockDim.x) {
-        Fr sc;
-        if (t >= n_here) sc = (bullet && t == n_here) ? s_dot : A.extra_s[row * A.n_extra + (t - n_here)];
-        else if (bullet) {
-            const BulletArgs &U = A.bul; const size_t j = bullet_slot(U, row, j0 + t), n = U.n, h = n / 2, i = j & (n - 1);
-            // L = <a_L, G_R>: generator slots of the upper half, paired with a[i - h];  R = <a_R, G_L>: lower half with a[i + h]
-            sc = fr_mul(bullet_fold_a(U, row == 0 ? i - h : i + h), bullet_fold_s(U, j));
-        } else sc = A.dense[row * A.stride + j0 + t];
-        Fr raw = fr_to_raw(sc);
-        uint64_t cy = 0;
-#pragma unroll
-        for (int i = 0; i < 8; i++) { cy += (uint64_t)raw.v[i] + A.K[i]; s_raw[t * 9 + i] = (uint32_t)cy; cy >>= 32; }
-        s_raw[t * 9 + 8] = (uint32_t)cy + A.K[8];
+        const Fr sc = t >= n_here ? A.extra_s[row * A.n_extra + (t - n_here)] : A.dense[row * A.stride + j0 + t];
+        recode_scalar(s_raw + t * 9, sc, A.K);
     }
     if (threadIdx.x < 8) s_base[threadIdx.x] = A.extra_base[threadIdx.x];
     __syncthreads();
@@ -127,10 +115,7 @@ template <int kKind> __global__ __launch_bounds__(kBlock) void k_msm_rows(MsmArg
         const size_t WE = (size_t)A.W * A.E;
         for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) {
             const uint32_t e16 = s_list[i], t = e16 >> 5, ww = e16 & 31u;
-            const int p2 = (int)ww * A.c, l2 = p2 >> 5, o2 = p2 & 31;
-            uint64_t x = s_raw[t * 9 + l2];
-            if (l2 < 8) x |= (uint64_t)s_raw[t * 9 + l2 + 1] << 32;
-            const int d = (int)((uint32_t)(x >> o2) & mask) - half;
+            const int d = recoded_digit(s_raw + t * 9, (int)ww, A.c);
             const size_t base = t < n_here ? j0 + t : (size_t)s_base[t - n_here];
             const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
             N10 e = n10_unpack(A.table[base * WE + (size_t)ww * A.E + (mag - 1)]);
@@ -138,15 +123,11 @@ template <int kKind> __global__ __launch_bounds__(kBlock) void k_msm_rows(MsmArg
             acc = p10_madd(acc, e);
         }
     } else if (tl < A.lanes) {
-        const int pos = w * A.c, limb = pos >> 5, off = pos & 31;
-        const uint32_t mask = (1u << A.c) - 1u; const int half = 1 << (A.c - 1);
         const size_t WE = (size_t)A.W * A.E;
         for (uint32_t t = tl; t < n_here + n_ex; t += A.lanes) {
-            uint64_t x = s_raw[t * 9 + limb];
-            if (limb < 8) x |= (uint64_t)s_raw[t * 9 + limb + 1] << 32;
-            int d = (int)((uint32_t)(x >> off) & mask) - half;
+            const int d = recoded_digit(s_raw + t * 9, w, A.c);
             if (d == 0) continue;
-            size_t base = t < n_here ? (bullet ? bullet_slot(A.bul, row, j0 + t) : j0 + t) : (size_t)s_base[t - n_here];
+            size_t base = t < n_here ? j0 + t : (size_t)s_base[t - n_here];
             uint32_t mag = (uint32_t)(d < 0 ? -d : d);
             N10 e = n10_unpack(A.table[base * WE + (size_t)w * A.E + (mag - 1)]);
             if (d < 0) e = n10_negate(e);
@@ -162,25 +143,166 @@ template <int kKind> __global__ __launch_bounds__(kBlock) void k_msm_rows(MsmArg
         if ((int)threadIdx.x < sft) acc = p10_add(acc, sm[threadIdx.x], d2);
         __syncthreads();
     }
-    if (!kSmall || !A.fuse) { if (threadIdx.x == 0) A.partial[row * A.nchunks + chunk_id] = p10_pack(acc); return; }
-    if (threadIdx.x == 0) { Pt pk = p10_pack(acc); store_words_sc1(&A.partial[row * A.nchunks + chunk_id], pk.X.v, 32); }
-    if (!arrive_and_check_last(A.counter, gridDim.x * gridDim.y)) return;
-    {   // 128 threads per row: one partial each, 7-level tree
-        const uint32_t r = threadIdx.x >> 7, idx = threadIdx.x & 127;
-        P10 sum = p10_identity();
-        if (r < A.rows && idx < A.nchunks) { Pt pk; load_words_sc1(pk.X.v, &A.partial[(size_t)r * A.nchunks + idx], 32); sum = p10_unpack(pk); }
-        for (int sft = 64; sft >= 1; sft >>= 1) {
-            if ((int)idx >= sft && (int)idx < 2 * sft) sm[r * 64 + idx - sft] = sum;
-            __syncthreads();
-            if ((int)idx < sft) sum = p10_add(sum, sm[r * 64 + idx], d2);
-            __syncthreads();
+    if (threadIdx.x == 0) A.partial[row * A.nchunks + chunk_id] = p10_pack(acc);
+}
+
+// ------------------------------------------------------------------------------------------------ the latency-bound launches
+// One or two rows of up to R terms (Cx, the bullet-reduction rounds, delta), or many rows of a handful of terms (blind * h per row
+// commitment, the tape-only points of every sum-check round).  Nothing here is throughput: a 2^20 proof makes 14 such launches one
+// after the other, each a dependent chain  scalars -> one mixed addition per (term, window) pair -> a reduction tree over ~16 k
+// points -> two points to the host.  The chain is what is shortened:
+//   * every addition is quad-parallel (fp10.h): 4 lanes per point, 2-3 multiplication depths per addition instead of 7-9;
+//   * a workgroup (64 quads) takes a SHORT chunk (about two pairs per quad), so the tree starts almost at once; its six levels go
+//     through LDS with one barrier each (every level has its own slots);
+//   * rows of at most two: the last workgroup to arrive (agent-scope counter, sc1 hand-off) sums the chunk results the same way
+//     and mails the extended row sums to pinned host memory — no finish launch, no copy, no stream synchronise;
+//   * a bullet round's c_L / c_R is not computed by one workgroup ahead of its MSM: every workgroup takes a slice of the dot product
+//     and adds (its slice) * Q as one more term — the sum over workgroups is c_L * Q; the folded state (a, b, s) for the next
+//     round is written after the workgroup has handed its point over, off the path to the host.
+constexpr int kSmallChunk = 64;                // terms per workgroup at most (LDS: 36 B each)
+constexpr int kSmallQuads = kBlock / 4;
+// the folded a in RAW (non-Montgomery) form: a Montgomery product with one raw operand is raw, so the scalars of L / R and the slices of
+// c_L / c_R come out ready for recoding without a conversion multiplication on the path to the first addition
+__device__ __forceinline__ Fr bullet_fold_a_raw(const BulletArgs &U, size_t x) {
+    Fr one = fr_zero(); one.v[0] = 1;
+    return U.fold ? fr_add(fr_mul_shared(U.a_in[x], U.u_raw), fr_mul_shared(U.uinv_raw, U.a_in[U.n + x])) : fr_mul_shared(U.a_in[x], one);
+}
+__device__ __forceinline__ void recode_raw(uint32_t *dst9, const Fr &raw, const uint32_t (&K)[9]) {
+    uint64_t cy = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { cy += (uint64_t)raw.v[i] + K[i]; dst9[i] = (uint32_t)cy; cy >>= 32; }
+    dst9[8] = (uint32_t)cy + K[8];
+}
+__global__ __launch_bounds__(kBlock) void k_msm_small(MsmArgs A) {
+    __shared__ uint32_t s_raw[(kSmallChunk + 8) * 9];
+    __shared__ uint32_t s_base[8];
+    __shared__ F10 s_tree[kSmallQuads - 1][4];                   // a level with `sft` writers per row segment uses slots [(sft - 1) * segs, (2 sft - 1) * segs)
+    const size_t row = blockIdx.y; const uint32_t chunk_id = blockIdx.x;
+    const size_t j0 = (size_t)chunk_id * A.chunk;
+    const uint32_t n_here = j0 < A.n_dense ? (uint32_t)min((size_t)A.chunk, A.n_dense - j0) : 0u;
+    const bool bullet = A.bul.on != 0;
+    const BulletArgs &U = A.bul;
+    // extras: plain launches carry them in chunk 0; a bullet round has {slice of <a, b> on Q} everywhere and {blind on H} in chunk 0
+    const uint32_t n_ex = bullet ? (chunk_id == 0 ? 2u : 1u) : (chunk_id == 0 ? (uint32_t)A.n_extra : 0u);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const bool stamp0 = A.stamps && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0;
+    if (stamp0) A.stamps[0] = wall_clock64();
+    // ---- scalars, recoded, into LDS.  Wave 0: the chunk's terms; wave 1: the bullet dot-product slice; wave 2: the other extras
+    Fr keep_s = fr_zero();                                       // bullet: the folded generator coefficient of this thread's term
+    Fr raw_one = fr_zero(); raw_one.v[0] = 1;                    // Montgomery product with the integer 1 = conversion to the raw integer
+    if (wave == 0 && (uint32_t)lane < n_here) {
+        if (bullet) {
+            const size_t j = bullet_slot(U, row, j0 + lane), n = U.n, h = n / 2, i = j & (n - 1);
+            keep_s = bullet_fold_s(U, j);
+            // L = <a_L, G_R>: generator slots of the upper half, paired with a[i - h];  R = <a_R, G_L>: lower half with a[i + h]
+            recode_raw(s_raw + lane * 9, fr_mul_shared(bullet_fold_a_raw(U, row == 0 ? i - h : i + h), keep_s), A.K);
+        } else recode_raw(s_raw + lane * 9, fr_mul_shared(A.dense[row * A.stride + j0 + lane], raw_one), A.K);
+    } else if (wave == 1 && bullet) {                            // c_L = <a_L, b_R> (row 0), c_R = <a_R, b_L> (row 1): elements chunk_id, chunk_id + #chunks, ..
+        const size_t h = U.n / 2;
+        Fr acc = fr_zero();
+        for (size_t x = chunk_id + (size_t)lane * gridDim.x; x < h; x += (size_t)64 * gridDim.x)
+            acc = fr_add(acc, row == 0 ? fr_mul_shared(bullet_fold_a_raw(U, x), bullet_fold_b(U, h + x)) : fr_mul_shared(bullet_fold_a_raw(U, h + x), bullet_fold_b(U, x)));
+        // lanes at and beyond ceil(h / #chunks) hold zero: reduce only as far as there is data
+        const size_t per = (h + gridDim.x - 1) / gridDim.x;
+        for (int off = 32; off >= 1; off >>= 1) { if ((size_t)off < per) acc = fr_add(acc, shfl_xor_fr(acc, off)); }
+        if (lane == 0) recode_raw(s_raw + n_here * 9, acc, A.K);
+    } else if (wave == 2 && (uint32_t)lane < n_ex && !(bullet && lane == 0)) {
+        recode_raw(s_raw + (n_here + lane) * 9, fr_mul_shared(A.extra_s[row * A.n_extra + lane], raw_one), A.K);
+    }
+    if (threadIdx.x < 8) s_base[threadIdx.x] = A.extra_base[threadIdx.x];
+    __syncthreads();
+    if (stamp0) A.stamps[1] = wall_clock64();
+    // ---- Two passes through ONE body (the instruction stream of an addition is long and every launch starts with a cold
+    // instruction cache: each phase running its own inlined copy cost more than the arithmetic).  Pass 0: this workgroup's (term,
+    // window) pairs, quad `qid` taking pairs qid, qid + 64, .., then a tree over the quads; the result goes to the chunk's slot in
+    // cached form.  Pass 1 (last workgroup to arrive only, rows <= 2): the same with the chunk results of a row as operands, the
+    // quads split between the rows.  A step of the body: fetch an operand in cached form (table entry / chunk result / LDS slot of
+    // the tree level), add it.  Operand loads are issued one step ahead of the addition that hides them.
+    const int q = threadIdx.x & 3, qid = threadIdx.x >> 2;
+    const size_t WE = (size_t)A.W * A.E;
+    const F10 d2 = f10_const(fp_2D());
+    F10 acc = q10_identity(q);
+    bool last = false;
+#pragma unroll 1
+    for (int pass = 0; pass < 2; pass++) {
+        const uint32_t segs = pass ? A.rows : 1u, qpr = kSmallQuads / segs, r = (uint32_t)qid / qpr, idx = (uint32_t)qid % qpr;
+        const uint32_t count = pass ? A.nchunks : (n_here + n_ex) * (uint32_t)A.W;       // operands of this segment
+        const int n_op = (int)((count + qpr - 1) / qpr);
+        int top = 1; while ((uint32_t)top < qpr && (uint32_t)top < count) top <<= 1;
+        int n_lv = 0; while ((1 << n_lv) < top) n_lv++;
+        // operand fetch (issue only: the value is unpacked when it is consumed)
+        Fp nxt; bool nxt_have = false, nxt_neg = false;
+        auto fetch = [&](int step) {
+            const uint32_t p = idx + (uint32_t)step * qpr;
+            nxt_have = false;
+            if (p >= count) return;
+            if (pass) { load_words_sc1(nxt.v, reinterpret_cast<const Fp *>(&A.partial[(size_t)r * A.nchunks + p]) + q, 8); nxt_have = true; nxt_neg = false; return; }
+            const uint32_t t = p / (uint32_t)A.W, w = p - t * (uint32_t)A.W;
+            const int d = recoded_digit(s_raw + t * 9, (int)w, A.c);
+            if (d == 0) return;
+            const size_t base = t < n_here ? (bullet ? bullet_slot(U, row, j0 + t) : j0 + t) : (size_t)s_base[t - n_here];
+            const Niels *e = &A.table[base * WE + (size_t)w * A.E + ((uint32_t)(d < 0 ? -d : d) - 1)];
+            nxt_neg = d < 0; nxt_have = true;
+            if (q < 3) nxt = reinterpret_cast<const Fp *>(e)[q == 2 ? 2 : (((q == 0) != nxt_neg) ? 1 : 0)];   // Niels = {yplusx, yminusx, xy2d}
+        };
+        if (pass) acc = q10_identity(q);
+        if (n_op) fetch(0);
+        F10 *const seg_tree = &s_tree[0][0] + (size_t)r * 4 + q;               // slot (level base + r * sft + k) of this lane: seg_tree[((sft - 1) * segs + r * (sft - 1) + k) * 4]
+#pragma unroll 1
+        for (int step = 0; step <= n_op + n_lv; step++) {
+            const F10 ua = q10_u(acc, q);                                         // needed by both roles of a tree level; formed before any wait
+            F10 v; bool have = false;
+            if (step < n_op) {
+                const Fp cur = nxt; const bool cur_neg = nxt_neg; have = nxt_have;
+                if (step + 1 < n_op) fetch(step + 1);
+                if (have) {
+                    if (!pass && q == 3) { v = f10_zero(); v.v[0] = 2; }                 // a table entry is affine: 2 Z = 2
+                    else { v = f10_unpack(cur); if (q == 2 && cur_neg) v = f10_carry(f10_neg(v)); }
+                }
+            } else {
+                if (step == n_op && threadIdx.x == 0 && A.stamps && (pass || stamp0)) A.stamps[pass ? 5 : 2] = wall_clock64();
+                const int sft = top >> (step - n_op + 1);                                // top/2, .., 1, then 0 = hand the segment's sum over
+                const bool out_cached = sft == 0 && !pass && A.fuse;
+                if (sft == 0 && !out_cached) break;
+                F10 *const level = seg_tree + (size_t)((sft - 1) * (int)segs + (int)r * (sft - 1)) * 4;
+                if (sft ? ((int)idx >= sft && (int)idx < 2 * sft) : idx == 0) {
+                    const F10 cv = q10_cached(ua, q, d2);
+                    if (sft) level[(idx - sft) * 4] = cv;
+                    else { const Fp pk = f10_pack(cv); store_words_sc1(reinterpret_cast<Fp *>(&A.partial[row * A.nchunks + chunk_id]) + q, pk.v, 8); }
+                }
+                if (sft == 0) break;
+                __syncthreads();
+                if ((int)idx < sft) { v = level[idx * 4]; have = true; }
+            }
+            if (have) acc = q10_add_cached_u(ua, v, q);
         }
-        if (idx == 0 && r < A.rows) { A.host_pts[r] = p10_pack(sum); __threadfence_system(); }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            __threadfence_system();
-            __hip_atomic_store(A.host_flag, A.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (pass == 0) {
+            if (stamp0) A.stamps[3] = wall_clock64();
+            if (!A.fuse) { if (qid == 0) reinterpret_cast<Fp *>(&A.partial[row * A.nchunks + chunk_id])[q] = f10_pack(acc); break; }
+            last = arrive_and_check_last(A.counter, gridDim.x * gridDim.y);
+            if (!last) break;
+            if (A.stamps && threadIdx.x == 0) A.stamps[4] = wall_clock64();
+        } else {
+            if (A.stamps && threadIdx.x == 0) A.stamps[6] = wall_clock64();
+            if (idx == 0) { reinterpret_cast<Fp *>(&A.host_pts[r])[q] = f10_pack(acc); __threadfence_system(); }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                __threadfence_system();
+                __hip_atomic_store(A.host_flag, A.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (A.stamps) A.stamps[7] = wall_clock64();
+            }
         }
+    }
+    // ---- a bullet round persists the folded state for the next round, each element written once: a and b by the row-0 workgroups,
+    // s by whichever row walks that generator slot.  State is ping-ponged, so nobody reads what this launch writes.  (After the
+    // hand-over: the host is already hashing L and R while this is written.)
+    if (bullet) {
+        const size_t n = U.n;
+        if (row == 0) {
+            const size_t cx = (n + gridDim.x - 1) / gridDim.x, x0 = (size_t)chunk_id * cx;
+            for (size_t x = x0 + threadIdx.x; x < min(n, x0 + cx); x += blockDim.x) { U.a_out[x] = bullet_fold_a(U, x); U.b_out[x] = bullet_fold_b(U, x); }
+        }
+        if (wave == 0 && (uint32_t)lane < n_here) U.s_out[bullet_slot(U, row, j0 + lane)] = keep_s;
     }
 }
 // one wave per row: sum the row's chunk partials into one extended point
@@ -237,7 +359,7 @@ double dev_small_fraction(DevCtx &c, const Fr *z, size_t n) {
 unsigned long long dev_bullet_round(DevCtx &c, const DeviceGens &g, size_t R, size_t n_cur, bool fold, const Fr &u, const Fr &u_inv, const Fr *a_in,
                                     const Fr *b_in, const Fr *s_in, Fr *a_out, Fr *b_out, Fr *s_out, const Fr *extra_s, const uint32_t *extra_base) {
     BulletArgs U; U.on = 1; U.fold = fold ? 1 : 0; U.n = (uint32_t)n_cur; U.a_in = a_in; U.b_in = b_in; U.s_in = s_in;
-    U.a_out = a_out; U.b_out = b_out; U.s_out = s_out; U.u = u; U.uinv = u_inv;
+    U.a_out = a_out; U.b_out = b_out; U.s_out = s_out; U.u = u; U.uinv = u_inv; U.u_raw = fr_to_raw(u); U.uinv_raw = fr_to_raw(u_inv);
     return msm_launch(c, g, nullptr, 0, R / 2, 2, extra_s, extra_base, 2, MSM_COMPRESSED, nullptr, &U, false);   // R/2 active terms per row
 }
 static unsigned long long msm_launch(DevCtx &c, const DeviceGens &g, const Fr *dense, size_t stride, size_t n_dense, size_t rows, const Fr *extra_s,
@@ -249,15 +371,29 @@ static unsigned long long msm_launch(DevCtx &c, const DeviceGens &g, const Fr *d
     A.table = g.table.p; A.c = g.c; A.W = g.W; A.E = (uint32_t)g.E; A.lanes = kBlock / g.W;
     A.dense = dense; A.stride = stride; A.n_dense = n_dense; A.extra_s = extra_s; A.n_extra = (int)n_extra;
     for (int i = 0; i < 8; i++) A.extra_base[i] = i < (int)n_extra ? extra_base[i] : 0;
-    // chunking: aim for >= 1024 workgroups (4 per CU) but keep at least one term per term lane and at most kMsmMaxChunk per workgroup
-    size_t nchunks = std::max<size_t>(1, (1024 + rows - 1) / rows);
-    nchunks = std::min(nchunks, std::max<size_t>(1, n_dense / (size_t)A.lanes));
-    if (!n_dense) nchunks = 1;
-    // bulk launches keep a (term, window) work list in LDS: (chunk + extras) * W <= kMsmListCap;  W <= 32 there (5-bit window field)
     const bool bulk = rows * n_dense >= ((size_t)1 << 16) && !bul;
     const bool sparse = bulk && sparse_hint && g.W <= 32;
-    const size_t max_chunk = sparse ? std::min<size_t>(kMsmBulkChunk, (size_t)kMsmListCap / (size_t)g.W - n_extra) : (size_t)kMsmMaxChunk;
-    nchunks = std::max(nchunks, (n_dense + max_chunk - 1) / max_chunk);
+    size_t nchunks;
+    if (bulk) {
+        // aim for >= 1024 workgroups (4 per CU) but keep at least one term per term lane and at most kMsmMaxChunk per workgroup;
+        // the sparse variant keeps a (term, window) work list in LDS: (chunk + extras) * W <= kMsmListCap;  W <= 32 there (5-bit window field)
+        nchunks = std::max<size_t>(1, (1024 + rows - 1) / rows);
+        nchunks = std::min(nchunks, std::max<size_t>(1, n_dense / (size_t)A.lanes));
+        const size_t max_chunk = sparse ? std::min<size_t>(kMsmBulkChunk, (size_t)kMsmListCap / (size_t)g.W - n_extra) : (size_t)kMsmMaxChunk;
+        nchunks = std::max(nchunks, (n_dense + max_chunk - 1) / max_chunk);
+    } else {
+        // latency-bound launches: about two (term, window) pairs per quad (one or two rows) or four (many rows), at most 2048 workgroups
+        // and, when the last workgroup sums the chunk results itself (rows <= 2), at most 256 of them per row
+        // (whole steps: a workgroup's pairs, extras included, should fill its 64 quads k times — the bullet rounds carry one extra
+        // term per workgroup, the slice of c_L / c_R, and two in chunk 0)
+        const size_t steps = rows <= 2 ? 3 : 4, per_wg = steps * (size_t)kSmallQuads / (size_t)g.W, ex_wg = bul ? 2 : n_extra;
+        const size_t terms_wg = per_wg > ex_wg ? per_wg - ex_wg : 1;
+        nchunks = std::max<size_t>(1, (n_dense + terms_wg - 1) / terms_wg);
+        nchunks = std::min(nchunks, rows <= 2 ? (size_t)256 : std::max<size_t>(1, 2048 / rows));
+        nchunks = std::min(nchunks, std::max<size_t>(1, n_dense));
+        nchunks = std::max(nchunks, (n_dense + kSmallChunk - 1) / (size_t)kSmallChunk);
+    }
+    if (!n_dense) nchunks = 1;
     size_t chunk = n_dense ? (n_dense + nchunks - 1) / nchunks : 1;
     nchunks = n_dense ? (n_dense + chunk - 1) / chunk : 1;
     A.chunk = (uint32_t)chunk; A.nchunks = (uint32_t)nchunks;
@@ -265,15 +401,30 @@ static unsigned long long msm_launch(DevCtx &c, const DeviceGens &g, const Fr *d
     for (int w = 0; w < g.W; w++) { int bit = g.c - 1 + g.c * w; A.K[bit >> 5] |= 1u << (bit & 31); }
     c.ensure_points(rows, nchunks);
     A.partial = c.msm_partial.p;
-    A.fuse = (!bulk && mode == MSM_COMPRESSED && !addend && rows <= 2 && nchunks > 1 && nchunks <= 128) ? 1 : 0;
+    A.fuse = (!bulk && mode == MSM_COMPRESSED && !addend && rows <= 2 && rows * nchunks <= 512) ? 1 : 0;
     if (bul) A.bul = *bul; else { memset(&A.bul, 0, sizeof A.bul); }
     A.rows = (uint32_t)rows; A.counter = c.d_counter2.p; A.host_pts = c.d_pts_alias; A.host_flag = c.d_flag_alias; A.seq = A.fuse ? ++c.seq : 0;
     dim3 grid((unsigned)nchunks, (unsigned)rows);
+    // OTTI_MSM_STAMPS=1: phase stamps of every fused small launch on stderr (development aid; synchronises the stream)
+    static const bool want_stamps = getenv("OTTI_MSM_STAMPS") != nullptr;
+    static thread_local unsigned long long *h_stamps = nullptr, *d_stamps = nullptr;
+    A.stamps = nullptr;
+    if (want_stamps && A.fuse) {
+        if (!h_stamps) { OTTI_HIP(hipHostMalloc((void **)&h_stamps, 128, hipHostMallocDefault)); OTTI_HIP(hipHostGetDevicePointer((void **)&d_stamps, h_stamps, 0)); }
+        memset(h_stamps, 0, 128); A.stamps = d_stamps;
+    }
     {
         KScope ks(c, bulk ? KC_MSM_ROWS : KC_MSM_SMALL);
         if (sparse) hipLaunchKernelGGL(k_msm_rows<MSM_BULK_SPARSE>, grid, kBlock, 0, c.stream, A);
         else if (bulk) hipLaunchKernelGGL(k_msm_rows<MSM_BULK>, grid, kBlock, 0, c.stream, A);
-        else hipLaunchKernelGGL(k_msm_rows<MSM_SMALL>, grid, kBlock, 0, c.stream, A);
+        else hipLaunchKernelGGL(k_msm_small, grid, kBlock, 0, c.stream, A);
+    }
+    if (A.stamps) {
+        OTTI_HIP(hipStreamSynchronize(c.stream));
+        const unsigned long long *t = h_stamps;
+        auto us = [&](int a, int b) { return t[b] >= t[a] ? (double)(t[b] - t[a]) * 0.01 : -1.0; };
+        fprintf(stderr, "[otti] k_msm_small rows=%zu terms=%zu chunks=%zu bullet=%d: scalars %.2f | pairs %.2f | tree %.2f | (others arrive) %.2f | chunk sums %.2f | row tree %.2f | mail %.2f | total %.2f us\n",
+                rows, n_dense + n_extra, nchunks, bul ? 1 : 0, us(0, 1), us(1, 2), us(2, 3), us(3, 4), us(4, 5), us(5, 6), us(6, 7), us(0, 7));
     }
     if (A.fuse) { c.pending_host_encode = rows; return A.seq; }
     // rows with a single chunk need no finish pass: their partial IS the row sum

@@ -21,6 +21,11 @@ template <int MODE> __global__ void k_chain(Fp *io, int iters) {
     if (MODE == 6) { F10 x = f10_unpack(a); for (int k = 0; k < iters; k++) x = f10_sqr(x); a = f10_pack(x); }
     if (MODE == 7) { P10 p; p.X = f10_unpack(a); p.Y = f10_unpack(b); p.Z = f10_one(); p.T = f10_mul(p.X, p.Y); N10 n; n.yplusx = p.X; n.yminusx = p.Y; n.xy2d = p.T; for (int k = 0; k < iters; k++) p = p10_madd(p, n); a = f10_pack(p.X); }
     if (MODE == 8) { P10 p; p.X = f10_unpack(a); p.Y = f10_unpack(b); p.Z = f10_one(); p.T = f10_mul(p.X, p.Y); P10 q = p; F10 d2 = f10_const(fp_2D()); for (int k = 0; k < iters; k++) p = p10_add(p, q, d2); a = f10_pack(p.X); }
+    // quad-parallel forms (fp10.h): four lanes per point; one "op" = one addition of the whole quad
+    if (MODE == 9) { const int q = threadIdx.x & 3; F10 acc = f10_unpack(a), v = f10_unpack(b); for (int k = 0; k < iters; k++) acc = q10_add_cached(acc, v, q); a = f10_pack(acc); }
+    if (MODE == 10) { const int q = threadIdx.x & 3; F10 acc = f10_unpack(a), o = f10_unpack(b); const F10 d2 = f10_const(fp_2D());
+                      for (int k = 0; k < iters; k++) acc = q10_add_cached(acc, q10_cached(q10_u(o, q), q, d2), q), o = acc; a = f10_pack(acc); }
+    if (MODE == 11) { const int q = threadIdx.x & 3; F10 acc = f10_unpack(a); for (int k = 0; k < iters; k++) acc = q10_u(acc, q); a = f10_pack(acc); }
     io[2 * i] = a;
 }
 template <int MODE> static int run(const char *name, int blocks, int threads, int iters, double ops_per_iter) {
@@ -46,6 +51,9 @@ int main() {
     run<6>("f10_sqr latency (1 wave)", 1, 64, 2000, 1);
     run<7>("p10_madd latency (1 wave)", 1, 64, 500, 1);
     run<8>("p10_add latency (1 wave)", 1, 64, 500, 1);
+    run<9>("q10 madd latency (1 wave)", 1, 64, 500, 1);
+    run<10>("q10 cached+add latency", 1, 64, 500, 1);
+    run<11>("q10_u latency (1 wave)", 1, 64, 2000, 1);
     run<5>("f10_mul throughput", 256 * 8, 256, 500, 1);
     run<6>("f10_sqr throughput", 256 * 8, 256, 500, 1);
     run<7>("p10_madd throughput", 256 * 4, 256, 200, 1);
