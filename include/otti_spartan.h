@@ -114,6 +114,11 @@ size_t  otti_last_error(char *buf, size_t cap);
 int32_t otti_prepare_device(otti_instance *inst, otti_gens *gens);
 /* number of visible gfx950 devices (0 when none; never initialises a context) */
 int32_t otti_device_count(void);
+/* Self-test of the host-side fast paths that sit on the prover's sequential Fiat-Shamir path (five-limb GF(2^255-19): point
+   compression, fixed-base window tables) against the generic field code and a variable-base multiplication, on `iterations`
+   pseudo-random inputs.  0 = consistent.  Needs no GPU; the prover itself only runs on one, so this is how the CPU test suite
+   reaches that code. */
+int32_t otti_host_selftest(uint32_t iterations);
 
 /* ---- zkInterface ingest (replaces spartan-zkinterface's reader; schema zkinterface 1.x) ---- */
 typedef struct {
@@ -202,6 +207,10 @@ int32_t otti_dev_alloc(size_t nbytes, void **d_out);
 int32_t otti_dev_free(void *d);
 int32_t otti_dev_upload(void *d_dst, const void *h_src, size_t nbytes);
 int32_t otti_dev_download(void *h_dst, const void *d_src, size_t nbytes);
+/* a HIP stream of the runtime the library itself is linked to (a caller with its own HIP code passes its hipStream_t instead) */
+int32_t otti_dev_stream_create(void **stream_out);
+int32_t otti_dev_stream_sync(void *stream);
+int32_t otti_dev_stream_destroy(void *stream);
 
 /* per-kernel-class timing with HIP events recorded on the library's own stream around every launch of that class.
    classes: msm_rows (>= 2^16 scalars per launch: the witness commitment) msm_small msm_finish sc_cubic sc_quad spmv eq reduce poly_bound bullet other.  enable(1) also resets the counters. */

@@ -62,6 +62,7 @@ def _sig(name, res, *args):
 _sig("otti_last_error", _sz, ctypes.c_char_p, _sz)
 _sig("otti_buf_free", None, _vp)
 _sig("otti_device_count", _i32)
+_sig("otti_host_selftest", _i32, ctypes.c_uint32)
 _sig("otti_instance_new", _i32, _u64, _u64, _u64, _vp, _sz, _vp, _sz, _vp, _sz, ctypes.POINTER(_vp))
 _sig("otti_instance_free", None, _vp)
 _sig("otti_instance_dims", _i32, _vp, ctypes.POINTER(_u64), ctypes.POINTER(_u64), ctypes.POINTER(_u64))
@@ -128,6 +129,9 @@ _sig("otti_dev_alloc", _i32, _sz, ctypes.POINTER(_vp))
 _sig("otti_dev_free", _i32, _vp)
 _sig("otti_dev_upload", _i32, _vp, _vp, _sz)
 _sig("otti_dev_download", _i32, _vp, _vp, _sz)
+_sig("otti_dev_stream_create", _i32, ctypes.POINTER(_vp))
+_sig("otti_dev_stream_sync", _i32, _vp)
+_sig("otti_dev_stream_destroy", _i32, _vp)
 
 
 def _last_error():
@@ -165,6 +169,11 @@ def _scalars(a, what):
 
 def device_count():
     return int(lib.otti_device_count())
+
+
+def host_selftest(iterations=200):
+    """host-side fast paths of the prover (five-limb field, fixed-base tables) against the generic code; raises on a mismatch"""
+    _check(lib.otti_host_selftest(iterations))
 
 
 # ---------------------------------------------------------------------------------------------- libspartan mirror
@@ -629,6 +638,18 @@ class DeviceArray:
 
 class kernels_dev:
     """otti_kd_*: the same kernels on device pointers and a caller's stream (None = the library's stream of this thread)"""
+
+    @staticmethod
+    def stream_create():
+        s = _vp(); _check(lib.otti_dev_stream_create(ctypes.byref(s))); return s
+
+    @staticmethod
+    def stream_sync(s):
+        _check(lib.otti_dev_stream_sync(s))
+
+    @staticmethod
+    def stream_destroy(s):
+        _check(lib.otti_dev_stream_destroy(s))
 
     @staticmethod
     def multiply_vec(inst, z, Az, Bz, Cz, stream=None):

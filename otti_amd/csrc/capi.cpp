@@ -50,6 +50,37 @@ int32_t otti_device_count(void) {
     return count;
 }
 
+int32_t otti_host_selftest(uint32_t iterations) {
+    return guarded([&] {
+        auto g = gens_new(16, 16, 1);
+        Shake256 xof; xof.absorb("otti-host-selftest", 18);
+        for (uint32_t it = 0; it < iterations; it++) {
+            uint8_t w[64]; xof.squeeze(w, 64);
+            Fr s = fr_from_bytes_wide(w);
+            if (it == 0) s = fr_zero(); if (it == 1) s = fr_one(); if (it == 2) s = fr_neg(fr_one());
+            xof.squeeze(w, 64);
+            const Pt rnd = pt_from_uniform_bytes(w);
+            // five-limb round trip and compression against the generic code
+            uint8_t a[32], b[32];
+            pt_encode_fast(a, rnd); pt_encode_ref(b, rnd);
+            if (memcmp(a, b, 32)) throw Error(OTTI_ERR_INTERNAL, "pt_encode_fast differs from pt_encode_ref");
+            const Pt back = ptfe_to(ptfe_from(rnd));
+            pt_encode_ref(a, back);
+            if (memcmp(a, b, 32)) throw Error(OTTI_ERR_INTERNAL, "five-limb round trip changed a point");
+            // fixed-base table (8-bit windows, five-limb mixed additions) against a variable-base multiplication
+            const size_t slot = it % g->small_tables.size();
+            size_t base = 0; for (size_t i = 0; i < g->small_slot.size(); i++) if (g->small_slot[i] == (int)slot) base = i;
+            Pt acc = rnd; g->small_tables[slot].accumulate(acc, s);
+            const Pt want = pt_add(rnd, host_scalarmul(g->P[base], s));
+            pt_encode_ref(a, acc); pt_encode_ref(b, want);
+            if (memcmp(a, b, 32)) throw Error(OTTI_ERR_INTERNAL, "fixed-base table result differs from the variable-base multiplication");
+            pt_encode_fast(a, pt_identity()); pt_encode_ref(b, pt_identity());
+            if (memcmp(a, b, 32)) throw Error(OTTI_ERR_INTERNAL, "identity encodes differently");
+        }
+        return OTTI_OK;
+    });
+}
+
 int32_t otti_instance_new(uint64_t nc, uint64_t nv, uint64_t ni, const otti_entry *A, size_t nA, const otti_entry *B, size_t nB,
                           const otti_entry *C, size_t nC, otti_instance **out) {
     return guarded([&] {
@@ -443,6 +474,9 @@ int32_t otti_dev_alloc(size_t nbytes, void **out) { return guarded([&] { if (!ou
 int32_t otti_dev_free(void *d) { return guarded([&] { if (d) OTTI_HIP(hipFree(d)); return OTTI_OK; }); }
 int32_t otti_dev_upload(void *d, const void *h, size_t n) { return guarded([&] { DevCtx::get(); if (n) OTTI_HIP(hipMemcpy(d, h, n, hipMemcpyHostToDevice)); return OTTI_OK; }); }
 int32_t otti_dev_download(void *h, const void *d, size_t n) { return guarded([&] { DevCtx::get(); if (n) OTTI_HIP(hipMemcpy(h, d, n, hipMemcpyDeviceToHost)); return OTTI_OK; }); }
+int32_t otti_dev_stream_create(void **out) { return guarded([&] { if (!out) throw Error(OTTI_ERR_BAD_ARG, "null argument"); DevCtx::get(); hipStream_t s; OTTI_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); *out = (void *)s; return OTTI_OK; }); }
+int32_t otti_dev_stream_sync(void *stream) { return guarded([&] { OTTI_HIP(hipStreamSynchronize((hipStream_t)stream)); return OTTI_OK; }); }
+int32_t otti_dev_stream_destroy(void *stream) { return guarded([&] { if (stream) OTTI_HIP(hipStreamDestroy((hipStream_t)stream)); return OTTI_OK; }); }
 int32_t otti_kd_multiply_vec(otti_instance *inst, const void *z, void *Az, void *Bz, void *Cz, void *stream) {
     return guarded([&] {
         if (!inst || !z || !Az || !Bz || !Cz) throw Error(OTTI_ERR_BAD_ARG, "null argument");

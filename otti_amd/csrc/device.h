@@ -76,7 +76,7 @@ struct DevCtx {
     Pt *d_pts_alias = nullptr; DevBuf<unsigned> d_counter2;
     void ensure_points(size_t rows, size_t splits);
 };
-constexpr int kResultSlots = 64;
+constexpr int kResultSlots = 256;
 constexpr size_t kHostEncodeRows = 8;
 constexpr size_t kHostPtsCap = 512;
 

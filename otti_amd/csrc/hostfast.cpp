@@ -1,0 +1,129 @@
+#include "hostfast.h"
+
+namespace otti {
+
+typedef unsigned __int128 u128;
+static const uint64_t M51 = ((uint64_t)1 << 51) - 1;
+
+Fe fe_from_fp(const Fp &a) {
+    uint64_t t[4]; memcpy(t, a.v, 32);
+    Fe r;
+    r.v[0] = t[0] & M51;
+    r.v[1] = ((t[0] >> 51) | (t[1] << 13)) & M51;
+    r.v[2] = ((t[1] >> 38) | (t[2] << 26)) & M51;
+    r.v[3] = ((t[2] >> 25) | (t[3] << 39)) & M51;
+    r.v[4] = t[3] >> 12;                                   // a loosely reduced Fp is < 2^256: this limb may use 52 bits
+    return r;
+}
+static inline void fe_carry(Fe &a) {                         // limbs below 2^51 (limb 0 may keep a few units above after the wrap)
+    uint64_t c;
+    c = a.v[0] >> 51; a.v[0] &= M51; a.v[1] += c;
+    c = a.v[1] >> 51; a.v[1] &= M51; a.v[2] += c;
+    c = a.v[2] >> 51; a.v[2] &= M51; a.v[3] += c;
+    c = a.v[3] >> 51; a.v[3] &= M51; a.v[4] += c;
+    c = a.v[4] >> 51; a.v[4] &= M51; a.v[0] += 19 * c;
+    c = a.v[0] >> 51; a.v[0] &= M51; a.v[1] += c;
+}
+Fp fe_to_fp(const Fe &a0) {
+    Fe a = a0; fe_carry(a); fe_carry(a);                     // every limb < 2^51 (limb 1 by at most one unit more): value < 2^255 + 2^52
+    u128 acc = a.v[0];
+    uint64_t t[4];
+    acc += (u128)a.v[1] << 51; t[0] = (uint64_t)acc; acc >>= 64;
+    acc += (u128)a.v[2] << 38; t[1] = (uint64_t)acc; acc >>= 64;
+    acc += (u128)a.v[3] << 25; t[2] = (uint64_t)acc; acc >>= 64;
+    acc += (u128)a.v[4] << 12; t[3] = (uint64_t)acc;         // < 2^256: fits (a valid loosely reduced Fp)
+    Fp r; memcpy(r.v, t, 32); return r;
+}
+static inline Fe fe_add(const Fe &a, const Fe &b) { Fe r; for (int i = 0; i < 5; i++) r.v[i] = a.v[i] + b.v[i]; return r; }
+static inline Fe fe_sub(const Fe &a, const Fe &b) {          // a - b + 4p; b limbs < 2^53
+    Fe r;
+    r.v[0] = a.v[0] + 0x1fffffffffffb4ULL - b.v[0];
+    for (int i = 1; i < 5; i++) r.v[i] = a.v[i] + 0x1ffffffffffffcULL - b.v[i];
+    return r;
+}
+static inline Fe fe_mul(const Fe &a, const Fe &b) {          // limbs < 2^54 in, < 2^51 + 2^13 out
+    uint64_t r0 = b.v[0], r1 = b.v[1], r2 = b.v[2], r3 = b.v[3], r4 = b.v[4];
+    const uint64_t s0 = a.v[0], s1 = a.v[1], s2 = a.v[2], s3 = a.v[3], s4 = a.v[4];
+    u128 t0 = (u128)r0 * s0;
+    u128 t1 = (u128)r0 * s1 + (u128)r1 * s0;
+    u128 t2 = (u128)r0 * s2 + (u128)r2 * s0 + (u128)r1 * s1;
+    u128 t3 = (u128)r0 * s3 + (u128)r3 * s0 + (u128)r1 * s2 + (u128)r2 * s1;
+    u128 t4 = (u128)r0 * s4 + (u128)r4 * s0 + (u128)r3 * s1 + (u128)r1 * s3 + (u128)r2 * s2;
+    r1 *= 19; r2 *= 19; r3 *= 19; r4 *= 19;
+    t0 += (u128)r4 * s1 + (u128)r1 * s4 + (u128)r2 * s3 + (u128)r3 * s2;
+    t1 += (u128)r4 * s2 + (u128)r2 * s4 + (u128)r3 * s3;
+    t2 += (u128)r4 * s3 + (u128)r3 * s4;
+    t3 += (u128)r4 * s4;
+    Fe o; uint64_t c;
+    o.v[0] = (uint64_t)t0 & M51; c = (uint64_t)(t0 >> 51);
+    t1 += c; o.v[1] = (uint64_t)t1 & M51; c = (uint64_t)(t1 >> 51);
+    t2 += c; o.v[2] = (uint64_t)t2 & M51; c = (uint64_t)(t2 >> 51);
+    t3 += c; o.v[3] = (uint64_t)t3 & M51; c = (uint64_t)(t3 >> 51);
+    t4 += c; o.v[4] = (uint64_t)t4 & M51; c = (uint64_t)(t4 >> 51);
+    o.v[0] += c * 19; c = o.v[0] >> 51; o.v[0] &= M51; o.v[1] += c;
+    return o;
+}
+static inline Fe fe_sqr(const Fe &a) {
+    const uint64_t r0 = a.v[0], r1 = a.v[1], r2 = a.v[2], r3 = a.v[3], r4 = a.v[4];
+    const uint64_t d0 = r0 * 2, d1 = r1 * 2, d2 = r2 * 2 * 19, d419 = r4 * 19, d4 = d419 * 2;
+    u128 t0 = (u128)r0 * r0 + (u128)d4 * r1 + (u128)d2 * r3;
+    u128 t1 = (u128)d0 * r1 + (u128)d4 * r2 + (u128)r3 * (r3 * 19);
+    u128 t2 = (u128)d0 * r2 + (u128)r1 * r1 + (u128)d4 * r3;
+    u128 t3 = (u128)d0 * r3 + (u128)d1 * r2 + (u128)r4 * d419;
+    u128 t4 = (u128)d0 * r4 + (u128)d1 * r3 + (u128)r2 * r2;
+    Fe o; uint64_t c;
+    o.v[0] = (uint64_t)t0 & M51; c = (uint64_t)(t0 >> 51);
+    t1 += c; o.v[1] = (uint64_t)t1 & M51; c = (uint64_t)(t1 >> 51);
+    t2 += c; o.v[2] = (uint64_t)t2 & M51; c = (uint64_t)(t2 >> 51);
+    t3 += c; o.v[3] = (uint64_t)t3 & M51; c = (uint64_t)(t3 >> 51);
+    t4 += c; o.v[4] = (uint64_t)t4 & M51; c = (uint64_t)(t4 >> 51);
+    o.v[0] += c * 19; c = o.v[0] >> 51; o.v[0] &= M51; o.v[1] += c;
+    return o;
+}
+static inline Fe fe_sqr_n(Fe a, int n) { for (int i = 0; i < n; i++) a = fe_sqr(a); return a; }
+static Fe fe_pow22523(const Fe &a) {                         // a^((p-5)/8) = a^(2^252 - 3)
+    Fe z2 = fe_sqr(a), z9 = fe_mul(fe_sqr_n(z2, 2), a), z11 = fe_mul(z9, z2);
+    Fe t5 = fe_mul(fe_sqr(z11), z9);
+    Fe t10 = fe_mul(fe_sqr_n(t5, 5), t5), t20 = fe_mul(fe_sqr_n(t10, 10), t10), t40 = fe_mul(fe_sqr_n(t20, 20), t20);
+    Fe t50 = fe_mul(fe_sqr_n(t40, 10), t10), t100 = fe_mul(fe_sqr_n(t50, 50), t50), t200 = fe_mul(fe_sqr_n(t100, 100), t100);
+    Fe t250 = fe_mul(fe_sqr_n(t200, 50), t50);
+    return fe_mul(fe_sqr_n(t250, 2), a);
+}
+
+PtFe ptfe_from(const Pt &p) { PtFe r; r.X = fe_from_fp(p.X); r.Y = fe_from_fp(p.Y); r.Z = fe_from_fp(p.Z); r.T = fe_from_fp(p.T); return r; }
+Pt ptfe_to(const PtFe &p) { Pt r; r.X = fe_to_fp(p.X); r.Y = fe_to_fp(p.Y); r.Z = fe_to_fp(p.Z); r.T = fe_to_fp(p.T); return r; }
+NielsFe nielsfe_from(const Niels &n) { NielsFe r; r.yplusx = fe_from_fp(n.yplusx); r.yminusx = fe_from_fp(n.yminusx); r.xy2d = fe_from_fp(n.xy2d); return r; }
+// add-2008-hwcd-3 mixed addition (7M), as pt_madd / pt_msub of point.h.  Coordinates stay < 2^51 + 2^13 per limb (products).
+void ptfe_madd(PtFe &p, const NielsFe &q, bool negate) {
+    const Fe a = fe_mul(fe_sub(p.Y, p.X), negate ? q.yplusx : q.yminusx);
+    const Fe b = fe_mul(fe_add(p.Y, p.X), negate ? q.yminusx : q.yplusx);
+    const Fe c = fe_mul(p.T, q.xy2d);
+    const Fe d = fe_add(p.Z, p.Z);
+    const Fe e = fe_sub(b, a), h = fe_add(b, a);
+    const Fe f = negate ? fe_add(d, c) : fe_sub(d, c), g = negate ? fe_sub(d, c) : fe_add(d, c);
+    p.X = fe_mul(e, f); p.Y = fe_mul(g, h); p.T = fe_mul(e, h); p.Z = fe_mul(f, g);
+}
+
+void pt_encode_fast(uint8_t out[32], const Pt &p) {
+    static const Fe sqrt_m1 = fe_from_fp(fp_SQRT_M1()), invsqrt_a_minus_d = fe_from_fp(fp_INVSQRT_A_MINUS_D());
+    const Fe X = fe_from_fp(p.X), Y = fe_from_fp(p.Y), Z = fe_from_fp(p.Z), T = fe_from_fp(p.T);
+    const Fe u1 = fe_mul(fe_add(Z, Y), fe_sub(Z, Y)), u2 = fe_mul(X, Y);
+    // SQRT_RATIO_M1(1, v), v = u1 * u2^2  (RFC 9496 4.2): r = v^3 (v^7)^((p-5)/8); fix the sign of the root by what v r^2 turns out to be
+    const Fe v = fe_mul(u1, fe_sqr(u2));
+    const Fe v3 = fe_mul(fe_sqr(v), v), v7 = fe_mul(fe_sqr(v3), v);
+    Fe r = fe_mul(v3, fe_pow22523(v7));
+    const Fp check = fe_to_fp(fe_mul(v, fe_sqr(r)));
+    const Fp neg_one = fp_neg(fp_one());
+    if (fp_eq(check, neg_one) || fp_eq(check, fp_mul(neg_one, fp_SQRT_M1()))) r = fe_mul(r, sqrt_m1);
+    const Fe inv = fe_from_fp(fp_abs(fe_to_fp(r)));
+    const Fe den1 = fe_mul(inv, u1), den2 = fe_mul(inv, u2);
+    const Fe zinv = fe_mul(fe_mul(den1, den2), T);
+    const bool rotate = fp_is_negative(fe_to_fp(fe_mul(T, zinv)));
+    Fe x = X, y = Y, deninv = den2;
+    if (rotate) { x = fe_mul(Y, sqrt_m1); y = fe_mul(X, sqrt_m1); deninv = fe_mul(den1, invsqrt_a_minus_d); }
+    Fe zy = fe_sub(Z, y);
+    if (fp_is_negative(fe_to_fp(fe_mul(x, zinv)))) zy = fe_add(Z, y);           // y -> -y
+    fp_to_bytes(out, fp_abs(fe_to_fp(fe_mul(deninv, zy))));
+}
+
+}  // namespace otti

@@ -1,0 +1,27 @@
+// Host-only GF(2^255-19) arithmetic in five 51-bit limbs, for the two things the prover's HOST does between two device launches of
+// a sum-check or bullet round: compress a point (an inverse square root: ~254 dependent squarings), a fixed-base scalar
+// multiplication (32 mixed additions from an 8-bit window table).  These sit on the strictly sequential
+// Fiat-Shamir path — about three compressions per round, 41 + 10 rounds at 2^20 — so their latency is proof latency.  The generic
+// 4 x u64 schoolbook product of field.h (shared with the device code, which uses other limb forms) costs ~27 ns; the unsaturated
+// form needs no carry chain inside the product and has a dedicated squaring.
+// Same values as point.h / field.h: every function here is checked against them by otti_host_selftest (tests/test_host.py).
+#pragma once
+#include "point.h"
+
+namespace otti {
+
+struct Fe { uint64_t v[5]; };
+struct PtFe { Fe X, Y, Z, T; };
+struct NielsFe { Fe yplusx, yminusx, xy2d; };               // 120 B
+
+Fe fe_from_fp(const Fp &a);
+Fp fe_to_fp(const Fe &a);
+PtFe ptfe_from(const Pt &p);
+Pt ptfe_to(const PtFe &p);
+NielsFe nielsfe_from(const Niels &n);
+void ptfe_madd(PtFe &p, const NielsFe &q, bool negate);      // p += q (or -= q)
+
+// RFC 9496 4.3.2 Encode; identical output to pt_encode (point.h)
+void pt_encode_fast(uint8_t out[32], const Pt &p);
+
+}  // namespace otti

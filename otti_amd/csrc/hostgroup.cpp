@@ -91,16 +91,16 @@ void FixedBaseTable::build(const Pt &base) {
     for (size_t i = 0; i < ext.size(); i++) z[i] = ext[i].Z;
     host_batch_invert(z.data(), z.size());
     t.resize(ext.size());
-    for (size_t i = 0; i < ext.size(); i++) t[i] = pt_to_niels(ext[i], z[i]);
+    for (size_t i = 0; i < ext.size(); i++) t[i] = nielsfe_from(pt_to_niels(ext[i], z[i]));
 }
 
-void FixedBaseTable::accumulate(Pt &acc, const Fr &s) const {
+void FixedBaseTable::accumulate(PtFe &acc, const Fr &s) const {
     int dig[kHostWindows]; scalar_digits(s, kHostWinBits, kHostWindows, dig);
     for (int w = 0; w < kHostWindows; w++) {
-        int d = dig[w];
-        if (d > 0) acc = pt_madd(acc, t[(size_t)w * kHostWinEntries + d - 1]);
-        else if (d < 0) acc = pt_msub(acc, t[(size_t)w * kHostWinEntries - d - 1]);
+        const int d = dig[w];
+        if (d) ptfe_madd(acc, t[(size_t)w * kHostWinEntries + (d > 0 ? d : -d) - 1], d < 0);
     }
 }
+void FixedBaseTable::accumulate(Pt &acc, const Fr &s) const { PtFe a = ptfe_from(acc); accumulate(a, s); acc = ptfe_to(a); }
 
 }  // namespace otti

@@ -14,6 +14,8 @@
 
 namespace otti {
 
+constexpr size_t kHostTailBits = 5;           // sum-check tables of at most 2^5 elements (all ranks together) are finished on the host
+constexpr int kTailSlot = 64;                 // where their elements land in the pinned result buffer
 constexpr double kSparseWitness = 0.25;       // above this share of small witness values the commitment uses the work-list MSM variant
 
 static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -301,15 +303,37 @@ std::vector<uint8_t> nizk_prove_resident(Instance &I, DeviceWitness &wit, Gens &
         st.claim = fr_zero(); st.blind_claim = fr_zero();
         { Term t2[2] = {{g.sc_1.G[0], fr_zero()}, {g.sc_1.h, fr_zero()}}; g.commit_terms_c(st.comm_claim.b, t2, 2); }
         P.sc1.comm_polys.resize(nrx); P.sc1.comm_evals.resize(nrx); P.sc1.proofs.resize(nrx);
-        std::vector<Fr> tail1[4];
+        // The device plays the rounds while the tables are long; once a table is down to a few dozen elements a round's kernel is
+        // all launch + hand-off latency (~15 us more than the arithmetic costs on a host core), so the LAST rounds are played on the
+        // host: the launch that produces the sums of round `ndev` also leaves the tables folded to T1 elements (per rank), they are
+        // copied out behind it, and the host folds and sums from there on (same arithmetic: host_cubic_evals / host_fold_top).
+        // Sharded, every rank does so identically on the T1 * G gathered elements.
+        const size_t lgT1 = std::min(s_loc, kHostTailBits > lgG ? kHostTailBits - lgG : (size_t)0), T1 = (size_t)1 << lgT1, ndev = s_loc - lgT1;
+        const size_t dsum = T1 >= 2 ? ndev + 1 : ndev;            // rounds whose sums the device delivers (a one-element local table has no pair left to sum)
+        std::vector<Fr> tail1[4]; bool tail_built = false;
+        auto fetch_tail = [&] { for (int k = 1; k < 4; k++) dev_fetch(c, S.T[k].p, kTailSlot + (k - 1) * (int)T1, T1); OTTI_HIP(hipEventRecord(c.ev0, c.stream)); };
+        auto build_tail = [&] {                                    // the tables as the device left them: T1 elements per table and rank
+            OTTI_HIP(hipEventSynchronize(c.ev0));
+            const Fr *mine = &c.h_results[kTailSlot];
+            std::vector<Fr> all;
+            if (sh) { all.resize(3 * T1 * G); sh->allgather(mine, 3 * T1 * sizeof(Fr), all.data()); }
+            for (int k = 1; k < 4; k++) {
+                tail1[k].resize(T1 * G);
+                for (size_t r = 0; r < G; r++) for (size_t i = 0; i < T1; i++) tail1[k][i * G + r] = (sh ? all.data() + 3 * T1 * r : mine)[(k - 1) * T1 + i];
+            }
+            tail1[0] = eq_evals_host(tau.data() + ndev, nrx - ndev);         // the eq table's remaining entries: c_j * eq(tau[ndev..), .)
+            for (auto &x : tail1[0]) x = fr_mul(x, cj);
+            tail_built = true;
+        };
         unsigned long long ticket = dev_sc_cubic3_eval(c, S.T[1].p, S.T[2].p, S.T[3].p, Nl, eq_src(s_loc - 1), 0);
+        if (ndev == 0) fetch_tail();
         const Fr one = fr_one();
         double tw = 0, tb = 0, tl = 0, tf = 0, ta;
-        const size_t ndev = nrx - lgG;                                           // rounds played on the device tables
         for (size_t j = 0; j < nrx; j++) {
             Fr e[3];
             ta = now_ms();
-            if (j < ndev) {
+            if (j >= dsum && !tail_built) build_tail();
+            if (j < dsum) {
                 c.wait_ticket(ticket);
                 e[0] = c.h_results[0]; e[1] = c.h_results[1]; e[2] = c.h_results[2];       // S_t = sum_i E_j[i] (Az_t Bz_t - Cz_t)[i], t = 0, 2, 3
                 if (sh) { for (auto &x : e) x = fr_mul(x, eq_ranks[rk]); sh->allreduce_fr(e, 3); }   // per-round exchange: 96 bytes per rank
@@ -324,35 +348,28 @@ std::vector<uint8_t> nizk_prove_resident(Instance &I, DeviceWitness &wit, Gens &
             tb += now_ms() - ta; ta = now_ms();
             P.rx[j] = p1.r_j;
             if (j < ndev) {
-                size_t len = Nl >> j;
+                const size_t len = Nl >> j;
                 if (len >= 4) ticket = dev_sc_cubic3_fold_eval(c, S.T[1].p, S.T[2].p, S.T[3].p, len, p1.r_j, eq_src(s_loc - j - 2), 0);
                 else for (int k = 1; k < 4; k++) dev_fold_top(c, S.T[k].p, len, p1.r_j);
+                if (j + 1 == ndev) fetch_tail();
                 // eq(tau_j, r_j) = tau_j r_j + (1 - tau_j)(1 - r_j)
                 cj = fr_mul(cj, fr_add(fr_mul(tau[j], p1.r_j), fr_mul(fr_sub(one, tau[j]), fr_sub(one, p1.r_j))));
-            } else for (auto &t : tail1) host_fold_top(t, p1.r_j);
+            }
             tl += now_ms() - ta; ta = now_ms();
             sumcheck_round_finish(P.sc1, j, p1, st, g, g.sc_4, tr);             // overlaps the device fold
             tf += now_ms() - ta;
-            if (sh && j + 1 == ndev) {                                           // one element per table and rank is left: collect them
-                for (int k = 1; k < 4; k++) dev_fetch(c, S.T[k].p, 8 + k, 1);
-                c.sync();
-                std::vector<Fr> all(3 * G);
-                sh->allgather(&c.h_results[9], 3 * sizeof(Fr), all.data());
-                for (int k = 1; k < 4; k++) { tail1[k].resize(G); for (size_t r = 0; r < G; r++) tail1[k][r] = all[3 * r + (k - 1)]; }
-                tail1[0].resize(G); for (size_t r = 0; r < G; r++) tail1[0][r] = fr_mul(cj, eq_ranks[r]);   // the eq table's G remaining entries
-            }
+            if (j >= ndev && !tail_built) build_tail();
+            if (j >= ndev) for (auto &t : tail1) host_fold_top(t, p1.r_j);
         }
-        if (getenv("OTTI_TRACE")) fprintf(stderr, "[otti] phase1 rounds=%zu wait %.3f begin %.3f launch %.3f finish %.3f ms\n", nrx, tw, tb, tl, tf);
+        if (getenv("OTTI_TRACE")) fprintf(stderr, "[otti] phase1 rounds=%zu (device %zu) wait %.3f begin %.3f launch %.3f finish %.3f ms\n", nrx, ndev + 1, tw, tb, tl, tf);
         blind_claim_postsc1 = st.blinds_evals[nrx - 1];
-        if (sh) for (int k = 0; k < 4; k++) c.h_results[8 + k] = tail1[k][0];
+        for (int k = 0; k < 4; k++) c.h_results[8 + k] = tail1[k][0];
     }
-    if (!sh) { for (int k = 1; k < 4; k++) dev_fetch(c, S.T[k].p, 8 + k, 1); OTTI_HIP(hipEventRecord(c.ev0, c.stream)); }
     // what phase two needs from rx alone — eq(rx, .) (the full table on every rank: a column needs every row) and the working copy of
     // z — is queued now, so the device builds it while the host runs the sigma protocols between the phases
     dev_eq_evals(c, P.rx.data(), nrx, S.T[0].p, S.eqs.p);
     if (sh) dev_gather_strided(c, wit.z.p, G, rk, S.zw.p, V2l);
     else OTTI_HIP(hipMemcpyAsync(S.zw.p, wit.z.p, 2 * V * sizeof(Fr), hipMemcpyDeviceToDevice, c.stream));
-    if (!sh) { OTTI_HIP(hipEventSynchronize(c.ev0)); c.h_results[8] = cj; }   // eq(tau, rx) is the scalar the rounds accumulated
     const Fr tau_claim = c.h_results[8], Az_claim = c.h_results[9], Bz_claim = c.h_results[10], Cz_claim = c.h_results[11];
     T.ms[2] = now_ms() - t0;
 
@@ -393,12 +410,27 @@ std::vector<uint8_t> nizk_prove_resident(Instance &I, DeviceWitness &wit, Gens &
         st.claim = claim2; st.blind_claim = blind_claim2;
         { Term t2[2] = {{g.sc_1.G[0], claim2}, {g.sc_1.h, blind_claim2}}; g.commit_terms_c(st.comm_claim.b, t2, 2); }
         P.sc2.comm_polys.resize(nry); P.sc2.comm_evals.resize(nry); P.sc2.proofs.resize(nry);
+        const size_t s_loc2 = nry - lgG, lgT2 = std::min(s_loc2, kHostTailBits > lgG ? kHostTailBits - lgG : (size_t)0), T2 = (size_t)1 << lgT2, ndev = s_loc2 - lgT2;
+        const size_t dsum = T2 >= 2 ? ndev + 1 : ndev;
+        std::vector<Fr> tail2[2]; bool tail_built = false;
+        auto fetch_tail = [&] { dev_fetch(c, S.zw.p, kTailSlot, T2); dev_fetch(c, S.ABC.p, kTailSlot + (int)T2, T2); OTTI_HIP(hipEventRecord(c.ev0, c.stream)); };
+        auto build_tail = [&] {
+            OTTI_HIP(hipEventSynchronize(c.ev0));
+            const Fr *mine = &c.h_results[kTailSlot];
+            std::vector<Fr> all;
+            if (sh) { all.resize(2 * T2 * G); sh->allgather(mine, 2 * T2 * sizeof(Fr), all.data()); }
+            for (int k = 0; k < 2; k++) {
+                tail2[k].resize(T2 * G);
+                for (size_t r = 0; r < G; r++) for (size_t i = 0; i < T2; i++) tail2[k][i * G + r] = (sh ? all.data() + 2 * T2 * r : mine)[k * T2 + i];
+            }
+            tail_built = true;
+        };
         unsigned long long ticket = dev_sc_quad_eval(c, S.zw.p, S.ABC.p, V2l, 0);
-        std::vector<Fr> tail2[2];
-        const size_t ndev = nry - lgG;
+        if (ndev == 0) fetch_tail();
         for (size_t j = 0; j < nry; j++) {
             Fr e[2];
-            if (j < ndev) {
+            if (j >= dsum && !tail_built) build_tail();
+            if (j < dsum) {
                 c.wait_ticket(ticket);
                 e[0] = c.h_results[0]; e[1] = c.h_results[1];
                 if (sh) sh->allreduce_fr(e, 2);
@@ -407,26 +439,17 @@ std::vector<uint8_t> nizk_prove_resident(Instance &I, DeviceWitness &wit, Gens &
             RoundPart1 p1 = sumcheck_round_begin(P.sc2, j, ev, 3, st, g, g.sc_3, tr);
             P.ry[j] = p1.r_j;
             if (j < ndev) {
-                size_t len = V2l >> j;
+                const size_t len = V2l >> j;
                 if (len >= 4) ticket = dev_sc_quad_fold_eval(c, S.zw.p, S.ABC.p, len, p1.r_j, 0);
                 else { dev_fold_top(c, S.zw.p, len, p1.r_j); dev_fold_top(c, S.ABC.p, len, p1.r_j); }
-            } else for (auto &t : tail2) host_fold_top(t, p1.r_j);
-            sumcheck_round_finish(P.sc2, j, p1, st, g, g.sc_3, tr);
-            if (sh && j + 1 == ndev) {
-                dev_fetch(c, S.zw.p, 8, 1); dev_fetch(c, S.ABC.p, 9, 1);
-                c.sync();
-                std::vector<Fr> all(2 * G);
-                sh->allgather(&c.h_results[8], 2 * sizeof(Fr), all.data());
-                for (int k = 0; k < 2; k++) { tail2[k].resize(G); for (size_t r = 0; r < G; r++) tail2[k][r] = all[2 * r + k]; }
+                if (j + 1 == ndev) fetch_tail();
             }
+            sumcheck_round_finish(P.sc2, j, p1, st, g, g.sc_3, tr);
+            if (j >= ndev && !tail_built) build_tail();
+            if (j >= ndev) for (auto &t : tail2) host_fold_top(t, p1.r_j);
         }
         blind_claim_postsc2 = st.blinds_evals[nry - 1];
-        if (sh) { claims_phase2[0] = tail2[0][0]; claims_phase2[1] = tail2[1][0]; }
-        else {
-            dev_fetch(c, S.zw.p, 8, 1); dev_fetch(c, S.ABC.p, 9, 1);
-            c.sync();
-            claims_phase2[0] = c.h_results[8]; claims_phase2[1] = c.h_results[9];
-        }
+        claims_phase2[0] = tail2[0][0]; claims_phase2[1] = tail2[1][0];
     }
     T.ms[4] = now_ms() - t0;
 

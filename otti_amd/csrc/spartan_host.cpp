@@ -123,13 +123,13 @@ std::unique_ptr<Gens> gens_new(size_t num_cons, size_t num_vars, size_t num_inpu
 }
 
 Pt Gens::commit_terms(const Term *t, size_t n) const {
-    Pt acc = pt_identity();
+    PtFe acc = ptfe_from(pt_identity());
     for (size_t i = 0; i < n; i++) {
         int slot = small_slot[t[i].base];
         if (slot < 0) throw Error(OTTI_ERR_INTERNAL, "commit_terms: base without a host table");
         small_tables[slot].accumulate(acc, t[i].s);
     }
-    return acc;
+    return ptfe_to(acc);
 }
 Pt Gens::commit_generic(const Fr *v, size_t n, const Fr &blind, const GensView &gv) const {
     std::vector<Fr> s(v, v + n); s.push_back(blind);

@@ -117,10 +117,7 @@ def test_bullet_rounds_on_original_generators_equal_the_folding_reduction(rng, l
 
 # ------------------------------------------------------------------------------------------------ device pointers + caller's stream
 def test_device_pointer_entry_points_match_the_staged_ones(rng):
-    import ctypes
-    hip = ctypes.CDLL("libamdhip64.so")
-    stream = ctypes.c_void_p()
-    assert hip.hipStreamCreate(ctypes.byref(stream)) == 0
+    stream = KD.stream_create()
     try:
         for st in (None, stream):
             n = 1 << 12
@@ -138,7 +135,7 @@ def test_device_pointer_entry_points_match_the_staged_ones(rng):
             KD.fold_top(dC, n // 2, r2, st)
             out = oa.DeviceArray(n // 4); KD.fold_bot(dD, out, n // 2, r2, st)
             if st is not None:
-                assert hip.hipStreamSynchronize(st) == 0
+                KD.stream_sync(st)
             assert eq(dC.to_host(n // 4), orc.fold_top(fc, r2)) and eq(out.to_host(), orc.fold_bot(fd, r2))
             rr = orc.rand_fr(rng, 14); dE = oa.DeviceArray(1 << 14)
             KD.eq_evals(rr, dE, st)
@@ -158,7 +155,7 @@ def test_device_pointer_entry_points_match_the_staged_ones(rng):
             dZ, dbl, dpts = oa.DeviceArray.from_host(Zm), oa.DeviceArray.from_host(bl), oa.DeviceArray(Lr)
             KD.msm_rows(gens, dZ, Lr, Rr, dbl, dpts, st)
             if st is not None:
-                assert hip.hipStreamSynchronize(st) == 0
+                KD.stream_sync(st)
             want = orc.multiply_vec(oi, z)
             assert all(eq(o[k].to_host(), want[k]) for k in range(3))
             ea, eb, ec = orc.eval_table_sparse(oi, ex); l = orc.L_ORDER
@@ -167,4 +164,4 @@ def test_device_pointer_entry_points_match_the_staged_ones(rng):
             assert orc.fr_to_ints(dout.to_host()) == comb
             assert eq(dpts.to_host(), orc.commit_rows(og, Zm, Lr, Rr, bl))
     finally:
-        hip.hipStreamDestroy(stream)
+        KD.stream_destroy(stream)

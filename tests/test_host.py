@@ -264,3 +264,8 @@ def test_host_parsers_under_address_and_ub_sanitizers(tmp_path):
                          capture_output=True, text=True, timeout=900, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0"))
     assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-3000:]
     assert "sanitized run" in res.stdout
+
+
+def test_host_fast_paths_agree_with_the_generic_field_code():
+    """five-limb GF(2^255-19) point compression and the fixed-base window tables of the prover's per-round host work (hostfast.h)"""
+    oa.host_selftest(300)
