@@ -3,29 +3,40 @@
 
   python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
 
-A "step" is one batch of B independent NIZK::prove calls of the workload in flight on a GPU at once (B prover threads of the rank's
-process, each with its own stream and workspace, sharing the instance, the generator window table and the resident witness: a single
-proof is a chain of ~50 strictly sequential Fiat-Shamir rounds that leave most of the chip idle, so a prover that serves a stream of
-proofs keeps several in flight).  B = --concurrent (default: what this rank's host cores feed, at most 6; --concurrent 1 = one proof
-at a time, whose latency is reported as single_proof_ms either way).  Instance, generators (and their window table) and witness are
-resident in HBM before timing; W untimed warm-up steps, then exactly K timed steps bracketed by barrier + device sync; rank 0 prints
-ONE JSON line; value = constraints of all proofs of all ranks / elapsed.
-metric = BASELINE.json's "R1CS constraints/sec proved" on the synthetic 2^20-constraint R1CS of SURVEY.md 8(d).
-Every timed proof is checked: all K proofs of a rank are byte-identical (fixed random-tape seed) and the product verifier
-accepts them; rank 0 additionally compares a 2^12 proof with the CPU oracle (checker only, outside the timed region).
+Metric (BASELINE.json, SURVEY.md 8(d)): R1CS constraints proved per second = N_constraints / wall time of NIZK::prove, on the
+synthetic satisfiable 2^20-constraint R1CS; instance, generators (with their window table) and witness resident in HBM before timing.
+A "step" is ONE NIZK::prove of that workload, one proof at a time; W untimed warm-up steps, then exactly K timed steps bracketed by
+barrier + device synchronisation; time = max over ranks; rank 0 prints ONE JSON line.
 
-N > 1, default: each rank proves its own independent instance of the same size — no data-path collective; scaling = weak
-(proofs are independent objects; this is how a node serves a stream of Otti proofs).
-N > 1 with --shard: ALL ranks prove ONE instance together (commitment rows, sum-check tables and the sparse
-matrices are sharded; per-round sums cross ranks through the node-local mailbox of otti_amd/csrc/shard.h; the witness is
-replicated beforehand with a torch.distributed broadcast over RCCL/xGMI); value = N / time of that one proof; scaling = strong.
+  N = 1   value = 2^20 * K / elapsed  (single-proof latency, what SURVEY 8(d) defines)
+  N > 1   ALL ranks prove the SAME proof together (SURVEY.md 8(e): commitment rows, sparse matrices and sum-check tables are sharded;
+          the witness is replicated beforehand by a torch.distributed broadcast over RCCL/xGMI; per-round sums cross ranks through
+          the node-local mailbox or, with OTTI_SHARD_TRANSPORT=rccl, an ncclUint64/ncclSum all-reduce of u64 lanes); value =
+          2^20 * K / elapsed of that one sharded proof; "scaling": "strong".  --replicas makes the primary line independent proofs per
+          GPU instead (weak scaling).
+
+Extras in the same line (all measured in this run, none of them the headline):
+  in_flight     throughput with B independent proofs in flight per GPU (B prover threads, each with its OWN instance, witness and
+                random-tape seed; they share only the generator table) — how a prover serving a stream of proofs uses the card;
+                summed over the GPUs (independent proofs per GPU = the replicas figure for N > 1)
+  roofline      the kernel class with the largest summed device time of one instrumented proof, over ALL classes: algorithmic bytes
+                per launch / average launch duration (HIP events on the library's stream over the timed region) against the HBM
+                peak; for the MSM classes additionally mixed point additions per second against the ALU roof measured in this run
+  cpu_baseline  the CPU oracle (the reference Rust prover cannot be built here) on the same workload, host cores stated
+  spzk_e2e      the path run.py actually executes: `spzk verify --nizk` on a zkInterface triple of the workload, one process
+                (parse + Instance::new + generators + device tables + prove + verify), next to the oracle's prove + verify
+Every timed proof is checked: identical bytes across steps (fixed seed), accepted by the verifier; rank 0 also compares a 2^12 proof
+with the CPU oracle (checker only, outside the timed region) and, when the CPU baseline runs the same workload, the full-size proof.
 OTTI_BENCH_REHEARSE=1 puts every rank on GPU 0 with the gloo backend (how the sharded mode is rehearsed on a one-GPU box).
 """
 import argparse
 import hashlib
 import json
 import os
+import subprocess
 import sys
+import tempfile
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -34,12 +45,33 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (guide: MI355X_MICROARCH.md); ~6300 achievable
 F = 32                          # bytes per field element
-MADD_PEAK_G = 24.07             # measured: 10-limb mixed point additions per second (x1e9), tools/mulbench.hip on MI355X
+KERNEL_NAMES = {"msm_rows": "k_msm_rows<0>", "msm_small": "k_msm_small", "sc_cubic": "k_sc_cubic3_fold_eval", "sc_quad": "k_sc_quad_fold_eval",
+                "spmv": "k_spmv3_light", "msm_finish": "k_encode_points", "eq": "k_eq_expand", "poly_bound": "k_poly_bound_slab"}
 
 
 def algorithmic_bytes(N, V, nnz):
     """compulsory HBM traffic of one proof, W = 80*nnz + 704*N + 736*V bytes."""
     return 80 * nnz + 704 * N + 736 * V
+
+
+def class_bytes_per_proof(cls, N, V, nnz):
+    """algorithmic bytes one proof moves in the launches of a kernel class (SURVEY 8(d)'s per-stage figures)"""
+    ell = V.bit_length() - 1
+    L, R = 1 << (ell // 2), 1 << (ell - ell // 2)
+    nrx, nry, lgR = N.bit_length() - 1, (2 * V).bit_length() - 1, R.bit_length() - 1
+    return {
+        "msm_rows": F * V,                                                     # the witness commitment reads V scalars once
+        # the one/two-row launches: 32 B per term summed — blinds, the tape-only points of every round (4 rows x 6 bases), Cx, delta,
+        # the bullet rounds (2 rows x (R/2 + 2) terms each)
+        "msm_small": F * (L + 24 * (nrx + nry) + 2 * (R + 1) + lgR * (R + 4)),
+        "sc_cubic": 384 * N,                                                   # three tables (eq factored out), fold fused with the next round's sums
+        "sc_quad": 512 * V,
+        "spmv": 80 * nnz + 160 * V + 128 * N,
+        "eq": F * N + 2 * F * (L + R),
+        "poly_bound": F * V + 2 * F * R,
+        "msm_finish": (128 + 32) * L,                                          # row sums in, compressed points out
+        "bullet": 3 * F * R, "reduce": 4 * F, "other": 0,
+    }.get(cls, 0)
 
 
 def usable_cores():
@@ -67,13 +99,17 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log2-constraints", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the one-shot `spzk verify --nizk` figure")
     ap.add_argument("--dist", choices=("uniform", "compiler"), default="uniform", help="synthetic instance distribution (SURVEY 8d); the metric is quoted on 'uniform'")
     ap.add_argument("--cpu-log2", type=int, default=None, help="size of the CPU-baseline sample (default: same workload)")
-    ap.add_argument("--shard", action="store_true", help="N > 1: all ranks prove ONE instance together (strong scaling) instead of one proof per GPU")
-    ap.add_argument("--concurrent", type=int, default=0, help="prover threads per GPU: a step is then that many proofs of the workload in flight at once "
-                    "(each thread has its own stream/workspace; instance, window table and witness are shared).  0 = as many as the host "
-                    "cores of this rank feed (2 host threads per prover, at most 6); 1 = one proof at a time (latency mode)")
+    ap.add_argument("--replicas", action="store_true", help="N > 1: primary line = one independent proof per GPU (weak scaling) instead of one proof sharded over all GPUs")
+    ap.add_argument("--shard", action="store_true", help="(default for N > 1; kept for older command lines)")
+    ap.add_argument("--in-flight", type=int, default=0, help="extra figure: proofs in flight per GPU (prover threads).  0 = what this rank's host cores feed "
+                    "(2 host threads per prover, at most 6); -1 = skip")
+    ap.add_argument("--concurrent", type=int, default=None, help="alias of --in-flight (older command lines)")
     args = ap.parse_args()
+    if args.concurrent is not None:
+        args.in_flight = args.concurrent if args.concurrent != 1 else -1
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -82,13 +118,12 @@ def main():
     if rehearse:
         local_rank = 0
     os.environ.setdefault("OTTI_DEVICE", str(local_rank))
-    shard = bool(args.shard and world > 1)
-    # how many proofs this rank keeps in flight, and the environment that goes with it — before anything initialises the HIP runtime
+    shard = world > 1 and not args.replicas
     lws = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
     cores_here = max(1, usable_cores() // lws)                  # host cores of this rank
-    conc = 1 if shard else (args.concurrent if args.concurrent > 0 else max(1, min(6, cores_here // 2)))
-    # host threads per prover (itself + spinning helpers for the per-round sigma-protocol work): share this rank's cores fairly
-    os.environ.setdefault("OTTI_HOST_THREADS", str(max(1, min(4, cores_here // conc))))
+    conc = 0 if args.in_flight < 0 else (args.in_flight if args.in_flight > 0 else max(1, min(6, cores_here // 2)))
+    # host threads of the single-proof prover (itself + spinning helpers for the per-round sigma-protocol work)
+    os.environ.setdefault("OTTI_HOST_THREADS", str(max(1, min(4, cores_here))))
     if conc > 1:
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")         # one hardware queue per prover stream (HIP's default is 4)
     dist = None
@@ -102,7 +137,6 @@ def main():
         else:
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     xdev = "cpu" if rehearse else "cuda"                     # where tensors handed to torch.distributed live
-    import threading
     import numpy as np
     import otti_amd as oa
 
@@ -112,10 +146,11 @@ def main():
     lg = args.log2_constraints
     n, ni, label, seed = 1 << lg, 10, b"nizk_example", b"\x2a" * 32
     gen = oa.synth_r1cs if args.dist == "uniform" else oa.synth_r1cs_compiler_like
-    r = gen(n, ni, 1 if shard else 1 + rank)               # one proof per GPU: each rank its own instance; --shard: the same one
+    r = gen(n, ni, 1 if (shard or world == 1) else 1 + rank)   # --replicas: each rank its own instance
     inst = oa.Instance.new(r["num_cons"], r["num_vars"], r["num_inputs"], r["A"], r["B"], r["C"])
     gens = oa.NIZKGens.new(r["num_cons"], r["num_vars"], r["num_inputs"])
     vars_, inputs = oa.VarsAssignment.new(r["vars"]), oa.InputsAssignment.new(r["inputs"])
+    transport = None
     if shard:
         # the instance is public (every rank builds it); the WITNESS exists on rank 0 only and reaches the other GPUs over RCCL/xGMI
         import torch
@@ -126,6 +161,7 @@ def main():
         name = [("otti-bench-%d-%d" % (os.getpid(), time.time_ns())) if rank == 0 else None]
         dist.broadcast_object_list(name, src=0)
         oa.shard_init(name[0], rank, world)
+        transport = oa.shard_info()[2]
     t0 = time.perf_counter()
     inst.prepare_device(gens)                              # CSR upload + generator window table: resident before timing
     t_prepare = time.perf_counter() - t0
@@ -146,71 +182,27 @@ def main():
     def prove_once():
         return oa.NIZK.prove_sharded(inst, wit, gens, label, seed) if shard else oa.NIZK.prove(inst, wit, None, gens, label, seed)
 
-    proofs = []
-    for _ in range(args.warmup):
-        proofs.append(prove_once())
-    # latency of ONE proof with the GPU to itself (untimed region; the timed region below may keep several proofs in flight)
-    single_ms = []
-    for _ in range(3):
-        t0 = time.perf_counter(); proofs.append(prove_once()); single_ms.append(1e3 * (time.perf_counter() - t0))
-    # one untimed, fully instrumented proof: per-class kernel time -> picks the dominant kernel class
+    proofs = [prove_once() for _ in range(args.warmup)]
+    # one untimed, fully instrumented proof: per-class kernel time -> the dominant kernel class, chosen over ALL classes
     oa.stats_enable(True)
-    prove_once()
+    proofs.append(prove_once())
     breakdown = oa.stats_read()
-    # dominant kernel = the streaming/ALU kernel class with the largest summed time.  "msm_small" is the same k_msm_rows kernel in
-    # its one/two-row launches of the bullet reduction (latency-bound by construction); it is reported in kernel_ms_per_step only.
-    dom = max(("msm_rows", "sc_cubic", "sc_quad", "spmv"), key=lambda k: breakdown[k][1])
+    dom = max(breakdown, key=lambda k: breakdown[k][1])
     # timed region: HIP events only around the dominant class (two event records per launch would otherwise tax every round)
     oa.stats_enable(True, only=dom)
-    # --concurrent B: B - 1 more prover threads (own device context each), warmed up and parked on a barrier
-    # the K steps x B proofs of the timed region are handed out from one counter, so no thread idles while another still has work
-    gate, others, other_proofs, other_stats, errors = threading.Barrier(conc), [], [], [], []
-    todo, todo_lock = [conc * args.steps], threading.Lock()
-
-    def take():
-        with todo_lock:
-            if todo[0] <= 0:
-                return False
-            todo[0] -= 1
-            return True
-
-    def extra_prover():
-        try:
-            oa.stats_enable(True, only=dom)                     # kernel timing state is per prover thread; its event pool is built on first use
-            mine = [prove_once() for _ in range(max(1, args.warmup))]
-            oa.stats_enable(True, only=dom)                     # again: resets the counters for the timed region
-            gate.wait()
-            while take():
-                mine.append(prove_once())
-            other_stats.append(oa.stats_read()[dom])
-            oa.stats_enable(False)
-            other_proofs.extend(mine)
-        except BaseException as e:                              # noqa: BLE001 - reported after the join
-            errors.append(e)
-            gate.abort()
-
-    for _ in range(conc - 1):
-        th = threading.Thread(target=extra_prover); th.start(); others.append(th)
     barrier()
-    gate.wait()
     t0 = time.perf_counter()
-    stage_acc, mine_n = {}, 0
-    while take():
+    stage_acc = {}
+    for _ in range(args.steps):
         p = prove_once()                                       # returns after the library's stream has been synchronised
-        proofs.append(p); mine_n += 1
+        proofs.append(p)
         for k, v in p.stage_ms.items():
             stage_acc[k] = stage_acc.get(k, 0.0) + v
-    for th in others:
-        th.join()
     barrier()
     elapsed = time.perf_counter() - t0
-    if errors:
-        raise errors[0]
-    proofs += other_proofs
     stats = dict(oa.stats_read())
     oa.stats_enable(False)
-    for cnt_, ms_ in other_stats:                               # the dominant kernel's launches of every prover thread in the timed region
-        stats[dom] = (stats[dom][0] + cnt_, stats[dom][1] + ms_)
+    madd_peak = oa.madd_peak()                                 # the MSM's ALU roof, measured in this run (after the timed region)
 
     # correctness of what was timed
     digests = {hashlib.sha256(p.bytes).hexdigest() for p in proofs}
@@ -231,6 +223,56 @@ def main():
             assert all(bool((e == dg).all()) for e in every), "ranks of a sharded proof returned different bytes"
             oa.shard_finalize()
 
+    # ---- extra: B independent proofs in flight per GPU, each prover thread with its own instance, witness and seed
+    in_flight = None
+    if conc >= 1:
+        isteps = max(2, min(args.steps, 10))
+        jobs = []
+        for t in range(conc):
+            if t == 0 and not shard:
+                jobs.append((inst, wit, seed))
+                continue
+            rt = gen(n, ni, 1000 + 16 * rank + t)
+            it = oa.Instance.new(rt["num_cons"], rt["num_vars"], rt["num_inputs"], rt["A"], rt["B"], rt["C"])
+            it.prepare_device(gens)
+            jobs.append((it, oa.Witness(it, oa.VarsAssignment.new(rt["vars"]), oa.InputsAssignment.new(rt["inputs"])), bytes([t + 1]) * 32))
+            del rt
+        gate, errors, lat = threading.Barrier(conc + 1), [], []
+
+        def prover(job):
+            try:
+                it, wt, sd = job
+                oa.NIZK.prove(it, wt, None, gens, label, sd)          # warm-up: this thread's device context and workspace
+                gate.wait()
+                for _ in range(isteps):
+                    t1 = time.perf_counter(); oa.NIZK.prove(it, wt, None, gens, label, sd); lat.append(time.perf_counter() - t1)
+            except BaseException as e:                              # noqa: BLE001 - reported after the join
+                errors.append(e)
+                gate.abort()
+
+        ths = [threading.Thread(target=prover, args=(j,)) for j in jobs]
+        for th in ths:
+            th.start()
+        barrier()
+        gate.wait()
+        t0 = time.perf_counter()
+        for th in ths:
+            th.join()
+        barrier()
+        el = time.perf_counter() - t0
+        if errors:
+            raise errors[0]
+        if dist is not None:
+            import torch
+            t = torch.tensor([el], dtype=torch.float64, device=xdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        in_flight = {"proofs_in_flight_per_gpu": conc, "n_gpus": world, "value": round(world * conc * isteps * n / el, 1), "unit": "constraints/s",
+                     "proofs_per_thread": isteps, "latency_ms_per_proof": round(1e3 * sum(lat) / max(1, len(lat)), 3),
+                     "note": "independent proofs: every prover thread has its own instance, witness and random-tape seed (only the generator window table is shared); "
+                             "each GPU works for itself (for n_gpus > 1 this is the replicas figure)"}
+        del jobs
+
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -238,7 +280,7 @@ def main():
 
     steps = max(1, args.steps)
     ms_per_step = 1e3 * elapsed / steps
-    value = (1 if shard else world) * conc * n * steps / elapsed
+    value = (world if (world > 1 and not shard) else 1) * n * steps / elapsed
 
     # oracle cross-check of the GPU path (checker only; small size, outside the timed region)
     import orc
@@ -249,68 +291,53 @@ def main():
     op, _ = orc.nizk_prove(oi, rs["vars"], rs["inputs"], og, label, seed)
     parity_ok = sp.bytes == op
 
-    # dominant kernel: the one with the largest summed HIP-event time inside the timed region
+    # ---- roofline of the dominant kernel class (largest summed HIP-event time of one proof, all classes considered)
     cnt, tot_ms = stats[dom]
-    ell = V.bit_length() - 1
-    Lsz, Rsz = 1 << (ell // 2), 1 << (ell - ell // 2)
+    per_proof = breakdown[dom][0]                               # launches of that class in one proof
     roofline = None
-    if cnt:
+    if cnt and per_proof:
         avg_ms = tot_ms / cnt
-        if dom == "msm_rows":
-            # the witness commitment: one launch per proof reads V scalars once (SURVEY 8d "commit 32*V"); the window-table gathers
-            # (96 B per mixed addition) are not compulsory traffic and are not counted
-            bytes_per_launch = F * V
-        elif dom == "sc_cubic":
-            bytes_per_launch = 384 * N / max(1, (N.bit_length() - 1))          # phase one streams three tables (eq factored out): 384*N over log2(N) launches
-        elif dom == "sc_quad":
-            bytes_per_launch = 512 * V / max(1, ((2 * V).bit_length() - 1))
-        elif dom == "spmv":
-            bytes_per_launch = (80 * nnz + 160 * V + 128 * N) / 2.0
-        else:
-            bytes_per_launch = algorithmic_bytes(N, V, nnz) / max(1, cnt / steps)
-        if shard:
-            bytes_per_launch /= world                      # each rank's launch covers 1/world of the rows / table
+        bytes_per_launch = class_bytes_per_proof(dom, N, V, nnz) / per_proof / (world if shard else 1)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-        traffic = None
-        try:   # HBM traffic of the dominant kernel's largest launch, from a separate rocprofv3 --pmc pass (profiles/, see its note)
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
-            kname = {"msm_rows": "k_msm_rows<0>", "sc_cubic": "k_sc_cubic3_fold_eval", "sc_quad": "k_sc_quad_fold_eval", "spmv": "k_spmv3_light"}.get(dom)
-            if kname and lg == pm.get("log2_constraints", 20) and cbits == pm.get("msm_window_bits", 12):
-                traffic = pm["kernels"][kname]["traffic_bytes_corrected"]
-        except Exception:
-            traffic = None
-        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic, "launches": cnt, "avg_launch_ms": round(avg_ms, 4),
-                    "algorithmic_bytes_per_launch": int(bytes_per_launch)}
-        if conc > 1 and breakdown[dom][0]:
-            # the same kernel with the GPU to itself (the instrumented single proof above): under `conc` proofs in flight a launch shares
-            # the CUs with other streams' kernels and its wall duration is no longer the kernel's own speed
-            u_ms = breakdown[dom][1] / breakdown[dom][0]
-            roofline["uncontended"] = {"avg_launch_ms": round(u_ms, 4), "achieved": round(bytes_per_launch / (u_ms * 1e-3) / 1e9, 3),
-                                       "frac": round(bytes_per_launch / (u_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 6)}
-        if dom == "msm_rows":
+        traffic, traffic_src = None, None
+        for cand in ("r2_pmc_traffic.json", "r1_pmc_traffic.json"):   # HBM bytes of the kernel's largest launch, from a SEPARATE rocprofv3 --pmc pass
+            try:
+                pm = json.load(open(os.path.join(ROOT, "profiles", cand)))
+                if lg == pm.get("log2_constraints", 20) and cbits == pm.get("msm_window_bits", 12) and KERNEL_NAMES.get(dom) in pm["kernels"]:
+                    traffic = pm["kernels"][KERNEL_NAMES[dom]]["traffic_bytes_corrected"]
+                    traffic_src = "profiles/%s: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, largest launch of the kernel (not measured in this run)" % cand
+                    break
+            except Exception:
+                pass
+        roofline = {"bound": "hbm", "kernel": dom, "kernel_name": KERNEL_NAMES.get(dom, dom), "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic, "traffic_source": traffic_src, "launches": cnt,
+                    "launches_per_proof": per_proof, "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(bytes_per_launch),
+                    "chosen_from": {k: round(v[1], 3) for k, v in breakdown.items() if v[0]}}
+        if dom in ("msm_rows", "msm_small"):
             W = 253 // cbits + 1
-            adds = V * W // (world if shard else 1)        # one mixed addition (7 multiplications in GF(2^255-19)) per scalar and window
+            adds = class_bytes_per_proof(dom, N, V, nnz) // F * W / per_proof / (world if shard else 1)   # one mixed addition per scalar and window
             rate = adds / (avg_ms * 1e-3)
-            roofline["alu"] = {"bound": "integer ALU (v_mad_u64_u32)", "achieved": round(rate / 1e9, 3), "peak": MADD_PEAK_G, "unit": "G mixed additions/s",
-                               "frac": round(rate / 1e9 / MADD_PEAK_G, 4),
-                               "frac_uncontended": round(adds / (roofline["uncontended"]["avg_launch_ms"] * 1e-3) / 1e9 / MADD_PEAK_G, 4) if "uncontended" in roofline else None,
-                               "note": "peak = tools/mulbench.hip p10_madd throughput on this chip, all CUs busy, operands in registers"}
+            roofline["alu"] = {"bound": "integer ALU (v_mad_u64_u32)", "achieved": round(rate / 1e9, 3), "peak": round(madd_peak / 1e9, 3),
+                               "unit": "G mixed additions/s", "frac": round(rate / madd_peak, 4),
+                               "note": "peak = otti_bench_madd_peak measured in this run: the kernel's own 7-multiplication mixed addition, operands in registers, every CU busy"}
     whole = algorithmic_bytes(N, V, nnz)
-    proof_gbps = conc * whole / (ms_per_step * 1e-3) / 1e9
+    proof_gbps = whole / (ms_per_step * 1e-3) / 1e9
 
-    cpu_baseline = None
-    if not args.no_cpu_baseline:
+    cpu_baseline, cpu_e2e_ms = None, None
+    if not args.no_cpu_baseline and world == 1:
         cores = int(os.environ.get("OTTI_CPU_THREADS", min(usable_cores(), 16)))   # a 1-GPU box's CPU share is 16 cores
         clg = args.cpu_log2 if args.cpu_log2 is not None else lg
-        cr = r if (clg == lg and rank == 0) else gen(1 << clg, ni, 1)
+        cr = r if clg == lg else gen(1 << clg, ni, 1)
         ci, cg = orc.OInstance(cr["num_cons"], cr["num_vars"], cr["num_inputs"], cr["A"], cr["B"], cr["C"]), orc.OGens(cr["num_cons"], cr["num_vars"], cr["num_inputs"])
         orc.set_threads(cores)
-        orc.nizk_prove(orc.OInstance(256, 256, ni, *[oa.synth_r1cs(256, ni, 1)[k] for k in "ABC"]), oa.synth_r1cs(256, ni, 1)["vars"],
-                       oa.synth_r1cs(256, ni, 1)["inputs"], orc.OGens(256, 256, ni))       # spin up the OpenMP team
+        tiny = oa.synth_r1cs(256, ni, 1)
+        orc.nizk_prove(orc.OInstance(256, 256, ni, tiny["A"], tiny["B"], tiny["C"]), tiny["vars"], tiny["inputs"], orc.OGens(256, 256, ni))   # spin up the OpenMP team
         t0 = time.perf_counter()
         cp, cms = orc.nizk_prove(ci, cr["vars"], cr["inputs"], cg, label, seed)
         ct = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        assert orc.nizk_verify(ci, cr["inputs"], cg, cp) == 0
+        cpu_e2e_ms = 1e3 * (ct + time.perf_counter() - t0)
         same = (cp == proofs[-1].bytes) if clg == lg else None
         # SURVEY 8(d) also asks for the single-thread figure: one proof of a 2^16 instance on one core (a bounded sample)
         slg = min(clg, 16)
@@ -327,24 +354,56 @@ def main():
                                   "reference Spartan (Rust) is not buildable here",
                         "proof_equals_gpu_proof": same, "stage_ms": [round(x, 1) for x in cms]}
 
+    # ---- the one-shot path run.py executes: spzk verify --nizk <three zkif files>, one process
+    spzk_e2e = None
+    if not args.no_e2e and world == 1:
+        spzk = os.path.join(ROOT, "otti_amd", "spzk")
+        with tempfile.TemporaryDirectory(prefix="otti-bench-") as td:
+            pre = os.path.join(td, "w")
+            oa.zkif_write(r, pre + ".zkif", pre + ".inp.zkif", pre + ".wit.zkif")
+            fsize = sum(os.path.getsize(pre + e) for e in (".zkif", ".inp.zkif", ".wit.zkif"))
+            best, lines = None, None
+            for _ in range(2):                                  # second run: page cache warm, as in a pipeline that has just written the files
+                t0 = time.perf_counter()
+                res = subprocess.run([spzk, "verify", "--nizk", pre + ".zkif", pre + ".inp.zkif", pre + ".wit.zkif", "--seed", "2a" * 32], capture_output=True, text=True)
+                dt = 1e3 * (time.perf_counter() - t0)
+                assert res.returncode == 0 and "Verification successful" in res.stdout, res.stdout + res.stderr
+                if best is None or dt < best:
+                    best, lines = dt, res.stdout
+            stages = {}
+            for ln in lines.splitlines():
+                parts = ln.strip("* ").rsplit(" ", 2)
+                if len(parts) == 3 and parts[2] == "ms":
+                    try:
+                        stages[parts[0].strip()] = float(parts[1])
+                    except ValueError:
+                        pass
+            spzk_e2e = {"ms": round(best, 1), "process": "otti_amd/spzk verify --nizk c.zkif i.inp.zkif w.wit.zkif (process start to exit, files in the page cache)",
+                        "zkif_bytes": fsize, "stages_ms": stages,
+                        "cpu_prove_plus_verify_ms": None if cpu_e2e_ms is None else round(cpu_e2e_ms, 1),
+                        "cpu_note": "CPU oracle NIZK::prove + NIZK::verify of the same instance on the host cores above, instance already parsed (no zkif reader in the oracle)"}
+
     out = {
         "metric": "R1CS constraints/sec proved (Spartan NIZK) at 2^%d" % lg, "value": round(value, 1), "unit": "constraints/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-        "scaling": "strong" if shard else "weak", "vs_baseline": None, "dtype": "u256 (GF(l) / GF(2^255-19), 8 x u32 limbs)", "data": "synthetic",
+        "scaling": "weak" if (world > 1 and not shard) else "strong", "vs_baseline": None, "dtype": "u256 (GF(l) / GF(2^255-19), 8 x u32 limbs)", "data": "synthetic",
         "config": {"workload": (f"synthetic satisfiable R1CS, 2^{lg} constraints = variables, 10 inputs, 1 nnz/row/matrix, uniform GF(l) witness "
                                 if args.dist == "uniform" else
                                 f"synthetic compiler-like R1CS, 2^{lg} constraints = variables, 10 inputs, 1..8 nnz/row/matrix, 90% of the witness < 2^64, heavy constant column ")
-                               + "(SURVEY 8d); witness/instance/generators resident in HBM; one step = "
-                               + ("one NIZK::prove" if conc == 1 else "%d independent NIZK::prove calls of that workload in flight on the GPU (one prover thread each)" % conc),
-                   "parallelism": (("1 proof sharded over %d GPUs" % world if shard else "1 proof per GPU") if world > 1 else "single GPU")
-                                  + ("" if conc == 1 else ", %d proofs in flight per GPU (one prover thread each)" % conc), "proofs_in_flight_per_gpu": conc, "msm_window_bits": cbits, "msm_table_GB": round(table_bytes / 1e9, 2)},
+                               + "(SURVEY 8d); witness/instance/generators resident in HBM; one step = one NIZK::prove, one proof at a time",
+                   "parallelism": ("1 proof sharded over %d GPUs (%s exchange of the per-round sums)" % (world, transport)) if shard else
+                                  ("1 independent proof per GPU" if world > 1 else "single GPU"),
+                   "msm_window_bits": cbits, "msm_table_GB": round(table_bytes / 1e9, 2)},
         "roofline": roofline,
         "cpu_baseline": cpu_baseline,
-        "stage_ms": {k: round(v / max(1, mine_n), 3) for k, v in stage_acc.items()},
-        "kernel_ms_per_step": {k: round(v[1], 3) for k, v in breakdown.items() if v[0]},
+        "in_flight": in_flight,
+        "spzk_e2e": spzk_e2e,
+        "stage_ms": {k: round(v / steps, 3) for k, v in stage_acc.items()},
+        "kernel_ms_per_proof": {k: round(v[1], 3) for k, v in breakdown.items() if v[0]},
+        "kernel_launches_per_proof": {k: v[0] for k, v in breakdown.items() if v[0]},
         "whole_proof_algorithmic_GBps": round(proof_gbps, 2), "whole_proof_hbm_frac": round(proof_gbps / (HBM_PEAK_GBPS * (world if shard else 1)), 6),
-        "prepare_device_ms": round(1e3 * t_prepare, 1), "single_proof_ms": round(min(single_ms), 3), "witness_upload_ms": round(1e3 * t_upload, 2), "verify_ms": round(1e3 * t_verify, 2), "proof_bytes": len(proofs[-1].bytes), "proof_sha256": next(iter(digests)),
-        "oracle_parity_2^12": parity_ok,
+        "prepare_device_ms": round(1e3 * t_prepare, 1), "witness_upload_ms": round(1e3 * t_upload, 2), "verify_ms": round(1e3 * t_verify, 2),
+        "proof_bytes": len(proofs[-1].bytes), "proof_sha256": next(iter(digests)), "oracle_parity_2^12": parity_ok,
     }
     print(json.dumps(out))
     if dist is not None:

@@ -99,6 +99,9 @@ int32_t otti_nizk_prove_resident(otti_instance *inst, otti_witness *wit, otti_ge
    otti_shard_allgather / otti_shard_allreduce are the exchange primitives themselves (host memory; usable without a GPU). */
 int32_t otti_shard_init(const char *segment_name, uint32_t rank, uint32_t world);
 int32_t otti_shard_finalize(void);
+/* transport of the per-round sums: 0 = node-local mailbox (default), 1 = RCCL ncclAllReduce(ncclUint64, ncclSum) over u64 lanes
+   (environment OTTI_SHARD_TRANSPORT=rccl at otti_shard_init; needs the GPU) */
+int32_t otti_shard_info(uint32_t *rank, uint32_t *world, uint32_t *transport);
 int32_t otti_shard_allgather(const void *mine, size_t nbytes, void *out /* world * nbytes */);
 int32_t otti_shard_allreduce(uint8_t *scalars32 /* canonical, in place */, size_t count);
 int32_t otti_nizk_prove_sharded(otti_instance *inst, otti_witness *wit, otti_gens *gens, const uint8_t *tlabel, size_t tlabel_len,
@@ -211,6 +214,10 @@ int32_t otti_dev_download(void *h_dst, const void *d_src, size_t nbytes);
 int32_t otti_dev_stream_create(void **stream_out);
 int32_t otti_dev_stream_sync(void *stream);
 int32_t otti_dev_stream_destroy(void *stream);
+
+/* the integer-ALU roof the bulk MSM is priced against: whole-chip throughput of its mixed point addition (operands in registers,
+   every CU busy), measured now (about 10 ms of GPU time) */
+int32_t otti_bench_madd_peak(double *madds_per_second);
 
 /* per-kernel-class timing with HIP events recorded on the library's own stream around every launch of that class.
    classes: msm_rows (>= 2^16 scalars per launch: the witness commitment) msm_small msm_finish sc_cubic sc_quad spmv eq reduce poly_bound bullet other.  enable(1) also resets the counters. */

@@ -79,6 +79,7 @@ _sig("otti_nizk_prove_resident", _i32, _vp, _vp, _vp, ctypes.c_char_p, _sz, _vp,
      ctypes.POINTER(ctypes.c_double))
 _sig("otti_shard_init", _i32, ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint32)
 _sig("otti_shard_finalize", _i32)
+_sig("otti_shard_info", _i32, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32))
 _sig("otti_shard_allgather", _i32, _vp, _sz, _vp)
 _sig("otti_shard_allreduce", _i32, _vp, _sz)
 _sig("otti_nizk_prove_sharded", _i32, _vp, _vp, _vp, ctypes.c_char_p, _sz, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_sz),
@@ -90,6 +91,7 @@ _sig("otti_zkif_write", _i32, ctypes.POINTER(_R1CS), ctypes.c_char_p, ctypes.c_c
 _sig("otti_r1cs_free", None, ctypes.POINTER(_R1CS))
 _sig("otti_synth_r1cs", _i32, _u64, _u64, _u64, ctypes.POINTER(ctypes.POINTER(_R1CS)))
 _sig("otti_synth_r1cs_compiler_like", _i32, _u64, _u64, _u64, ctypes.POINTER(ctypes.POINTER(_R1CS)))
+_sig("otti_bench_madd_peak", _i32, ctypes.POINTER(ctypes.c_double))
 _sig("otti_stats_enable", _i32, _i32)
 _sig("otti_stats_select", _i32, ctypes.c_char_p)
 _sig("otti_stats_read", _i32, ctypes.c_char_p, ctypes.POINTER(_u64), ctypes.POINTER(ctypes.c_double))
@@ -349,6 +351,13 @@ def shard_finalize():
     _check(lib.otti_shard_finalize())
 
 
+def shard_info():
+    """(rank, world, transport) of the sharded-proof exchange; transport is 'mailbox' or 'rccl' (OTTI_SHARD_TRANSPORT)"""
+    r, w, t = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint32()
+    _check(lib.otti_shard_info(ctypes.byref(r), ctypes.byref(w), ctypes.byref(t)))
+    return r.value, w.value, ("mailbox", "rccl")[t.value]
+
+
 def shard_allgather(mine, world):
     """Exchange primitive: every rank's ``mine`` (bytes of equal length), concatenated in rank order."""
     mine = bytes(mine)
@@ -442,6 +451,13 @@ def stats_enable(on=True, only=None):
     _check(lib.otti_stats_enable(1 if on else 0))
     if on and only is not None:
         _check(lib.otti_stats_select(only.encode()))
+
+
+def madd_peak():
+    """whole-chip mixed point additions per second (the MSM's ALU roof), measured now"""
+    v = ctypes.c_double()
+    _check(lib.otti_bench_madd_peak(ctypes.byref(v)))
+    return v.value
 
 
 def stats_read():

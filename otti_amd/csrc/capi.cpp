@@ -184,6 +184,14 @@ int32_t otti_shard_init(const char *segment_name, uint32_t rank, uint32_t world)
         return OTTI_OK;
     });
 }
+int32_t otti_shard_info(uint32_t *rank, uint32_t *world, uint32_t *transport) {
+    return guarded([&] {
+        if (!shard_comm()) throw Error(OTTI_ERR_BAD_ARG, "otti_shard_init has not been called");
+        if (rank) *rank = (uint32_t)shard_comm()->rank(); if (world) *world = (uint32_t)shard_comm()->world();
+        if (transport) *transport = (uint32_t)shard_comm()->transport();
+        return OTTI_OK;
+    });
+}
 int32_t otti_shard_finalize(void) { return guarded([&] { shard_comm_set(nullptr); return OTTI_OK; }); }
 int32_t otti_shard_allgather(const void *mine, size_t nbytes, void *out) {
     return guarded([&] {
@@ -546,6 +554,10 @@ int32_t otti_kd_msm_rows(otti_gens *gens, const void *Z, size_t L, size_t R, con
     });
 }
 
+int32_t otti_bench_madd_peak(double *madds_per_second) {
+    return guarded([&] { if (!madds_per_second) throw Error(OTTI_ERR_BAD_ARG, "null argument"); *madds_per_second = dev_madd_peak(DevCtx::get()); return OTTI_OK; });
+}
+
 // ------------------------------------------------------------------------------------------------ kernel timing (HIP events on the library stream)
 static const char *kClassNames[KC_COUNT] = {"msm_rows", "msm_small", "msm_finish", "sc_cubic", "sc_quad", "spmv", "eq", "reduce", "poly_bound", "bullet", "other"};
 int32_t otti_stats_enable(int32_t on) { KStats::get().on = on != 0; KStats::get().mask = 0xffffffffu; KStats::get().reset(); return OTTI_OK; }
@@ -567,22 +579,9 @@ void otti_lanes_pack(const uint8_t *fr, size_t n, uint64_t *lanes) {
     for (size_t i = 0; i < n; i++) for (int k = 0; k < 8; k++) { uint32_t w; memcpy(&w, fr + 32 * i + 4 * k, 4); lanes[8 * i + k] = w; }
 }
 void otti_lanes_unpack(const uint64_t *lanes, size_t n, uint8_t *fr) {
-    // each lane holds a sum of up to 2^32 32-bit limbs: propagate carries into a 320-bit integer, then reduce mod l.
-    // value = sum_k lane_k 2^(32k) < 2^32 * 2^256; write it as lo (256 bits) + hi * 2^256 with hi < 2^32.
-    for (size_t i = 0; i < n; i++) {
-        uint32_t w[9]; unsigned __int128 c = 0;
-        for (int k = 0; k < 8; k++) { c += lanes[8 * i + k]; w[k] = (uint32_t)c; c >>= 32; }
-        w[8] = (uint32_t)c;
-        // lo may be >= l (it is an arbitrary 256-bit number): reduce both parts through Montgomery products with R^2:
-        // x*R^2/R = x*R, then multiply by 1 to drop back: (x*R)*1/R = x mod l.  The inputs were Montgomery values, and the
-        // sum of Montgomery values is the Montgomery value of the sum, so the result stays in Montgomery form.
-        Fr lo, hi = fr_zero(); for (int k = 0; k < 8; k++) lo.v[k] = w[k]; hi.v[0] = w[8];
-        Fr one_raw = fr_zero(); one_raw.v[0] = 1;
-        Fr lo_red = fr_mul(fr_mul(lo, fr_R2()), one_raw);                 // lo mod l
-        Fr hi_red = fr_mul(hi, fr_R2());                                  // hi * R^2 / R = hi * 2^256 mod l
-        Fr s = fr_add(lo_red, hi_red);
-        memcpy(fr + 32 * i, s.v, 32);
-    }
+    std::vector<Fr> out(n);
+    lanes_to_fr(lanes, n, out.data());                                  // shard.cpp: carries, then reduction mod l (Montgomery form kept)
+    for (size_t i = 0; i < n; i++) memcpy(fr + 32 * i, out[i].v, 32);
 }
 
 }  // extern "C"

@@ -507,6 +507,33 @@ std::shared_ptr<DeviceGens> build_device_gens(const Gens &g, int c) {
     return d;
 }
 
+// ------------------------------------------------------------------------------------------------ the ALU roof of the MSM, measured
+// Whole-chip throughput of the mixed point addition the bulk MSM is made of (p10_madd, operands in registers, every CU busy): what
+// bench.py prices k_msm_rows<0> against (roofline.alu.peak), measured in the run that reports it.  tools/mulbench.hip is the same loop.
+__global__ __launch_bounds__(kBlock) void k_madd_peak(Fp *io, int iters) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    P10 p; p.X = f10_unpack(io[2 * i]); p.Y = f10_unpack(io[2 * i + 1]); p.Z = f10_one(); p.T = f10_mul(p.X, p.Y);
+    N10 n; n.yplusx = p.X; n.yminusx = p.Y; n.xy2d = p.T;
+    for (int k = 0; k < iters; k++) p = p10_madd(p, n);
+    io[2 * i] = f10_pack(p.X);
+}
+double dev_madd_peak(DevCtx &c) {
+    const int blocks = 1024, iters = 200; const size_t n = (size_t)blocks * kBlock;
+    DevBuf<Fp> io(2 * n);
+    std::vector<Fp> h(2 * n);
+    for (size_t i = 0; i < 2 * n; i++) for (int q = 0; q < 8; q++) h[i].v[q] = (uint32_t)(0x9e3779b9u * (i * 8 + q + 1));
+    OTTI_HIP(hipMemcpyAsync(io.p, h.data(), 2 * n * sizeof(Fp), hipMemcpyHostToDevice, c.stream));
+    double best = 0;
+    for (int rep = 0; rep < 4; rep++) {                                  // the first launch warms up; best of the rest
+        OTTI_HIP(hipEventRecord(c.ev0, c.stream));
+        hipLaunchKernelGGL(k_madd_peak, blocks, kBlock, 0, c.stream, io.p, iters);
+        OTTI_HIP(hipEventRecord(c.ev1, c.stream)); OTTI_HIP(hipEventSynchronize(c.ev1));
+        float ms = 0; OTTI_HIP(hipEventElapsedTime(&ms, c.ev0, c.ev1));
+        if (rep && ms > 0) best = std::max(best, (double)n * iters / (ms * 1e-3));
+    }
+    return best;
+}
+
 // ------------------------------------------------------------------------------------------------ K10 bullet reduction bookkeeping
 // Instead of folding the generator vector (n/2 two-scalar multiplications per round upstream), keep the ORIGINAL generators and a
 // coefficient vector s with G^(k)_i = sum_{j = i mod n} s[j] * P[j]; L and R of each round are then fixed-base MSM rows over P.

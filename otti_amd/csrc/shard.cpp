@@ -3,7 +3,9 @@
 // e + 2 (and overwrite parity-e slots) after every rank has posted epoch e + 1, which each of them does only after it has finished
 // reading epoch e — so two slot sets are enough and no second barrier is needed.
 #include "shard.h"
-#include "spartan.h"
+#include "device.h"
+#include <rccl/rccl.h>
+#include <dlfcn.h>
 #include <atomic>
 #include <chrono>
 #include <vector>
@@ -37,6 +39,69 @@ struct Deadline {
 std::atomic<uint64_t> *seq_of(uint8_t *base, int r) { return reinterpret_cast<std::atomic<uint64_t> *>(base + 64 * (size_t)(r + 1)); }
 }  // namespace
 
+// ---- RCCL transport.  librccl is loaded at run time (the library carries no link-time dependency on it; a process that already
+// holds PyTorch's copy gets that one), the communicator is bootstrapped through the mailbox (rank 0's ncclUniqueId).
+struct ShardComm::Rccl {
+    void *lib = nullptr; ncclComm_t comm = nullptr; hipStream_t stream = nullptr;
+    uint64_t *h_lanes = nullptr, *d_lanes = nullptr; size_t cap = 0;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    void check(ncclResult_t r, const char *what) { if (r != ncclSuccess) throw Error(OTTI_ERR_NO_DEVICE, std::string("RCCL: ") + what + ": " + (GetErrorString ? GetErrorString(r) : "error")); }
+    explicit Rccl(ShardComm &c) {
+        DevCtx::get();                                                   // selects this rank's device for the calling thread (OTTI_DEVICE / LOCAL_RANK)
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) if ((lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
+        if (!lib) throw Error(OTTI_ERR_NO_DEVICE, "OTTI_SHARD_TRANSPORT=rccl: librccl.so not found");
+        auto sym = [&](const char *n) { void *p = dlsym(lib, n); if (!p) throw Error(OTTI_ERR_NO_DEVICE, std::string("librccl lacks ") + n); return p; };
+        GetUniqueId = (decltype(GetUniqueId))sym("ncclGetUniqueId"); CommInitRank = (decltype(CommInitRank))sym("ncclCommInitRank");
+        AllReduce = (decltype(AllReduce))sym("ncclAllReduce"); CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
+        GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
+        ncclUniqueId id; memset(&id, 0, sizeof id);
+        if (c.rank() == 0) check(GetUniqueId(&id), "ncclGetUniqueId");
+        std::vector<ncclUniqueId> ids((size_t)c.world());
+        c.allgather(&id, sizeof id, ids.data());
+        check(CommInitRank(&comm, c.world(), ids[0], c.rank()), "ncclCommInitRank");
+        OTTI_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        reserve(8 * 64);
+    }
+    void reserve(size_t lanes) {
+        if (lanes <= cap) return;
+        if (h_lanes) (void)hipHostFree(h_lanes);
+        if (d_lanes) (void)hipFree(d_lanes);
+        OTTI_HIP(hipHostMalloc((void **)&h_lanes, lanes * 8, hipHostMallocDefault)); OTTI_HIP(hipMalloc((void **)&d_lanes, lanes * 8)); cap = lanes;
+    }
+    void allreduce(Fr *v, size_t n) {
+        reserve(8 * n);
+        for (size_t i = 0; i < n; i++) for (int k = 0; k < 8; k++) h_lanes[8 * i + k] = v[i].v[k];
+        OTTI_HIP(hipMemcpyAsync(d_lanes, h_lanes, 64 * n, hipMemcpyHostToDevice, stream));
+        check(AllReduce(d_lanes, d_lanes, 8 * n, ncclUint64, ncclSum, comm, stream), "ncclAllReduce");
+        OTTI_HIP(hipMemcpyAsync(h_lanes, d_lanes, 64 * n, hipMemcpyDeviceToHost, stream));
+        OTTI_HIP(hipStreamSynchronize(stream));
+        lanes_to_fr(h_lanes, n, v);
+    }
+    ~Rccl() {
+        if (comm && CommDestroy) (void)CommDestroy(comm);
+        if (stream) (void)hipStreamDestroy(stream);
+        if (h_lanes) (void)hipHostFree(h_lanes);
+        if (d_lanes) (void)hipFree(d_lanes);
+    }
+};
+
+void lanes_to_fr(const uint64_t *lanes, size_t n, Fr *out) {
+    for (size_t i = 0; i < n; i++) {
+        uint32_t w[9]; unsigned __int128 c = 0;
+        for (int k = 0; k < 8; k++) { c += lanes[8 * i + k]; w[k] = (uint32_t)c; c >>= 32; }
+        w[8] = (uint32_t)c;
+        // value = lo (256 bits, any value) + hi * 2^256 with hi < 2^32: reduce both through Montgomery products with R^2
+        // (x * R^2 / R = x * R, then * 1 / R drops back to x mod l)
+        Fr lo, hi = fr_zero(); for (int k = 0; k < 8; k++) lo.v[k] = w[k]; hi.v[0] = w[8];
+        Fr one_raw = fr_zero(); one_raw.v[0] = 1;
+        out[i] = fr_add(fr_mul(fr_mul(lo, fr_R2()), one_raw), fr_mul(hi, fr_R2()));
+    }
+}
+
 ShardComm::ShardComm(const std::string &name, int rank, int world) : name_(name), rank_(rank), world_(world) {
     if (world < 1 || world > kMaxWorld || (world & (world - 1)) || rank < 0 || rank >= world) throw Error(OTTI_ERR_BAD_ARG, "shard: world must be a power of two <= 64 and 0 <= rank < world");
     if (name.empty() || name.find('/') != std::string::npos) throw Error(OTTI_ERR_BAD_ARG, "shard: segment name must be non-empty and contain no '/'");
@@ -67,9 +132,13 @@ ShardComm::ShardComm(const std::string &name, int rank, int world) : name_(name)
     }
     barrier();
     if (rank == 0) shm_unlink(path.c_str());                            // everyone is attached: the name can go, the mapping stays
+    const char *tr = getenv("OTTI_SHARD_TRANSPORT");
+    if (tr && !strcmp(tr, "rccl")) rccl_ = new Rccl(*this);
+    else if (tr && *tr && strcmp(tr, "mailbox")) throw Error(OTTI_ERR_BAD_ARG, "OTTI_SHARD_TRANSPORT must be 'mailbox' or 'rccl'");
 }
 
 ShardComm::~ShardComm() {
+    delete rccl_;
     if (base_) munmap(base_, bytes_);
     if (fd_ >= 0) close(fd_);
 }
@@ -89,6 +158,10 @@ void ShardComm::allgather(const void *mine, size_t n, void *out) {
 }
 
 void ShardComm::allreduce_fr(Fr *v, size_t n) {
+    if (rccl_) { rccl_->allreduce(v, n); return; }                      // also with a world of one: the path is exercised on a one-GPU box
+    allreduce_mailbox(v, n);
+}
+void ShardComm::allreduce_mailbox(Fr *v, size_t n) {
     if (world_ == 1) return;
     const size_t per = kSlotBytes / sizeof(Fr);
     std::vector<Fr> all;

@@ -30,10 +30,23 @@ public:
     void barrier() { uint8_t b = 0, all[64]; allgather(&b, 1, all); }
     static constexpr size_t kSlotBytes = (size_t)1 << 20;
     static constexpr int kMaxWorld = 64;
+    // Transport of allreduce_fr.  Default: the mailbox above.  OTTI_SHARD_TRANSPORT=rccl: every element travels as 8 x u32 limbs
+    // widened to u64 lanes through ncclAllReduce(ncclUint64, ncclSum) on the GPUs (RCCL has no modular reduce op,
+    // but world * 2^32 < 2^64, so a plain integer sum of lanes followed by one normalisation mod l is exact), i.e. over xGMI when
+    // the ranks sit on different cards.  Selectable so that the two can be compared on a multi-GPU node; the mailbox wins on
+    // latency for payloads of 64-96 bytes.  allgather always uses the mailbox.
+    enum Transport { kMailbox = 0, kRccl = 1 };
+    Transport transport() const { return rccl_ ? kRccl : kMailbox; }
 private:
     uint8_t *slot(int parity, int r) const;
+    void allreduce_mailbox(Fr *v, size_t n);
     std::string name_; int rank_, world_; int fd_ = -1; uint8_t *base_ = nullptr; size_t bytes_ = 0; uint64_t epoch_ = 0;
+    struct Rccl; Rccl *rccl_ = nullptr;
 };
+// sum of lane groups back to field elements: each group of 8 u64 lanes holds a sum of up to 2^32 32-bit limbs of Montgomery-form
+// values; carries are propagated and the 288-bit result reduced mod l (still Montgomery form: the sum of Montgomery values is the
+// Montgomery value of the sum)
+void lanes_to_fr(const uint64_t *lanes, size_t n, Fr *out);
 
 // process-wide communicator used by nizk_prove_sharded (set through the C ABI: otti_shard_init / otti_shard_finalize)
 ShardComm *shard_comm();

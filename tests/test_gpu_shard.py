@@ -55,3 +55,25 @@ def test_too_many_ranks_for_the_instance_is_refused():
     wit = oa.Witness(inst, oa.VarsAssignment.new(r["vars"]), oa.InputsAssignment.new(r["inputs"]))
     with pytest.raises(oa.SpartanError):
         oa.NIZK.prove_sharded(inst, wit, gens, LABEL, SEED)                         # no otti_shard_init
+
+
+def test_rccl_lane_transport_of_the_round_sums_on_one_card(tmp_path):
+    """OTTI_SHARD_TRANSPORT=rccl: allreduce_fr goes pack -> ncclAllReduce(ncclUint64, ncclSum) on the GPU -> normalise mod l.  RCCL
+    refuses two ranks on one card, so this box can only run a world of one — which still exercises the whole path (bootstrap of the
+    communicator through the mailbox, lanes on the device, the collective call, carry propagation and reduction); the arithmetic of
+    summing lanes across ranks is rehearsed with gloo in tests/test_dist_cpu.py."""
+    import subprocess, sys
+    out = tmp_path / "x.npz"
+    env = dict(os.environ, OTTI_SHARD_TRANSPORT="rccl", OTTI_DEVICE="0")
+    res = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "shard_worker.py"), "exchange",
+                          "otti-test-" + uuid.uuid4().hex, "0", "1", str(out)], env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout + res.stderr
+    got = np.load(out)
+    assert bytes(got["transport"]).decode() == "rccl"
+    rng = np.random.default_rng(1234)
+    for nbytes in [1, 32, 96, 4096, 1 << 20, 7, 96, 96, 96]:
+        rng.integers(0, 256, nbytes, dtype=np.uint8)
+    for it, n in enumerate([1, 3, 1000, 40000]):
+        vals = [int(x) for x in rng.integers(0, 2 ** 62, n)]
+        vals[0] = oa.L_ORDER - 1
+        assert np.array_equal(got["r%d" % it], oa.fr_from_ints(vals)), it     # a world of one: the sum is the rank's own values
