@@ -7,7 +7,7 @@ import csv
 import json
 import sys
 
-KERNELS = ("k_msm_rows<0>", "k_msm_rows<1>", "k_sc_cubic3_fold_eval", "k_sc_quad_fold_eval", "k_sc_cubic3_eval", "k_sc_quad_eval", "k_spmv3_light", "k_eq_expand",
+KERNELS = ("k_msm_rows<0>", "k_msm_small", "k_msm_rows<2>", "k_sc_cubic3_fold_eval", "k_sc_quad_fold_eval", "k_sc_cubic3_eval", "k_sc_quad_eval", "k_spmv3_light", "k_eq_expand",
            "k_poly_bound_slab", "k_gather_strided")
 
 
@@ -35,7 +35,7 @@ def main():
         if best:
             out[k] = {"largest_launch_FETCH_SIZE_KiB": best[0], "largest_launch_WRITE_SIZE_KiB": best[1],
                       "traffic_bytes_corrected": int((2 * best[0] + best[1]) * 1024)}
-    json.dump({"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python3 bench.py --steps 1 --warmup 1 "
+    json.dump({"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python3 bench.py --steps 1 --warmup 1 --in-flight -1 --no-e2e "
                        "--no-cpu-baseline` (2^20; window width in msm_window_bits). Unit of the counters: KiB. gfx950 correction (MI355X guide): FETCH_SIZE reports half of the "
                        "bytes of wide coalesced 16-B-per-lane reads, so it is doubled; for the scattered 16-B loads of the window-table gathers that "
                        "factor is not calibrated and the corrected figure is an upper estimate.",
