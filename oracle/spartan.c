@@ -6,6 +6,7 @@
  * Deviation kept deliberately small and documented in DESIGN.md: RandomTape takes a caller seed instead of OsRng.
  */
 #include "spartan.h"
+#include "internal.h"
 #include <stdlib.h>
 #include <string.h>
 #include <assert.h>
@@ -14,13 +15,13 @@
 #include <omp.h>
 #endif
 
-static int g_threads = 1;
+int g_threads = 1;
 void orc_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
 int orc_get_threads(void) { return g_threads; }
-static double now_ms(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
+double now_ms(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
 
-static size_t ilog2(size_t n) { size_t l = 0; while (((size_t)1 << l) < n) l++; return l; }
-static size_t next_pow2(size_t n) { size_t p = 1; while (p < n) p <<= 1; return p; }
+size_t ilog2(size_t n) { size_t l = 0; while (((size_t)1 << l) < n) l++; return l; }
+size_t next_pow2(size_t n) { size_t p = 1; while (p < n) p <<= 1; return p; }
 
 void orc_fr_from_canon(fr_t *o, const uint8_t *b, size_t n) { for (size_t i = 0; i < n; i++) { int ok = fr_from_bytes(&o[i], b + 32 * i); assert(ok); (void)ok; } }
 void orc_fr_to_canon(uint8_t *b, const fr_t *a, size_t n) { for (size_t i = 0; i < n; i++) fr_to_bytes(b + 32 * i, &a[i]); }
@@ -28,28 +29,28 @@ void orc_buf_free(void *p) { free(p); }
 
 /* ------------------------------------------------------------------ commitments.rs */
 /* MultiCommitGens::new: SHAKE256(label || compress(B)) XOF, n+1 chunks of 64 B -> one-way map; first n are G, last is h */
-static void gens_stream(ge_t *out, size_t count, const char *label) {
+void gens_stream(ge_t *out, size_t count, const char *label) {
     shake256_t sh; shake256_init(&sh);
     shake256_absorb(&sh, (const uint8_t *)label, strlen(label));
     shake256_absorb(&sh, RISTRETTO_BASEPOINT_COMPRESSED, 32);
     for (size_t i = 0; i < count; i++) { uint8_t u[64]; shake256_squeeze(&sh, u, 64); ge_from_uniform_bytes(&out[i], u); }
 }
-static void mcgens_from(orc_mcgens *g, const ge_t *P, size_t n, const ge_t *h) {
+void mcgens_from(orc_mcgens *g, const ge_t *P, size_t n, const ge_t *h) {
     g->n = n; g->G = (ge_t *)malloc(n * sizeof(ge_t)); memcpy(g->G, P, n * sizeof(ge_t)); g->h = *h;
 }
-static void mcgens_free(orc_mcgens *g) { free(g->G); g->G = NULL; }
+void mcgens_free(orc_mcgens *g) { free(g->G); g->G = NULL; }
 
 /* Commitments for [Scalar]: MSM(v, G) + blind*h */
-static void commit_vec(ge_t *o, const fr_t *v, size_t n, const fr_t *blind, const orc_mcgens *g) {
+void commit_vec(ge_t *o, const fr_t *v, size_t n, const fr_t *blind, const orc_mcgens *g) {
     assert(n == g->n);
     fr_t *s = (fr_t *)malloc((n + 1) * sizeof(fr_t)); ge_t *P = (ge_t *)malloc((n + 1) * sizeof(ge_t));
     memcpy(s, v, n * sizeof(fr_t)); s[n] = *blind; memcpy(P, g->G, n * sizeof(ge_t)); P[n] = g->h;
     ge_msm(o, s, P, n + 1);
     free(s); free(P);
 }
-static void commit_scalar(ge_t *o, const fr_t *x, const fr_t *blind, const orc_mcgens *g) { assert(g->n == 1); commit_vec(o, x, 1, blind, g); }
-static void commit_vec_c(uint8_t out[32], const fr_t *v, size_t n, const fr_t *blind, const orc_mcgens *g) { ge_t p; commit_vec(&p, v, n, blind, g); ge_encode(out, &p); }
-static void commit_scalar_c(uint8_t out[32], const fr_t *x, const fr_t *blind, const orc_mcgens *g) { ge_t p; commit_scalar(&p, x, blind, g); ge_encode(out, &p); }
+void commit_scalar(ge_t *o, const fr_t *x, const fr_t *blind, const orc_mcgens *g) { assert(g->n == 1); commit_vec(o, x, 1, blind, g); }
+void commit_vec_c(uint8_t out[32], const fr_t *v, size_t n, const fr_t *blind, const orc_mcgens *g) { ge_t p; commit_vec(&p, v, n, blind, g); ge_encode(out, &p); }
+void commit_scalar_c(uint8_t out[32], const fr_t *x, const fr_t *blind, const orc_mcgens *g) { ge_t p; commit_scalar(&p, x, blind, g); ge_encode(out, &p); }
 
 /* ------------------------------------------------------------------ lib.rs NIZKGens / r1csproof.rs R1CSGens */
 orc_gens *orc_gens_new(size_t num_cons, size_t num_vars, size_t num_inputs) {
@@ -149,7 +150,7 @@ void orc_fold_bot(fr_t *Z, size_t len, const fr_t *r) {
     for (size_t i = 0; i < n; i++) { fr_t d; fr_sub(&d, &Z[2 * i + 1], &Z[2 * i]); fr_mul(&d, &d, r); fr_add(&Z[i], &Z[2 * i], &d); }
 }
 
-static void dot(fr_t *o, const fr_t *a, const fr_t *b, size_t n) {
+void dot(fr_t *o, const fr_t *a, const fr_t *b, size_t n) {
     fr_t acc = FR_ZERO;
     if (g_threads > 1 && n >= 4096) {
 #pragma omp parallel num_threads(g_threads)
@@ -200,7 +201,7 @@ void orc_eval_table_sparse(const orc_instance *I, const fr_t *rx, fr_t *eA, fr_t
     for (int k = 0; k < 3; k++) sparse_evaltable(m[k], rx, o[k], 2 * I->num_vars);
 }
 /* R1CSInstance::evaluate -> SparseMatPolynomial::multi_evaluate */
-static void inst_evaluate(const orc_instance *I, const fr_t *rx, size_t nrx, const fr_t *ry, size_t nry, fr_t ev[3]) {
+void inst_evaluate(const orc_instance *I, const fr_t *rx, size_t nrx, const fr_t *ry, size_t nry, fr_t ev[3]) {
     fr_t *ex = (fr_t *)malloc(((size_t)1 << nrx) * sizeof(fr_t)), *ey = (fr_t *)malloc(((size_t)1 << nry) * sizeof(fr_t));
     orc_eq_evals(rx, nrx, ex); orc_eq_evals(ry, nry, ey);
     const orc_sparse *m[3] = {&I->A, &I->B, &I->C};
@@ -239,7 +240,7 @@ int orc_instance_is_sat(const orc_instance *I, const uint8_t *vars32, size_t nva
 }
 
 /* ------------------------------------------------------------------ unipoly.rs */
-static void unipoly_from_evals(fr_t *c, const fr_t *e, size_t n) {
+void unipoly_from_evals(fr_t *c, const fr_t *e, size_t n) {
     fr_t two, six, two_inv, six_inv, t;
     fr_from_u64(&two, 2); fr_from_u64(&six, 6); fr_inv(&two_inv, &two); fr_inv(&six_inv, &six);
     if (n == 3) {
@@ -258,14 +259,14 @@ static void unipoly_from_evals(fr_t *c, const fr_t *e, size_t n) {
         c[0] = e[0]; fr_sub(&t, &e[1], &e[0]); fr_sub(&t, &t, &a); fr_sub(&c[1], &t, &b); c[2] = b; c[3] = a;
     }
 }
-static void unipoly_eval(fr_t *o, const fr_t *c, size_t n, const fr_t *r) {
+void unipoly_eval(fr_t *o, const fr_t *c, size_t n, const fr_t *r) {
     fr_t ev = c[0], pw = *r, t;
     for (size_t i = 1; i < n; i++) { fr_mul(&t, &pw, &c[i]); fr_add(&ev, &ev, &t); fr_mul(&pw, &pw, r); }
     *o = ev;
 }
 
 /* ------------------------------------------------------------------ random.rs RandomTape */
-static void tape_init(transcript_t *tape, const uint8_t seed32[32]) {
+void tape_init(transcript_t *tape, const uint8_t seed32[32]) {
     /* upstream: Transcript::new(b"proof") + append_scalar(b"init_randomness", Scalar::random(OsRng)).
        Here the scalar is from_bytes_wide(seed || 0^32) so that proofs are reproducible. */
     uint8_t w[64]; memset(w, 0, 64); memcpy(w, seed32, 32);
@@ -274,27 +275,7 @@ static void tape_init(transcript_t *tape, const uint8_t seed32[32]) {
     tr_append_scalar(tape, "init_randomness", &s);
 }
 
-/* ------------------------------------------------------------------ proof structures (field order = bincode order) */
-typedef struct { uint8_t delta[32], beta[32]; size_t nz; fr_t z[4]; fr_t z_delta, z_beta; } dp_proof_t;
-typedef struct { size_t rounds; uint8_t *comm_polys, *comm_evals; dp_proof_t *proofs; } zksc_t;
-typedef struct { uint8_t alpha[32]; fr_t z1, z2; } know_t;
-typedef struct { uint8_t alpha[32], beta[32], delta[32]; fr_t z[5]; } prod_t;
-typedef struct { uint8_t alpha[32]; fr_t z; } eqp_t;
-typedef struct { size_t n; uint8_t *Lv, *Rv; uint8_t delta[32], beta[32]; fr_t z1, z2; } dplog_t;
-typedef struct {
-    size_t nC; uint8_t *comm_vars;
-    zksc_t sc1;
-    uint8_t claims2[4][32];
-    know_t pok; prod_t prod;
-    eqp_t eq1;
-    zksc_t sc2;
-    uint8_t comm_vars_at_ry[32];
-    dplog_t pe;
-    eqp_t eq2;
-    size_t nrx, nry; fr_t *rx, *ry;
-} nizk_t;
-
-static void nizk_free(nizk_t *p) {
+void nizk_free(nizk_t *p) {
     free(p->comm_vars); free(p->sc1.comm_polys); free(p->sc1.comm_evals); free(p->sc1.proofs);
     free(p->sc2.comm_polys); free(p->sc2.comm_evals); free(p->sc2.proofs); free(p->pe.Lv); free(p->pe.Rv); free(p->rx); free(p->ry);
 }
@@ -634,8 +615,8 @@ static int bullet_verify(const dplog_t *pf, size_t n, const fr_t *a, transcript_
 }
 
 /* ------------------------------------------------------------------ nizk/mod.rs DotProductProofLog, dense_mlpoly.rs PolyEvalProof */
-static void dplog_prove(dplog_t *pf, uint8_t Cy_out[32], const orc_gens *g, transcript_t *tr, transcript_t *tape,
-                        const fr_t *x, const fr_t *blind_x, const fr_t *a, size_t n, const fr_t *y, const fr_t *blind_y) {
+void dplog_prove(dplog_t *pf, uint8_t Cy_out[32], const orc_mcgens *gn, const orc_mcgens *g1, transcript_t *tr, transcript_t *tape,
+                 const fr_t *x, const fr_t *blind_x, const fr_t *a, size_t n, const fr_t *y, const fr_t *blind_y) {
     tr_protocol_name(tr, "dot product proof (log)");
     size_t lg = ilog2(n);
     fr_t d, r_delta, r_beta, c, t, u;
@@ -648,47 +629,46 @@ static void dplog_prove(dplog_t *pf, uint8_t Cy_out[32], const orc_gens *g, tran
     fr_t *blinds = (fr_t *)malloc((4 * lg + 2) * sizeof(fr_t));
     for (size_t i = 0; i < 2 * lg; i++) { blinds[2 * i] = v1[i]; blinds[2 * i + 1] = v2[i]; }
     uint8_t Cx[32];
-    commit_vec_c(Cx, x, n, blind_x, &g->pc_n); tr_append_point(tr, "Cx", Cx);
-    commit_scalar_c(Cy_out, y, blind_y, &g->pc_1); tr_append_point(tr, "Cy", Cy_out);
+    commit_vec_c(Cx, x, n, blind_x, gn); tr_append_point(tr, "Cx", Cx);
+    commit_scalar_c(Cy_out, y, blind_y, g1); tr_append_point(tr, "Cy", Cy_out);
     fr_t blind_Gamma; fr_add(&blind_Gamma, blind_x, blind_y);
     fr_t x_hat, a_hat, rhat; ge_t g_hat;
-    bullet_prove(pf, tr, &g->pc_1.G[0], g->pc_n.G, &g->pc_n.h, x, a, n, &blind_Gamma, blinds, &x_hat, &a_hat, &g_hat, &rhat);
+    bullet_prove(pf, tr, &g1->G[0], gn->G, &gn->h, x, a, n, &blind_Gamma, blinds, &x_hat, &a_hat, &g_hat, &rhat);
     fr_t y_hat; fr_mul(&y_hat, &x_hat, &a_hat);
-    { orc_mcgens gh = {1, &g_hat, g->pc_1.h}; commit_scalar_c(pf->delta, &d, &r_delta, &gh); } tr_append_point(tr, "delta", pf->delta);
-    commit_scalar_c(pf->beta, &d, &r_beta, &g->pc_1); tr_append_point(tr, "beta", pf->beta);
+    { orc_mcgens gh = {1, &g_hat, g1->h}; commit_scalar_c(pf->delta, &d, &r_delta, &gh); } tr_append_point(tr, "delta", pf->delta);
+    commit_scalar_c(pf->beta, &d, &r_beta, g1); tr_append_point(tr, "beta", pf->beta);
     tr_challenge_scalar(tr, "c", &c);
     fr_mul(&t, &c, &y_hat); fr_add(&pf->z1, &d, &t);
     fr_mul(&t, &c, &rhat); fr_add(&t, &t, &r_beta); fr_mul(&u, &a_hat, &t); fr_add(&pf->z2, &u, &r_delta);
     free(v1); free(v2); free(blinds);
 }
-static int dplog_verify(const dplog_t *pf, size_t n, const orc_gens *g, transcript_t *tr, const fr_t *a, const uint8_t Cx[32], const uint8_t Cy[32]) {
-    if (g->pc_n.n != n) return ORC_ERR_VERIFY_INTERNAL;
+int dplog_verify(const dplog_t *pf, size_t n, const orc_mcgens *gn, const orc_mcgens *g1, transcript_t *tr, const fr_t *a, const uint8_t Cx[32], const uint8_t Cy[32]) {
+    if (gn->n != n) return ORC_ERR_VERIFY_INTERNAL;
     tr_protocol_name(tr, "dot product proof (log)");
     tr_append_point(tr, "Cx", Cx); tr_append_point(tr, "Cy", Cy);
     ge_t X, Y, Gamma, g_hat, Gamma_hat, D, Bt; fr_t a_hat, c;
     if (!ge_decode(&X, Cx) || !ge_decode(&Y, Cy)) return ORC_ERR_VERIFY_DECOMPRESS;
     ge_add(&Gamma, &X, &Y);
-    int rc = bullet_verify(pf, n, a, tr, &Gamma, g->pc_n.G, &g_hat, &Gamma_hat, &a_hat);
+    int rc = bullet_verify(pf, n, a, tr, &Gamma, gn->G, &g_hat, &Gamma_hat, &a_hat);
     if (rc) return rc;
     tr_append_point(tr, "delta", pf->delta); tr_append_point(tr, "beta", pf->beta);
     tr_challenge_scalar(tr, "c", &c);
     if (!ge_decode(&D, pf->delta) || !ge_decode(&Bt, pf->beta)) return ORC_ERR_VERIFY_DECOMPRESS;
     ge_t lhs, rhs, t;
     ge_scalarmul(&lhs, &Gamma_hat, &c); ge_add(&lhs, &lhs, &Bt); ge_scalarmul(&lhs, &lhs, &a_hat); ge_add(&lhs, &lhs, &D);
-    ge_scalarmul(&t, &g->pc_1.G[0], &a_hat); ge_add(&t, &t, &g_hat); ge_scalarmul(&rhs, &t, &pf->z1);
-    ge_scalarmul(&t, &g->pc_1.h, &pf->z2); ge_add(&rhs, &rhs, &t);
+    ge_scalarmul(&t, &g1->G[0], &a_hat); ge_add(&t, &t, &g_hat); ge_scalarmul(&rhs, &t, &pf->z1);
+    ge_scalarmul(&t, &g1->h, &pf->z2); ge_add(&rhs, &rhs, &t);
     return ge_eq(&lhs, &rhs) ? ORC_OK : ORC_ERR_VERIFY_INTERNAL;
 }
 
 /* ------------------------------------------------------------------ bincode layout of NIZK [RECALL; SURVEY App. A item 12] */
-typedef struct { uint8_t *p; size_t len, cap; } wbuf_t;
-static void wb(wbuf_t *w, const void *d, size_t n) {
+void wb(wbuf_t *w, const void *d, size_t n) {
     if (w->len + n > w->cap) { w->cap = (w->len + n) * 2 + 64; w->p = (uint8_t *)realloc(w->p, w->cap); }
     memcpy(w->p + w->len, d, n); w->len += n;
 }
-static void wb_u64(wbuf_t *w, uint64_t x) { uint8_t b[8]; for (int i = 0; i < 8; i++) { b[i] = (uint8_t)x; x >>= 8; } wb(w, b, 8); }
+void wb_u64(wbuf_t *w, uint64_t x) { uint8_t b[8]; for (int i = 0; i < 8; i++) { b[i] = (uint8_t)x; x >>= 8; } wb(w, b, 8); }
 /* upstream Scalar derives Serialize over its [u64;4] Montgomery limbs, so bincode carries Montgomery form */
-static void wb_fr(wbuf_t *w, const fr_t *x) { uint8_t b[32]; fr_mont_bytes(b, x); wb(w, b, 32); }
+void wb_fr(wbuf_t *w, const fr_t *x) { uint8_t b[32]; fr_mont_bytes(b, x); wb(w, b, 32); }
 static void wb_zksc(wbuf_t *w, const zksc_t *s) {
     wb_u64(w, s->rounds); wb(w, s->comm_polys, 32 * s->rounds);
     wb_u64(w, s->rounds); wb(w, s->comm_evals, 32 * s->rounds);
@@ -699,8 +679,17 @@ static void wb_zksc(wbuf_t *w, const zksc_t *s) {
         wb_fr(w, &d->z_delta); wb_fr(w, &d->z_beta);
     }
 }
+void r1cs_serialize_body(wbuf_t *wp, const nizk_t *p);
 static void nizk_serialize(const nizk_t *p, uint8_t **out, size_t *len) {
     wbuf_t w = {0, 0, 0};
+    r1cs_serialize_body(&w, p);
+    wb_u64(&w, p->nrx); for (size_t i = 0; i < p->nrx; i++) wb_fr(&w, &p->rx[i]);
+    wb_u64(&w, p->nry); for (size_t i = 0; i < p->nry; i++) wb_fr(&w, &p->ry[i]);
+    *out = w.p; *len = w.len;
+}
+/* R1CSProof's fields in bincode order */
+void r1cs_serialize_body(wbuf_t *wp, const nizk_t *p) {
+    wbuf_t w = *wp;
     wb_u64(&w, p->nC); wb(&w, p->comm_vars, 32 * p->nC);
     wb_zksc(&w, &p->sc1);
     wb(&w, p->claims2, 128);
@@ -712,16 +701,13 @@ static void nizk_serialize(const nizk_t *p, uint8_t **out, size_t *len) {
     wb_u64(&w, p->pe.n); wb(&w, p->pe.Lv, 32 * p->pe.n); wb_u64(&w, p->pe.n); wb(&w, p->pe.Rv, 32 * p->pe.n);
     wb(&w, p->pe.delta, 32); wb(&w, p->pe.beta, 32); wb_fr(&w, &p->pe.z1); wb_fr(&w, &p->pe.z2);
     wb(&w, p->eq2.alpha, 32); wb_fr(&w, &p->eq2.z);
-    wb_u64(&w, p->nrx); for (size_t i = 0; i < p->nrx; i++) wb_fr(&w, &p->rx[i]);
-    wb_u64(&w, p->nry); for (size_t i = 0; i < p->nry; i++) wb_fr(&w, &p->ry[i]);
-    *out = w.p; *len = w.len;
+    *wp = w;
 }
 
-typedef struct { const uint8_t *p; size_t len, pos; int bad; } rbuf_t;
-static void rb(rbuf_t *r, void *d, size_t n) { if (r->bad || r->pos + n > r->len) { r->bad = 1; memset(d, 0, n); return; } memcpy(d, r->p + r->pos, n); r->pos += n; }
-static uint64_t rb_u64(rbuf_t *r) { uint8_t b[8]; rb(r, b, 8); uint64_t x = 0; for (int i = 7; i >= 0; i--) x = (x << 8) | b[i]; return x; }
-static void rb_fr(rbuf_t *r, fr_t *x) { uint8_t b[32]; rb(r, b, 32); if (!r->bad && !fr_from_mont_bytes(x, b)) r->bad = 1; }
-static uint8_t *rb_vec32(rbuf_t *r, size_t *n, size_t max) {
+void rb(rbuf_t *r, void *d, size_t n) { if (r->bad || r->pos + n > r->len) { r->bad = 1; memset(d, 0, n); return; } memcpy(d, r->p + r->pos, n); r->pos += n; }
+uint64_t rb_u64(rbuf_t *r) { uint8_t b[8]; rb(r, b, 8); uint64_t x = 0; for (int i = 7; i >= 0; i--) x = (x << 8) | b[i]; return x; }
+void rb_fr(rbuf_t *r, fr_t *x) { uint8_t b[32]; rb(r, b, 32); if (!r->bad && !fr_from_mont_bytes(x, b)) r->bad = 1; }
+uint8_t *rb_vec32(rbuf_t *r, size_t *n, size_t max) {
     uint64_t k = rb_u64(r); if (r->bad || k > max) { r->bad = 1; k = 0; }
     uint8_t *v = (uint8_t *)malloc(32 * (k ? k : 1)); rb(r, v, 32 * k); *n = (size_t)k; return v;
 }
@@ -736,8 +722,17 @@ static void rb_zksc(rbuf_t *r, zksc_t *s) {
         rb_fr(r, &d->z_delta); rb_fr(r, &d->z_beta);
     }
 }
+void r1cs_parse_body(rbuf_t *rp, nizk_t *p);
 static int nizk_parse(nizk_t *p, const uint8_t *buf, size_t len) {
     rbuf_t r = {buf, len, 0, 0}; memset(p, 0, sizeof *p);
+    r1cs_parse_body(&r, p);
+    uint64_t n = rb_u64(&r); if (n > 64) r.bad = 1; p->nrx = r.bad ? 0 : n; p->rx = (fr_t *)calloc(p->nrx + 1, sizeof(fr_t)); for (size_t i = 0; i < p->nrx; i++) rb_fr(&r, &p->rx[i]);
+    n = rb_u64(&r); if (n > 64) r.bad = 1; p->nry = r.bad ? 0 : n; p->ry = (fr_t *)calloc(p->nry + 1, sizeof(fr_t)); for (size_t i = 0; i < p->nry; i++) rb_fr(&r, &p->ry[i]);
+    if (r.bad || r.pos != r.len) return ORC_ERR_MALFORMED_PROOF;
+    return ORC_OK;
+}
+void r1cs_parse_body(rbuf_t *rp, nizk_t *p) {
+    rbuf_t r = *rp;
     p->comm_vars = rb_vec32(&r, &p->nC, (size_t)1 << 32);
     rb_zksc(&r, &p->sc1);
     rb(&r, p->claims2, 128);
@@ -749,46 +744,34 @@ static int nizk_parse(nizk_t *p, const uint8_t *buf, size_t len) {
     size_t nl, nr; p->pe.Lv = rb_vec32(&r, &nl, 64); p->pe.Rv = rb_vec32(&r, &nr, 64); if (nl != nr) r.bad = 1; p->pe.n = nl;
     rb(&r, p->pe.delta, 32); rb(&r, p->pe.beta, 32); rb_fr(&r, &p->pe.z1); rb_fr(&r, &p->pe.z2);
     rb(&r, p->eq2.alpha, 32); rb_fr(&r, &p->eq2.z);
-    uint64_t n = rb_u64(&r); if (n > 64) r.bad = 1; p->nrx = r.bad ? 0 : n; p->rx = (fr_t *)calloc(p->nrx + 1, sizeof(fr_t)); for (size_t i = 0; i < p->nrx; i++) rb_fr(&r, &p->rx[i]);
-    n = rb_u64(&r); if (n > 64) r.bad = 1; p->nry = r.bad ? 0 : n; p->ry = (fr_t *)calloc(p->nry + 1, sizeof(fr_t)); for (size_t i = 0; i < p->nry; i++) rb_fr(&r, &p->ry[i]);
-    if (r.bad || r.pos != r.len) return ORC_ERR_MALFORMED_PROOF;
-    return ORC_OK;
+    *rp = r;
 }
 
-/* ------------------------------------------------------------------ r1csproof.rs R1CSProof::prove + lib.rs NIZK::prove */
-int orc_nizk_prove(const orc_instance *I, const uint8_t *vars32, size_t nvars, const uint8_t *inputs32, size_t ni, const orc_gens *g,
-                   const uint8_t *tlabel, size_t tlabel_len, const uint8_t seed32[32], uint8_t **proof, size_t *proof_len, double *ms) {
+/* ------------------------------------------------------------------ r1csproof.rs R1CSProof::prove */
+/* vars: V padded elements, inputs: ni elements; the transcript already carries the caller's protocol names; fills P (incl. rx, ry) */
+void r1cs_prove(const orc_instance *I, const fr_t *vars, const fr_t *inputs, size_t ni, const orc_gens *g, transcript_t *tr, transcript_t *tape,
+                nizk_t *P, double st[7]) {
     size_t N = I->num_cons, V = I->num_vars;
-    if (nvars > V) return ORC_ERR_INVALID_NUM_VARS;
-    if (ni != I->num_inputs) return ORC_ERR_INVALID_NUM_INPUTS;
-    fr_t *vars = (fr_t *)calloc(V, sizeof(fr_t)), *inputs = (fr_t *)calloc(ni + 1, sizeof(fr_t));     /* VarsAssignment::pad */
-    for (size_t i = 0; i < nvars; i++) if (!fr_from_bytes(&vars[i], vars32 + 32 * i)) { free(vars); free(inputs); return ORC_ERR_INVALID_SCALAR; }
-    for (size_t i = 0; i < ni; i++) if (!fr_from_bytes(&inputs[i], inputs32 + 32 * i)) { free(vars); free(inputs); return ORC_ERR_INVALID_SCALAR; }
-
-    double t_start = now_ms(), t0, st[7] = {0};
-    transcript_t tr, tape; nizk_t P; memset(&P, 0, sizeof P);
-    tr_init(&tr, (const char *)tlabel, tlabel_len);
-    tape_init(&tape, seed32);
-    tr_protocol_name(&tr, "Spartan NIZK proof");
-    tr_protocol_name(&tr, "R1CS proof");
+    double t0;
+    tr_protocol_name(tr, "R1CS proof");
 
     /* polycommit: DensePolynomial::commit */
     t0 = now_ms();
     size_t ell = ilog2(V), Lsz = (size_t)1 << (ell / 2), Rsz = (size_t)1 << (ell - ell / 2);
     fr_t *blinds_vars = (fr_t *)malloc(Lsz * sizeof(fr_t));
-    tr_challenge_vector(&tape, "poly_blinds", blinds_vars, Lsz);
-    P.nC = Lsz; P.comm_vars = (uint8_t *)malloc(32 * Lsz);
-    orc_commit_rows(vars, Lsz, Rsz, blinds_vars, &g->pc_n, P.comm_vars);
-    tr_append(&tr, "poly_commitment", (const uint8_t *)"poly_commitment_begin", 21);
-    for (size_t i = 0; i < Lsz; i++) tr_append_point(&tr, "poly_commitment_share", P.comm_vars + 32 * i);
-    tr_append(&tr, "poly_commitment", (const uint8_t *)"poly_commitment_end", 19);
+    tr_challenge_vector(tape, "poly_blinds", blinds_vars, Lsz);
+    P->nC = Lsz; P->comm_vars = (uint8_t *)malloc(32 * Lsz);
+    orc_commit_rows(vars, Lsz, Rsz, blinds_vars, &g->pc_n, P->comm_vars);
+    tr_append(tr, "poly_commitment", (const uint8_t *)"poly_commitment_begin", 21);
+    for (size_t i = 0; i < Lsz; i++) tr_append_point(tr, "poly_commitment_share", P->comm_vars + 32 * i);
+    tr_append(tr, "poly_commitment", (const uint8_t *)"poly_commitment_end", 19);
     st[0] = now_ms() - t0;
 
     /* phase one */
     fr_t *z = build_z(I, vars, inputs, ni);
     size_t nrx = ilog2(N), nry = ilog2(2 * V);
     fr_t *tau = (fr_t *)malloc((nrx + 1) * sizeof(fr_t));
-    tr_challenge_vector(&tr, "challenge_tau", tau, nrx);
+    tr_challenge_vector(tr, "challenge_tau", tau, nrx);
     fr_t *Tq = (fr_t *)malloc(4 * N * sizeof(fr_t)), *Az = Tq + N, *Bz = Az + N, *Cz = Bz + N;
     t0 = now_ms();
     orc_eq_evals(tau, nrx, Tq);
@@ -796,12 +779,12 @@ int orc_nizk_prove(const orc_instance *I, const uint8_t *vars32, size_t nvars, c
     st[1] = now_ms() - t0;
 
     t0 = now_ms();
-    P.nrx = nrx; P.rx = (fr_t *)malloc((nrx + 1) * sizeof(fr_t));
+    P->nrx = nrx; P->rx = (fr_t *)malloc((nrx + 1) * sizeof(fr_t));
     fr_t *bp = (fr_t *)malloc((nrx + nry + 2) * sizeof(fr_t)), *be = (fr_t *)malloc((nrx + nry + 2) * sizeof(fr_t));
     fr_t blind_claim_postsc1;
     {
-        tr_challenge_vector(&tape, "blinds_poly", bp, nrx); tr_challenge_vector(&tape, "blinds_evals", be, nrx);
-        zksc_alloc(&P.sc1, nrx);
+        tr_challenge_vector(tape, "blinds_poly", bp, nrx); tr_challenge_vector(tape, "blinds_evals", be, nrx);
+        zksc_alloc(&P->sc1, nrx);
         sc_state_t s; s.claim = FR_ZERO; s.blind_claim = &FR_ZERO; s.blinds_poly = bp; s.blinds_evals = be;
         commit_scalar_c(s.comm_claim, &FR_ZERO, &FR_ZERO, &g->sc_1);
         size_t len = N;
@@ -809,8 +792,8 @@ int orc_nizk_prove(const orc_instance *I, const uint8_t *vars32, size_t nvars, c
             fr_t e[3], ev[4];
             orc_sc_cubic_evals(Tq, Az, Bz, Cz, len, e);
             ev[0] = e[0]; fr_sub(&ev[1], &s.claim, &e[0]); ev[2] = e[1]; ev[3] = e[2];
-            sc_round(&P.sc1, j, ev, 4, &s, &g->sc_1, &g->sc_4, &tr, &tape, &P.rx[j]);
-            orc_fold_top(Tq, len, &P.rx[j]); orc_fold_top(Az, len, &P.rx[j]); orc_fold_top(Bz, len, &P.rx[j]); orc_fold_top(Cz, len, &P.rx[j]);
+            sc_round(&P->sc1, j, ev, 4, &s, &g->sc_1, &g->sc_4, tr, tape, &P->rx[j]);
+            orc_fold_top(Tq, len, &P->rx[j]); orc_fold_top(Az, len, &P->rx[j]); orc_fold_top(Bz, len, &P->rx[j]); orc_fold_top(Cz, len, &P->rx[j]);
             len /= 2;
         }
         blind_claim_postsc1 = be[nrx - 1];
@@ -819,30 +802,30 @@ int orc_nizk_prove(const orc_instance *I, const uint8_t *vars32, size_t nvars, c
 
     fr_t tau_claim = Tq[0], Az_claim = Az[0], Bz_claim = Bz[0], Cz_claim = Cz[0];
     fr_t Az_blind, Bz_blind, Cz_blind, prod_blind, prod, t, u;
-    tr_challenge_scalar(&tape, "Az_blind", &Az_blind); tr_challenge_scalar(&tape, "Bz_blind", &Bz_blind);
-    tr_challenge_scalar(&tape, "Cz_blind", &Cz_blind); tr_challenge_scalar(&tape, "prod_Az_Bz_blind", &prod_blind);
-    know_prove(&P.pok, P.claims2[2], &g->sc_1, &tr, &tape, &Cz_claim, &Cz_blind);
+    tr_challenge_scalar(tape, "Az_blind", &Az_blind); tr_challenge_scalar(tape, "Bz_blind", &Bz_blind);
+    tr_challenge_scalar(tape, "Cz_blind", &Cz_blind); tr_challenge_scalar(tape, "prod_Az_Bz_blind", &prod_blind);
+    know_prove(&P->pok, P->claims2[2], &g->sc_1, tr, tape, &Cz_claim, &Cz_blind);
     fr_mul(&prod, &Az_claim, &Bz_claim);
-    prod_prove(&P.prod, P.claims2[0], P.claims2[1], P.claims2[3], &g->sc_1, &tr, &tape, &Az_claim, &Az_blind, &Bz_claim, &Bz_blind, &prod, &prod_blind);
-    tr_append_point(&tr, "comm_Az_claim", P.claims2[0]); tr_append_point(&tr, "comm_Bz_claim", P.claims2[1]);
-    tr_append_point(&tr, "comm_Cz_claim", P.claims2[2]); tr_append_point(&tr, "comm_prod_Az_Bz_claims", P.claims2[3]);
+    prod_prove(&P->prod, P->claims2[0], P->claims2[1], P->claims2[3], &g->sc_1, tr, tape, &Az_claim, &Az_blind, &Bz_claim, &Bz_blind, &prod, &prod_blind);
+    tr_append_point(tr, "comm_Az_claim", P->claims2[0]); tr_append_point(tr, "comm_Bz_claim", P->claims2[1]);
+    tr_append_point(tr, "comm_Cz_claim", P->claims2[2]); tr_append_point(tr, "comm_prod_Az_Bz_claims", P->claims2[3]);
     {
         fr_t blind_expected, claim_post;
         fr_sub(&t, &prod_blind, &Cz_blind); fr_mul(&blind_expected, &tau_claim, &t);
         fr_sub(&t, &prod, &Cz_claim); fr_mul(&claim_post, &t, &tau_claim);
-        eq_prove(&P.eq1, &g->sc_1, &tr, &tape, &claim_post, &blind_expected, &claim_post, &blind_claim_postsc1);
+        eq_prove(&P->eq1, &g->sc_1, tr, tape, &claim_post, &blind_expected, &claim_post, &blind_claim_postsc1);
     }
 
     /* phase two */
     fr_t rA, rB, rC, claim2, blind_claim2;
-    tr_challenge_scalar(&tr, "challenege_Az", &rA); tr_challenge_scalar(&tr, "challenege_Bz", &rB); tr_challenge_scalar(&tr, "challenege_Cz", &rC);
+    tr_challenge_scalar(tr, "challenege_Az", &rA); tr_challenge_scalar(tr, "challenege_Bz", &rB); tr_challenge_scalar(tr, "challenege_Cz", &rC);
     fr_mul(&claim2, &rA, &Az_claim); fr_mul(&t, &rB, &Bz_claim); fr_add(&claim2, &claim2, &t); fr_mul(&t, &rC, &Cz_claim); fr_add(&claim2, &claim2, &t);
     fr_mul(&blind_claim2, &rA, &Az_blind); fr_mul(&t, &rB, &Bz_blind); fr_add(&blind_claim2, &blind_claim2, &t); fr_mul(&t, &rC, &Cz_blind); fr_add(&blind_claim2, &blind_claim2, &t);
     t0 = now_ms();
     fr_t *ABC = (fr_t *)malloc(2 * V * sizeof(fr_t));
     {
         fr_t *erx = Tq;                                        /* reuse: N entries */
-        orc_eq_evals(P.rx, nrx, erx);
+        orc_eq_evals(P->rx, nrx, erx);
         fr_t *eA = (fr_t *)malloc(3 * 2 * V * sizeof(fr_t)), *eB = eA + 2 * V, *eC = eB + 2 * V;
         orc_eval_table_sparse(I, erx, eA, eB, eC);
 #pragma omp parallel for num_threads(g_threads) schedule(static) if (V >= 2048)
@@ -854,11 +837,11 @@ int orc_nizk_prove(const orc_instance *I, const uint8_t *vars32, size_t nvars, c
     st[3] = now_ms() - t0;
 
     t0 = now_ms();
-    P.nry = nry; P.ry = (fr_t *)malloc((nry + 1) * sizeof(fr_t));
+    P->nry = nry; P->ry = (fr_t *)malloc((nry + 1) * sizeof(fr_t));
     fr_t claims_phase2[2], blind_claim_postsc2;
     {
-        tr_challenge_vector(&tape, "blinds_poly", bp, nry); tr_challenge_vector(&tape, "blinds_evals", be, nry);
-        zksc_alloc(&P.sc2, nry);
+        tr_challenge_vector(tape, "blinds_poly", bp, nry); tr_challenge_vector(tape, "blinds_evals", be, nry);
+        zksc_alloc(&P->sc2, nry);
         sc_state_t s; s.claim = claim2; s.blind_claim = &blind_claim2; s.blinds_poly = bp; s.blinds_evals = be;
         commit_scalar_c(s.comm_claim, &claim2, &blind_claim2, &g->sc_1);
         size_t len = 2 * V;
@@ -866,8 +849,8 @@ int orc_nizk_prove(const orc_instance *I, const uint8_t *vars32, size_t nvars, c
             fr_t e[2], ev[3];
             orc_sc_quad_evals(z, ABC, len, e);
             ev[0] = e[0]; fr_sub(&ev[1], &s.claim, &e[0]); ev[2] = e[1];
-            sc_round(&P.sc2, j, ev, 3, &s, &g->sc_1, &g->sc_3, &tr, &tape, &P.ry[j]);
-            orc_fold_top(z, len, &P.ry[j]); orc_fold_top(ABC, len, &P.ry[j]);
+            sc_round(&P->sc2, j, ev, 3, &s, &g->sc_1, &g->sc_3, tr, tape, &P->ry[j]);
+            orc_fold_top(z, len, &P->ry[j]); orc_fold_top(ABC, len, &P->ry[j]);
             len /= 2;
         }
         claims_phase2[0] = z[0]; claims_phase2[1] = ABC[0];
@@ -879,69 +862,78 @@ int orc_nizk_prove(const orc_instance *I, const uint8_t *vars32, size_t nvars, c
     t0 = now_ms();
     fr_t eval_vars_at_ry, blind_eval;
     {
-        const fr_t *r = P.ry + 1; size_t rl = nry - 1;                 /* = ell */
+        const fr_t *r = P->ry + 1; size_t rl = nry - 1;                 /* = ell */
         fr_t *chis = (fr_t *)malloc(V * sizeof(fr_t));
         orc_eq_evals(r, rl, chis); dot(&eval_vars_at_ry, vars, chis, V);
         free(chis);
-        tr_challenge_scalar(&tape, "blind_eval", &blind_eval);
-        tr_protocol_name(&tr, "polynomial evaluation proof");
+        tr_challenge_scalar(tape, "blind_eval", &blind_eval);
+        tr_protocol_name(tr, "polynomial evaluation proof");
         size_t lv = rl / 2;
         fr_t *Lv = (fr_t *)malloc(Lsz * sizeof(fr_t)), *Rv = (fr_t *)malloc(Rsz * sizeof(fr_t)), *LZ = (fr_t *)malloc(Rsz * sizeof(fr_t));
         orc_eq_evals(r, lv, Lv); orc_eq_evals(r + lv, rl - lv, Rv);
         orc_poly_bound(vars, Lsz, Rsz, Lv, LZ);
         fr_t LZ_blind; dot(&LZ_blind, blinds_vars, Lv, Lsz);
-        dplog_prove(&P.pe, P.comm_vars_at_ry, g, &tr, &tape, LZ, &LZ_blind, Rv, Rsz, &eval_vars_at_ry, &blind_eval);
+        dplog_prove(&P->pe, P->comm_vars_at_ry, &g->pc_n, &g->pc_1, tr, tape, LZ, &LZ_blind, Rv, Rsz, &eval_vars_at_ry, &blind_eval);
         free(Lv); free(Rv); free(LZ);
     }
     st[5] = now_ms() - t0;
     {
         fr_t one_m, blind_eval_Z, blind_expected, claim_post;
-        fr_sub(&one_m, &FR_ONE, &P.ry[0]); fr_mul(&blind_eval_Z, &one_m, &blind_eval);
+        fr_sub(&one_m, &FR_ONE, &P->ry[0]); fr_mul(&blind_eval_Z, &one_m, &blind_eval);
         fr_mul(&blind_expected, &claims_phase2[1], &blind_eval_Z);
         fr_mul(&claim_post, &claims_phase2[0], &claims_phase2[1]);
-        eq_prove(&P.eq2, &g->pc_1, &tr, &tape, &claim_post, &blind_expected, &claim_post, &blind_claim_postsc2);
+        eq_prove(&P->eq2, &g->pc_1, tr, tape, &claim_post, &blind_expected, &claim_post, &blind_claim_postsc2);
     }
     (void)u;
+    free(blinds_vars); free(z); free(tau); free(Tq); free(bp); free(be); free(ABC);
+}
+
+/* ------------------------------------------------------------------ lib.rs NIZK::prove */
+int orc_nizk_prove(const orc_instance *I, const uint8_t *vars32, size_t nvars, const uint8_t *inputs32, size_t ni, const orc_gens *g,
+                   const uint8_t *tlabel, size_t tlabel_len, const uint8_t seed32[32], uint8_t **proof, size_t *proof_len, double *ms) {
+    size_t V = I->num_vars;
+    if (nvars > V) return ORC_ERR_INVALID_NUM_VARS;
+    if (ni != I->num_inputs) return ORC_ERR_INVALID_NUM_INPUTS;
+    fr_t *vars = (fr_t *)calloc(V, sizeof(fr_t)), *inputs = (fr_t *)calloc(ni + 1, sizeof(fr_t));     /* VarsAssignment::pad */
+    for (size_t i = 0; i < nvars; i++) if (!fr_from_bytes(&vars[i], vars32 + 32 * i)) { free(vars); free(inputs); return ORC_ERR_INVALID_SCALAR; }
+    for (size_t i = 0; i < ni; i++) if (!fr_from_bytes(&inputs[i], inputs32 + 32 * i)) { free(vars); free(inputs); return ORC_ERR_INVALID_SCALAR; }
+    double t_start = now_ms(), st[7] = {0};
+    transcript_t tr, tape; nizk_t P; memset(&P, 0, sizeof P);
+    tr_init(&tr, (const char *)tlabel, tlabel_len);
+    tape_init(&tape, seed32);
+    tr_protocol_name(&tr, "Spartan NIZK proof");
+    r1cs_prove(I, vars, inputs, ni, g, &tr, &tape, &P, st);
     nizk_serialize(&P, proof, proof_len);
     st[6] = now_ms() - t_start;
     if (ms) memcpy(ms, st, sizeof st);
-    nizk_free(&P); free(vars); free(inputs); free(blinds_vars); free(z); free(tau); free(Tq); free(bp); free(be); free(ABC);
+    nizk_free(&P); free(vars); free(inputs);
     return ORC_OK;
 }
 
-/* ------------------------------------------------------------------ r1csproof.rs R1CSProof::verify + lib.rs NIZK::verify */
-int orc_nizk_verify(const orc_instance *I, const uint8_t *inputs32, size_t ni, const orc_gens *g, const uint8_t *tlabel, size_t tlabel_len,
-                    const uint8_t *proof, size_t proof_len) {
-    size_t N = I->num_cons, V = I->num_vars, nrx = ilog2(N), nry = ilog2(2 * V);
-    if (ni != I->num_inputs) return ORC_ERR_INVALID_NUM_INPUTS;
-    nizk_t P; int rc = nizk_parse(&P, proof, proof_len);
-    fr_t *inputs = (fr_t *)calloc(ni + 1, sizeof(fr_t));
-    fr_t *tau = (fr_t *)malloc((nrx + 1) * sizeof(fr_t)), *rx = (fr_t *)malloc((nrx + 1) * sizeof(fr_t)), *ry = (fr_t *)malloc((nry + 1) * sizeof(fr_t));
+/* ------------------------------------------------------------------ r1csproof.rs R1CSProof::verify */
+/* returns the challenges (rx, ry) the transcript produced; inst_evals = (A, B, C)(rx, ry) as claimed by the caller */
+int r1cs_verify(const nizk_t *P, size_t N, size_t V, const fr_t *inputs, size_t ni, const fr_t inst_evals[3], const orc_gens *g, transcript_t *tr,
+                fr_t *rx, fr_t *ry) {
+    size_t nrx = ilog2(N), nry = ilog2(2 * V);
+    int rc = ORC_OK;
+    fr_t *tau = (fr_t *)malloc((nrx + 1) * sizeof(fr_t));
     fr_t *Lv = NULL, *Rv = NULL; ge_t *Cs = NULL;
-    if (rc) goto done;
-    for (size_t i = 0; i < ni; i++) if (!fr_from_bytes(&inputs[i], inputs32 + 32 * i)) { rc = ORC_ERR_INVALID_SCALAR; goto done; }
     size_t ell = ilog2(V), Lsz = (size_t)1 << (ell / 2), Rsz = (size_t)1 << (ell - ell / 2);
-    if (P.nrx != nrx || P.nry != nry || P.nC != Lsz || P.pe.n != ilog2(Rsz)) { rc = ORC_ERR_VERIFY_INTERNAL; goto done; }
-
-    transcript_t tr; tr_init(&tr, (const char *)tlabel, tlabel_len);
-    tr_protocol_name(&tr, "Spartan NIZK proof");
-    fr_t inst_evals[3];
-    inst_evaluate(I, P.rx, nrx, P.ry, nry, inst_evals);
-
-    tr_protocol_name(&tr, "R1CS proof");
-    tr_append(&tr, "poly_commitment", (const uint8_t *)"poly_commitment_begin", 21);
-    for (size_t i = 0; i < P.nC; i++) tr_append_point(&tr, "poly_commitment_share", P.comm_vars + 32 * i);
-    tr_append(&tr, "poly_commitment", (const uint8_t *)"poly_commitment_end", 19);
-    tr_challenge_vector(&tr, "challenge_tau", tau, nrx);
+    if (P->nC != Lsz || P->pe.n != ilog2(Rsz)) { rc = ORC_ERR_VERIFY_INTERNAL; goto done; }
+    tr_protocol_name(tr, "R1CS proof");
+    tr_append(tr, "poly_commitment", (const uint8_t *)"poly_commitment_begin", 21);
+    for (size_t i = 0; i < P->nC; i++) tr_append_point(tr, "poly_commitment_share", P->comm_vars + 32 * i);
+    tr_append(tr, "poly_commitment", (const uint8_t *)"poly_commitment_end", 19);
+    tr_challenge_vector(tr, "challenge_tau", tau, nrx);
 
     uint8_t claim_phase1[32], comm_post1[32], comm_post2[32];
     commit_scalar_c(claim_phase1, &FR_ZERO, &FR_ZERO, &g->sc_1);
-    if ((rc = zksc_verify(&P.sc1, claim_phase1, nrx, 3, &g->sc_1, &g->sc_4, &tr, comm_post1, rx))) goto done;
-    const uint8_t *cAz = P.claims2[0], *cBz = P.claims2[1], *cCz = P.claims2[2], *cPr = P.claims2[3];
-    if ((rc = know_verify(&P.pok, &g->sc_1, &tr, cCz))) goto done;
-    if ((rc = prod_verify(&P.prod, &g->sc_1, &tr, cAz, cBz, cPr))) goto done;
-    tr_append_point(&tr, "comm_Az_claim", cAz); tr_append_point(&tr, "comm_Bz_claim", cBz);
-    tr_append_point(&tr, "comm_Cz_claim", cCz); tr_append_point(&tr, "comm_prod_Az_Bz_claims", cPr);
+    if ((rc = zksc_verify(&P->sc1, claim_phase1, nrx, 3, &g->sc_1, &g->sc_4, tr, comm_post1, rx))) goto done;
+    const uint8_t *cAz = P->claims2[0], *cBz = P->claims2[1], *cCz = P->claims2[2], *cPr = P->claims2[3];
+    if ((rc = know_verify(&P->pok, &g->sc_1, tr, cCz))) goto done;
+    if ((rc = prod_verify(&P->prod, &g->sc_1, tr, cAz, cBz, cPr))) goto done;
+    tr_append_point(tr, "comm_Az_claim", cAz); tr_append_point(tr, "comm_Bz_claim", cBz);
+    tr_append_point(tr, "comm_Cz_claim", cCz); tr_append_point(tr, "comm_prod_Az_Bz_claims", cPr);
     fr_t taus_bound = FR_ONE, t, u, om;
     for (size_t i = 0; i < nrx; i++) {
         fr_mul(&t, &rx[i], &tau[i]); fr_sub(&om, &FR_ONE, &rx[i]); fr_sub(&u, &FR_ONE, &tau[i]); fr_mul(&u, &om, &u); fr_add(&t, &t, &u);
@@ -950,24 +942,24 @@ int orc_nizk_verify(const orc_instance *I, const uint8_t *inputs32, size_t ni, c
     ge_t Ppr, Pcz, Paz, Pbz, E; uint8_t expected1[32];
     if (!ge_decode(&Ppr, cPr) || !ge_decode(&Pcz, cCz) || !ge_decode(&Paz, cAz) || !ge_decode(&Pbz, cBz)) { rc = ORC_ERR_VERIFY_DECOMPRESS; goto done; }
     ge_sub(&E, &Ppr, &Pcz); ge_scalarmul(&E, &E, &taus_bound); ge_encode(expected1, &E);
-    if ((rc = eq_verify(&P.eq1, &g->sc_1, &tr, expected1, comm_post1))) goto done;
+    if ((rc = eq_verify(&P->eq1, &g->sc_1, tr, expected1, comm_post1))) goto done;
 
     fr_t rA, rB, rC;
-    tr_challenge_scalar(&tr, "challenege_Az", &rA); tr_challenge_scalar(&tr, "challenege_Bz", &rB); tr_challenge_scalar(&tr, "challenege_Cz", &rC);
+    tr_challenge_scalar(tr, "challenege_Az", &rA); tr_challenge_scalar(tr, "challenege_Bz", &rB); tr_challenge_scalar(tr, "challenege_Cz", &rC);
     uint8_t comm_claim2[32];
     { ge_t a, b, c; ge_scalarmul(&a, &Paz, &rA); ge_scalarmul(&b, &Pbz, &rB); ge_scalarmul(&c, &Pcz, &rC); ge_add(&a, &a, &b); ge_add(&a, &a, &c); ge_encode(comm_claim2, &a); }
-    if ((rc = zksc_verify(&P.sc2, comm_claim2, nry, 2, &g->sc_1, &g->sc_3, &tr, comm_post2, ry))) goto done;
+    if ((rc = zksc_verify(&P->sc2, comm_claim2, nry, 2, &g->sc_1, &g->sc_3, tr, comm_post2, ry))) goto done;
 
     /* PolyEvalProof::verify */
     {
         const fr_t *r = ry + 1; size_t rl = nry - 1, lv = rl / 2;
-        tr_protocol_name(&tr, "polynomial evaluation proof");
+        tr_protocol_name(tr, "polynomial evaluation proof");
         Lv = (fr_t *)malloc(Lsz * sizeof(fr_t)); Rv = (fr_t *)malloc(Rsz * sizeof(fr_t));
         orc_eq_evals(r, lv, Lv); orc_eq_evals(r + lv, rl - lv, Rv);
         Cs = (ge_t *)malloc(Lsz * sizeof(ge_t));
-        for (size_t i = 0; i < Lsz; i++) if (!ge_decode(&Cs[i], P.comm_vars + 32 * i)) { rc = ORC_ERR_VERIFY_DECOMPRESS; goto done; }
+        for (size_t i = 0; i < Lsz; i++) if (!ge_decode(&Cs[i], P->comm_vars + 32 * i)) { rc = ORC_ERR_VERIFY_DECOMPRESS; goto done; }
         ge_t CLZ; uint8_t C_LZ[32]; ge_msm(&CLZ, Lv, Cs, Lsz); ge_encode(C_LZ, &CLZ);
-        if ((rc = dplog_verify(&P.pe, Rsz, g, &tr, Rv, C_LZ, P.comm_vars_at_ry))) goto done;
+        if ((rc = dplog_verify(&P->pe, Rsz, &g->pc_n, &g->pc_1, tr, Rv, C_LZ, P->comm_vars_at_ry))) goto done;
     }
     /* poly_input_eval: SparsePolynomial over (1, inputs) at ry[1..], MSB-first bits */
     fr_t poly_input_eval = FR_ZERO;
@@ -985,18 +977,39 @@ int orc_nizk_verify(const orc_instance *I, const uint8_t *inputs32, size_t ni, c
     }
     {
         ge_t Cv, Ci, Z; uint8_t expected2[32];
-        if (!ge_decode(&Cv, P.comm_vars_at_ry)) { rc = ORC_ERR_VERIFY_DECOMPRESS; goto done; }
+        if (!ge_decode(&Cv, P->comm_vars_at_ry)) { rc = ORC_ERR_VERIFY_DECOMPRESS; goto done; }
         commit_scalar(&Ci, &poly_input_eval, &FR_ZERO, &g->pc_1);
         fr_sub(&om, &FR_ONE, &ry[0]);
         ge_scalarmul(&Cv, &Cv, &om); ge_scalarmul(&Ci, &Ci, &ry[0]); ge_add(&Z, &Cv, &Ci);
         fr_mul(&t, &rA, &inst_evals[0]); fr_mul(&u, &rB, &inst_evals[1]); fr_add(&t, &t, &u); fr_mul(&u, &rC, &inst_evals[2]); fr_add(&t, &t, &u);
         ge_scalarmul(&Z, &Z, &t); ge_encode(expected2, &Z);
-        if ((rc = eq_verify(&P.eq2, &g->sc_1, &tr, expected2, comm_post2))) goto done;
+        if ((rc = eq_verify(&P->eq2, &g->sc_1, tr, expected2, comm_post2))) goto done;
     }
+done:
+    free(tau); free(Lv); free(Rv); free(Cs);
+    return rc;
+}
+
+/* ------------------------------------------------------------------ lib.rs NIZK::verify */
+int orc_nizk_verify(const orc_instance *I, const uint8_t *inputs32, size_t ni, const orc_gens *g, const uint8_t *tlabel, size_t tlabel_len,
+                    const uint8_t *proof, size_t proof_len) {
+    size_t N = I->num_cons, V = I->num_vars, nrx = ilog2(N), nry = ilog2(2 * V);
+    if (ni != I->num_inputs) return ORC_ERR_INVALID_NUM_INPUTS;
+    nizk_t P; int rc = nizk_parse(&P, proof, proof_len);
+    fr_t *inputs = (fr_t *)calloc(ni + 1, sizeof(fr_t));
+    fr_t *rx = (fr_t *)malloc((nrx + 1) * sizeof(fr_t)), *ry = (fr_t *)malloc((nry + 1) * sizeof(fr_t));
+    if (rc) goto done;
+    for (size_t i = 0; i < ni; i++) if (!fr_from_bytes(&inputs[i], inputs32 + 32 * i)) { rc = ORC_ERR_INVALID_SCALAR; goto done; }
+    if (P.nrx != nrx || P.nry != nry) { rc = ORC_ERR_VERIFY_INTERNAL; goto done; }
+    transcript_t tr; tr_init(&tr, (const char *)tlabel, tlabel_len);
+    tr_protocol_name(&tr, "Spartan NIZK proof");
+    fr_t inst_evals[3];
+    inst_evaluate(I, P.rx, nrx, P.ry, nry, inst_evals);
+    if ((rc = r1cs_verify(&P, N, V, inputs, ni, inst_evals, g, &tr, rx, ry))) goto done;
     /* NIZK::verify: claimed (rx, ry) must be the ones the transcript produced */
     for (size_t i = 0; i < nrx; i++) if (!fr_eq(&rx[i], &P.rx[i])) { rc = ORC_ERR_VERIFY_INTERNAL; goto done; }
     for (size_t i = 0; i < nry; i++) if (!fr_eq(&ry[i], &P.ry[i])) { rc = ORC_ERR_VERIFY_INTERNAL; goto done; }
 done:
-    nizk_free(&P); free(inputs); free(tau); free(rx); free(ry); free(Lv); free(Rv); free(Cs);
+    nizk_free(&P); free(inputs); free(rx); free(ry);
     return rc;
 }
