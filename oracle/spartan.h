@@ -61,6 +61,22 @@ int  orc_nizk_verify(const orc_instance *, const uint8_t *inputs32, size_t ninpu
                      const uint8_t *tlabel, size_t tlabel_len, const uint8_t *proof, size_t proof_len);
 void orc_buf_free(void *);
 
+/* ---- SNARK mode (snark.c): lib.rs SNARKGens / SNARK::{encode, prove, verify}, r1csinstance.rs R1CSCommitment / R1CSEvalProof ---- */
+typedef struct orc_snark_gens orc_snark_gens;
+typedef struct orc_snark_comm orc_snark_comm;                             /* ComputationCommitment (+ ComputationDecommitment on the prover side) */
+orc_snark_gens *orc_snark_gens_new(size_t num_cons, size_t num_vars, size_t num_inputs, size_t num_nz_entries);
+void orc_snark_gens_free(orc_snark_gens *);
+const orc_gens *orc_snark_gens_sat(const orc_snark_gens *);
+orc_snark_comm *orc_snark_encode(const orc_instance *, const orc_snark_gens *);      /* NULL if the generators were made for another size */
+void orc_snark_comm_bytes(const orc_snark_comm *, uint8_t **out, size_t *len);       /* bincode of the commitment */
+orc_snark_comm *orc_snark_comm_parse(const uint8_t *buf, size_t len);                /* the verifier's view */
+void orc_snark_comm_free(orc_snark_comm *);
+/* stage_ms: 9 doubles or NULL — the seven R1CSProof stages, [7] R1CSEvalProof, [8] total */
+int  orc_snark_prove(const orc_instance *, const orc_snark_comm *, const uint8_t *vars32, size_t nvars, const uint8_t *inputs32, size_t ninputs,
+                     const orc_snark_gens *, const uint8_t *tlabel, size_t tlabel_len, const uint8_t seed32[32], uint8_t **proof, size_t *proof_len, double *stage_ms);
+int  orc_snark_verify(const orc_snark_comm *, const uint8_t *inputs32, size_t ninputs, const orc_snark_gens *, const uint8_t *tlabel, size_t tlabel_len,
+                      const uint8_t *proof, size_t proof_len);
+
 /* ---- kernel-level restatements (fr_t arrays are Montgomery form, as stored by fr.h) ---- */
 void orc_eq_evals(const fr_t *r, size_t ell, fr_t *out /* 2^ell */);                           /* dense_mlpoly.rs EqPolynomial::evals */
 void orc_multiply_vec(const orc_instance *, const fr_t *z /* 2V */, fr_t *Az, fr_t *Bz, fr_t *Cz);/* r1csinstance.rs multiply_vec */

@@ -53,6 +53,19 @@ lib.orc_set_threads.argtypes = [ctypes.c_int]
 lib.orc_bullet_reduce.argtypes = [_vp, _vp, _vp, _sz, _vp, _vp, _sz, _vp, _vp, _vp, _vp]
 
 
+lib.orc_snark_gens_new.restype = _vp
+lib.orc_snark_gens_new.argtypes = [_sz, _sz, _sz, _sz]
+lib.orc_snark_gens_free.argtypes = [_vp]
+lib.orc_snark_encode.restype = _vp
+lib.orc_snark_encode.argtypes = [_vp, _vp]
+lib.orc_snark_comm_bytes.argtypes = [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_sz)]
+lib.orc_snark_comm_parse.restype = _vp
+lib.orc_snark_comm_parse.argtypes = [_vp, _sz]
+lib.orc_snark_comm_free.argtypes = [_vp]
+lib.orc_snark_prove.argtypes = [_vp, _vp, _vp, _sz, _vp, _sz, _vp, ctypes.c_char_p, _sz, ctypes.c_char_p, ctypes.POINTER(_vp), ctypes.POINTER(_sz), ctypes.POINTER(ctypes.c_double)]
+lib.orc_snark_verify.argtypes = [_vp, _vp, _sz, _vp, ctypes.c_char_p, _sz, _vp, _sz]
+
+
 def _p(a):
     return a.ctypes.data_as(_vp) if a is not None and a.size else None
 
@@ -108,6 +121,61 @@ class OGens:
     def __del__(self):
         if getattr(self, "h", None):
             lib.orc_gens_free(self.h); self.h = None
+
+
+class OSnarkGens:
+    """lib.rs SNARKGens::new(num_cons, num_vars, num_inputs, num_nz_entries)"""
+
+    def __init__(self, num_cons, num_vars, num_inputs, num_nz_entries):
+        self.h = _vp(lib.orc_snark_gens_new(num_cons, num_vars, num_inputs, num_nz_entries))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib.orc_snark_gens_free(self.h); self.h = None
+
+
+class OSnarkComm:
+    """SNARK::encode: computation commitment (with its decommitment when made by encode; commitment only when parsed from bytes)"""
+
+    def __init__(self, h):
+        if not h:
+            raise ValueError("orc_snark_encode / parse failed")
+        self.h = _vp(h)
+
+    @classmethod
+    def encode(cls, inst, gens):
+        return cls(lib.orc_snark_encode(inst.h, gens.h))
+
+    @classmethod
+    def parse(cls, data):
+        buf = np.frombuffer(data, dtype=np.uint8)
+        return cls(lib.orc_snark_comm_parse(_p(buf), buf.size))
+
+    @property
+    def bytes(self):
+        p, n = _vp(), _sz()
+        lib.orc_snark_comm_bytes(self.h, ctypes.byref(p), ctypes.byref(n))
+        data = ctypes.string_at(p, n.value); lib.orc_buf_free(p); return data
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib.orc_snark_comm_free(self.h); self.h = None
+
+
+def snark_prove(inst, comm, vars32, inputs32, gens, label=b"snark_example", seed=b"\x2a" * 32):
+    v, i = _c(vars32), _c(inputs32)
+    p, n, ms = _vp(), _sz(), (ctypes.c_double * 9)()
+    rc = lib.orc_snark_prove(inst.h, comm.h, _p(v), v.shape[0], _p(i), i.shape[0], gens.h, label, len(label), seed, ctypes.byref(p), ctypes.byref(n), ms)
+    if rc:
+        raise ValueError(f"orc_snark_prove rc={rc}")
+    data = ctypes.string_at(p, n.value)
+    lib.orc_buf_free(p)
+    return data, list(ms)
+
+
+def snark_verify(comm, inputs32, gens, proof, label=b"snark_example"):
+    i = _c(inputs32); buf = np.frombuffer(proof, dtype=np.uint8)
+    return lib.orc_snark_verify(comm.h, _p(i), i.shape[0], gens.h, label, len(label), _p(buf), buf.size)
 
 
 def nizk_prove(inst, vars32, inputs32, gens, label=b"nizk_example", seed=b"\x2a" * 32):

@@ -189,3 +189,42 @@ def test_oracle_rejects_unsatisfied_instance():
     assert not oi.is_sat(v, r["inputs"])
     pf, _ = orc.nizk_prove(oi, v, r["inputs"], og)
     assert orc.nizk_verify(oi, r["inputs"], og, pf) != 0
+
+
+# ------------------------------------------------------------------------------------------------ SNARK mode (oracle/snark.c)
+@pytest.mark.parametrize("n,ni,kind", [(2, 0, "uniform"), (16, 3, "uniform"), (64, 10, "uniform"), (200, 4, "compiler"), (1 << 10, 10, "uniform")])
+def test_oracle_snark_round_trip_and_tamper(n, ni, kind):
+    """SNARK::encode / prove / verify of the restatement: accepts its own proofs (verifier given the commitment BYTES only), rejects
+    flipped bits anywhere in the proof, a wrong public input and a wrong commitment (upstream lib.rs check_snark has the first part)"""
+    import otti_amd as oa
+    r = (oa.synth_r1cs if kind == "uniform" else oa.synth_r1cs_compiler_like)(n, ni, 7)
+    oi = orc.OInstance(r["num_cons"], r["num_vars"], r["num_inputs"], r["A"], r["B"], r["C"])
+    nz = max(r["A"].size, r["B"].size, r["C"].size)
+    g = orc.OSnarkGens(r["num_cons"], r["num_vars"], r["num_inputs"], nz)
+    comm = orc.OSnarkComm.encode(oi, g)
+    proof, _ = orc.snark_prove(oi, comm, r["vars"], r["inputs"], g)
+    proof2, _ = orc.snark_prove(oi, comm, r["vars"], r["inputs"], g)
+    assert proof == proof2                                           # deterministic for a fixed tape seed
+    cv = orc.OSnarkComm.parse(comm.bytes)
+    assert orc.snark_verify(cv, r["inputs"], g, proof) == 0
+    rng = np.random.default_rng(n)
+    for pos in list(rng.integers(0, len(proof), 24)) + [0, len(proof) - 1]:
+        bad = bytearray(proof); bad[int(pos)] ^= 1 << int(rng.integers(0, 8))
+        assert orc.snark_verify(cv, r["inputs"], g, bytes(bad)) != 0, pos
+    assert orc.snark_verify(cv, r["inputs"], g, proof[:-1]) != 0 and orc.snark_verify(cv, r["inputs"], g, proof + b"\0") != 0
+    if ni:
+        wrong = r["inputs"].copy(); wrong[0, 0] ^= 1
+        assert orc.snark_verify(cv, wrong, g, proof) != 0
+    cb = bytearray(comm.bytes); cb[-5] ^= 2                          # another matrix commitment
+    assert orc.snark_verify(orc.OSnarkComm.parse(bytes(cb)), r["inputs"], g, proof) != 0
+    assert orc.snark_verify(cv, r["inputs"], g, proof, label=b"other") != 0
+
+
+def test_oracle_snark_commitment_binds_the_matrices():
+    import otti_amd as oa
+    r = oa.synth_r1cs(32, 2, 3)
+    g = orc.OSnarkGens(32, 32, 2, 32)
+    c1 = orc.OSnarkComm.encode(orc.OInstance(32, 32, 2, r["A"], r["B"], r["C"]), g).bytes
+    B2 = r["B"].copy(); B2["col"][5] = (B2["col"][5] + 1) % 32
+    c2 = orc.OSnarkComm.encode(orc.OInstance(32, 32, 2, r["A"], B2, r["C"]), g).bytes
+    assert c1 != c2 and len(c1) == len(c2)
