@@ -109,6 +109,26 @@ int32_t otti_nizk_prove_sharded(otti_instance *inst, otti_witness *wit, otti_gen
 /* NIZK::verify(&self, &inst, &inputs, &mut Transcript::new(tlabel), &gens) -> Result<(), ProofVerifyError> */
 int32_t otti_nizk_verify(const otti_instance *inst, const uint8_t *inputs32, size_t ninputs, const otti_gens *gens,
                          const uint8_t *tlabel, size_t tlabel_len, const uint8_t *proof, size_t proof_len);
+/* ---- SNARK mode (`spzk verify` without --nizk): upstream lib.rs SNARKGens / ComputationCommitment / SNARK [RECALL].
+   otti_snark_encode = SNARK::encode (once per circuit: the commitment to A, B, C — on the GPU); otti_snark_prove = SNARK::prove
+   (R1CSProof as in NIZK mode + R1CSEvalProof: memory-checking product circuits, batched cubic sum-checks, three polynomial
+   evaluation proofs); otti_snark_verify = SNARK::verify, which needs the commitment only (host; sub-linear in the circuit).
+   num_nz_entries: the largest number of non-zeros of A, B, C (what spartan-zkinterface passes to SNARKGens::new).
+   stage_ms (otti_snark_prove): 10 doubles — the six R1CSProof stages of otti_nizk_prove, [6] derefs commitment, [7] product
+   circuits, [8] hash layer, [9] total. */
+typedef struct otti_snark_gens otti_snark_gens;      /* upstream `SNARKGens` */
+typedef struct otti_comp_comm otti_comp_comm;        /* upstream `ComputationCommitment` (+ `ComputationDecommitment` when made by encode) */
+int32_t otti_snark_gens_new(uint64_t num_cons, uint64_t num_vars, uint64_t num_inputs, uint64_t num_nz_entries, otti_snark_gens **out);
+void    otti_snark_gens_free(otti_snark_gens *gens);
+int32_t otti_snark_encode(otti_instance *inst, otti_snark_gens *gens, otti_comp_comm **out);
+int32_t otti_comp_comm_bytes(const otti_comp_comm *comm, uint8_t **out, size_t *len);        /* bincode of the commitment; free with otti_buf_free */
+int32_t otti_comp_comm_from_bytes(const uint8_t *buf, size_t len, otti_comp_comm **out);     /* the verifier's copy (no decommitment) */
+void    otti_comp_comm_free(otti_comp_comm *comm);
+int32_t otti_snark_prove(otti_instance *inst, otti_comp_comm *comm, const uint8_t *vars32, size_t nvars, const uint8_t *inputs32, size_t ninputs,
+                         otti_snark_gens *gens, const uint8_t *tlabel, size_t tlabel_len, const uint8_t *seed32, uint32_t flags,
+                         uint8_t **proof, size_t *proof_len, double *stage_ms);
+int32_t otti_snark_verify(const otti_comp_comm *comm, const uint8_t *inputs32, size_t ninputs, const otti_snark_gens *gens,
+                          const uint8_t *tlabel, size_t tlabel_len, const uint8_t *proof, size_t proof_len);
 void    otti_buf_free(void *p);
 /* copies the calling thread's last error message (NUL-terminated, truncated to cap) */
 size_t  otti_last_error(char *buf, size_t cap);

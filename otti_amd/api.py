@@ -86,6 +86,15 @@ _sig("otti_nizk_prove_sharded", _i32, _vp, _vp, _vp, ctypes.c_char_p, _sz, _vp, 
      ctypes.POINTER(ctypes.c_double))
 _sig("otti_nizk_verify", _i32, _vp, _vp, _sz, _vp, ctypes.c_char_p, _sz, _vp, _sz)
 _sig("otti_prepare_device", _i32, _vp, _vp)
+_sig("otti_snark_gens_new", _i32, _u64, _u64, _u64, _u64, ctypes.POINTER(_vp))
+_sig("otti_snark_gens_free", None, _vp)
+_sig("otti_snark_encode", _i32, _vp, _vp, ctypes.POINTER(_vp))
+_sig("otti_comp_comm_bytes", _i32, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_sz))
+_sig("otti_comp_comm_from_bytes", _i32, _vp, _sz, ctypes.POINTER(_vp))
+_sig("otti_comp_comm_free", None, _vp)
+_sig("otti_snark_prove", _i32, _vp, _vp, _vp, _sz, _vp, _sz, _vp, ctypes.c_char_p, _sz, _vp, ctypes.c_uint32,
+     ctypes.POINTER(_vp), ctypes.POINTER(_sz), ctypes.POINTER(ctypes.c_double))
+_sig("otti_snark_verify", _i32, _vp, _vp, _sz, _vp, ctypes.c_char_p, _sz, _vp, _sz)
 _sig("otti_zkif_load", _i32, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.POINTER(_R1CS)))
 _sig("otti_zkif_write", _i32, ctypes.POINTER(_R1CS), ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p)
 _sig("otti_r1cs_free", None, ctypes.POINTER(_R1CS))
@@ -340,6 +349,82 @@ class NIZK:
         i = _scalars(inputs.assignment, "inputs")
         buf = np.frombuffer(self.bytes, dtype=np.uint8)
         _check(lib.otti_nizk_verify(inst._h, _ptr(i), i.shape[0], gens._h, label, len(label), _ptr(buf), buf.size))
+
+
+# ---------------------------------------------------------------------------------------------- SNARK mode (lib.rs SNARKGens / SNARK)
+class SNARKGens:
+    """SNARKGens::new(num_cons, num_vars, num_inputs, num_nz_entries)"""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @classmethod
+    def new(cls, num_cons, num_vars, num_inputs, num_nz_entries):
+        h = _vp()
+        _check(lib.otti_snark_gens_new(num_cons, num_vars, num_inputs, num_nz_entries, ctypes.byref(h)))
+        return cls(h)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib.otti_snark_gens_free(self._h)
+            self._h = None
+
+
+class ComputationCommitment:
+    """SNARK::encode(&inst, &gens) -> (ComputationCommitment, ComputationDecommitment); `from_bytes` gives the verifier's copy"""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @classmethod
+    def encode(cls, inst, gens):
+        h = _vp()
+        _check(lib.otti_snark_encode(inst._h, gens._h, ctypes.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_bytes(cls, data):
+        buf = np.frombuffer(bytes(data), dtype=np.uint8)
+        h = _vp()
+        _check(lib.otti_comp_comm_from_bytes(_ptr(buf), buf.size, ctypes.byref(h)))
+        return cls(h)
+
+    @property
+    def bytes(self):
+        p, n = _vp(), _sz()
+        _check(lib.otti_comp_comm_bytes(self._h, ctypes.byref(p), ctypes.byref(n)))
+        return NIZK._take(p, n)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib.otti_comp_comm_free(self._h)
+            self._h = None
+
+
+SNARK_STAGES = ("polycommit", "multiply_vec", "sc_phase_one", "eval_table_sparse", "sc_phase_two", "polyeval", "derefs_commit", "product_circuits", "hash_layer", "total")
+
+
+class SNARK:
+    """SNARK::prove(&inst, &comm, &decomm, vars, &inputs, &gens, &mut Transcript::new(label)) / SNARK::verify(&comm, &inputs, ..)"""
+
+    def __init__(self, proof_bytes, stage_ms=None):
+        self.bytes = proof_bytes
+        self.stage_ms = stage_ms
+
+    @classmethod
+    def prove(cls, inst, comm, vars_, inputs, gens, transcript_label=b"snark_example", seed=None):
+        label = bytes(transcript_label)
+        v, i = _scalars(vars_.assignment, "vars"), _scalars(inputs.assignment, "inputs")
+        p, n, ms = _vp(), _sz(), (ctypes.c_double * 10)()
+        _check(lib.otti_snark_prove(inst._h, comm._h, _ptr(v), v.shape[0], _ptr(i), i.shape[0], gens._h, label, len(label), _seed(seed), 1,
+                                    ctypes.byref(p), ctypes.byref(n), ms))
+        return cls(NIZK._take(p, n), dict(zip(SNARK_STAGES, ms)))
+
+    def verify(self, comm, inputs, gens, transcript_label=b"snark_example"):
+        label = bytes(transcript_label)
+        i = _scalars(inputs.assignment, "inputs")
+        buf = np.frombuffer(self.bytes, dtype=np.uint8)
+        _check(lib.otti_snark_verify(comm._h, _ptr(i), i.shape[0], gens._h, label, len(label), _ptr(buf), buf.size))
 
 
 def shard_init(segment_name, rank, world):

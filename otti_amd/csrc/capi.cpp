@@ -1,6 +1,7 @@
 // extern "C" surface of libottispartan (include/otti_spartan.h).  No exception crosses this boundary.
 #include "device.h"
 #include "shard.h"
+#include "snark.h"
 #include <array>
 #include <mutex>
 
@@ -9,6 +10,8 @@ using namespace otti;
 struct otti_instance { std::unique_ptr<Instance> I; };
 struct otti_gens { std::unique_ptr<Gens> g; };
 struct otti_witness { std::unique_ptr<DeviceWitness> w; };
+struct otti_snark_gens { std::unique_ptr<SnarkGens> g; };
+struct otti_comp_comm { std::unique_ptr<CompComm> c; };
 
 otti_r1cs *otti_r1cs_from(size_t nc, size_t nv, size_t ni, const std::vector<otti_entry> &A, const std::vector<otti_entry> &B,
                           const std::vector<otti_entry> &C, const std::vector<uint8_t> &vars, const std::vector<uint8_t> &inputs);
@@ -236,6 +239,54 @@ int32_t otti_nizk_verify(const otti_instance *inst, const uint8_t *inputs32, siz
             } catch (const Error &) { ev = nullptr; }
         }
         int rc = nizk_verify(*inst->I, inputs, *gens->g, tlabel, tlabel_len, proof, proof_len, ev);
+        if (rc) g_last_error = "proof rejected";
+        return rc;
+    });
+}
+
+// ------------------------------------------------------------------------------------------------ SNARK mode
+int32_t otti_snark_gens_new(uint64_t nc, uint64_t nv, uint64_t ni, uint64_t nnz, otti_snark_gens **out) {
+    return guarded([&] {
+        if (!out) throw Error(OTTI_ERR_BAD_ARG, "null out pointer");
+        auto h = std::make_unique<otti_snark_gens>(); h->g = snark_gens_new(nc, nv, ni, nnz); *out = h.release(); return OTTI_OK;
+    });
+}
+void otti_snark_gens_free(otti_snark_gens *p) { delete p; }
+int32_t otti_snark_encode(otti_instance *inst, otti_snark_gens *gens, otti_comp_comm **out) {
+    return guarded([&] {
+        if (!inst || !gens || !out) throw Error(OTTI_ERR_BAD_ARG, "null argument");
+        auto h = std::make_unique<otti_comp_comm>(); h->c = snark_encode_gpu(*inst->I, *gens->g); *out = h.release(); return OTTI_OK;
+    });
+}
+int32_t otti_comp_comm_bytes(const otti_comp_comm *comm, uint8_t **out, size_t *len) {
+    return guarded([&] { if (!comm || !out || !len) throw Error(OTTI_ERR_BAD_ARG, "null argument"); *out = to_malloc(comm->c->serialize(), len); return OTTI_OK; });
+}
+int32_t otti_comp_comm_from_bytes(const uint8_t *buf, size_t len, otti_comp_comm **out) {
+    return guarded([&] {
+        if (!buf || !out) throw Error(OTTI_ERR_BAD_ARG, "null argument");
+        auto h = std::make_unique<otti_comp_comm>(); h->c = CompComm::parse(buf, len); *out = h.release(); return OTTI_OK;
+    });
+}
+void otti_comp_comm_free(otti_comp_comm *p) { delete p; }
+int32_t otti_snark_prove(otti_instance *inst, otti_comp_comm *comm, const uint8_t *vars32, size_t nvars, const uint8_t *inputs32, size_t ninputs, otti_snark_gens *gens,
+                         const uint8_t *tlabel, size_t tlabel_len, const uint8_t *seed32, uint32_t flags, uint8_t **proof, size_t *proof_len, double *stage_ms) {
+    return guarded([&] {
+        if (!inst || !comm || !gens || !proof || !proof_len) throw Error(OTTI_ERR_BAD_ARG, "null argument");
+        if (!(flags & OTTI_FLAG_GPU)) throw Error(OTTI_ERR_BAD_ARG, "OTTI_FLAG_GPU is the only proving backend; there is no CPU path");
+        if (ninputs != inst->I->num_inputs) throw Error(OTTI_ERR_INVALID_NUM_INPUTS, "wrong number of inputs");
+        std::vector<Fr> inputs = scalars_from_bytes(inputs32, ninputs);
+        SnarkTimings tm{};
+        std::vector<uint8_t> pf = snark_prove_gpu(*inst->I, *comm->c, vars32, nvars, inputs, *gens->g, tlabel, tlabel_len, seed32, &tm);
+        if (stage_ms) memcpy(stage_ms, tm.ms, sizeof tm.ms);
+        *proof = to_malloc(pf, proof_len); return OTTI_OK;
+    });
+}
+int32_t otti_snark_verify(const otti_comp_comm *comm, const uint8_t *inputs32, size_t ninputs, const otti_snark_gens *gens, const uint8_t *tlabel, size_t tlabel_len,
+                          const uint8_t *proof, size_t proof_len) {
+    return guarded([&] {
+        if (!comm || !gens || !proof) throw Error(OTTI_ERR_BAD_ARG, "null argument");
+        std::vector<Fr> inputs = scalars_from_bytes(inputs32, ninputs);
+        int rc = snark_verify(*comm->c, inputs, *gens->g, tlabel, tlabel_len, proof, proof_len);
         if (rc) g_last_error = "proof rejected";
         return rc;
     });

@@ -114,7 +114,12 @@ void instance_evaluate_gpu(Instance &I, const std::vector<Fr> &rx, const std::ve
 class ShardComm;
 std::vector<uint8_t> nizk_prove_resident(Instance &I, DeviceWitness &wit, Gens &g, const void *tlabel, size_t tlabel_len, const uint8_t *seed32,
                                          ProveTimings *tm, ShardComm *sh = nullptr);
+void r1cs_prove_device(Instance &I, DeviceWitness &wit, Gens &g, Transcript &tr, RandomTape &tape, NizkProof &P, ProveTimings &T, ShardComm *sh);
 std::shared_ptr<DeviceShard> upload_instance_shard(const Instance &I, int rank, int world);
+// DotProductProofLog::prove on the device (prover.cpp): generator stream indices of (gens_n.h, gens_1.G[0], gens_1.h) and the row length
+struct PeBufs { Fr *LZ, *Rv, *a, *s, *b2, *s2, *rows, *extras; };      // R elements each (rows: 2 R, extras: 4 (log2 R + 1))
+DotProductProofLog dplog_prove_device(DevCtx &c, const DeviceGens &DG, const Gens &g, const PcView &v, const PeBufs &B, const Fr &LZ_blind, const Fr *y_known,
+                                      const Fr &blind_y, CPoint &Cy_out, Transcript &tr, RandomTape &tape);
 size_t dev_witness_ingest(DevCtx &c, Fr *z, size_t n);                     // returns the number of non-canonical scalars (zeroed)
 void dev_gather_strided(DevCtx &c, const Fr *in, size_t stride, size_t offset, Fr *out, size_t n);   // out[i] = in[i*stride + offset]
 

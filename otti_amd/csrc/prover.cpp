@@ -164,6 +164,73 @@ ProofScratch &workspace(DevCtx &c) { if (!c.scratch) c.scratch = new Scratch(); 
 inline CPoint point_at(const DevCtx &c, size_t i) { CPoint p; memcpy(p.b, c.h_points + 32 * i, 32); return p; }
 }  // namespace
 
+// nizk/mod.rs DotProductProofLog::prove on device vectors: x = LZ (the bound polynomial row, R elements) against a = Rv, over the
+// generators gens_n = P[0..R) / gens_1 of the stream `g` was derived from (PcView: stream indices).  Cx, the bullet-reduction rounds
+// (on the ORIGINAL generators, k_msm.hip) and delta are fixed-base MSM launches; y = <x, a> is either given or read from result slot 12
+// (a dev_dot queued by the caller).  Buffers are R elements each (rows: 2R, extras: 4 (lgR + 1)); LZ and Rv are consumed.
+DotProductProofLog dplog_prove_device(DevCtx &c, const DeviceGens &DG, const Gens &g, const PcView &v, const PeBufs &B, const Fr &LZ_blind, const Fr *y_known,
+                                      const Fr &blind_y, CPoint &Cy_out, Transcript &tr, RandomTape &tape) {
+    const size_t Rsz = v.R, lgR = ilog2(Rsz);
+    DotProductProofLog pf;
+    tr.append_protocol_name("dot product proof (log)");
+    Fr d = tape.random_scalar("d"), r_delta = tape.random_scalar("r_delta"), r_beta = tape.random_scalar("r_delta");   // sic: upstream reuses the label
+    std::vector<Fr> bv1 = tape.random_vector("blinds_vec_1", 2 * lgR), bv2 = tape.random_vector("blinds_vec_2", 2 * lgR);
+    unsigned long long tk_cx = 0;
+    {   // Cx = commit(LZ, LZ_blind) over gens_n
+        OTTI_HIP(hipMemcpyAsync(B.extras, &LZ_blind, sizeof(Fr), hipMemcpyHostToDevice, c.stream));
+        uint32_t hb = v.h_n;
+        tk_cx = dev_msm_rows(c, DG, B.LZ, Rsz, Rsz, 1, B.extras, &hb, 1);
+    }
+    c.wait_points(tk_cx);
+    const Fr y = y_known ? *y_known : c.h_results[12];
+    CPoint Cx = point_at(c, 0);
+    tr.append_point("Cx", Cx.b);
+    { Term t2[2] = {{v.g1, y}, {v.h1, blind_y}}; g.commit_terms_c(Cy_out.b, t2, 2); }
+    tr.append_point("Cy", Cy_out.b);
+    Fr blind_fin = fr_add(LZ_blind, blind_y);
+    // BulletReductionProof::prove on the original generators (see k_msm.hip)
+    std::vector<Fr> ex(4 * (lgR + 1), fr_zero());
+    for (size_t k = 0; k < lgR; k++) { ex[4 * k + 1] = bv1[k]; ex[4 * k + 3] = bv2[k]; }
+    OTTI_HIP(hipMemcpyAsync(B.extras, ex.data(), ex.size() * sizeof(Fr), hipMemcpyHostToDevice, c.stream));
+    // round state ping-pongs between two buffer sets: launch k reads set k&1 and writes the folded state to set (k+1)&1
+    Fr *abuf[2] = {B.LZ, B.a}, *bbuf[2] = {B.Rv, B.b2}, *sbuf[2] = {B.s, B.s2};
+    dev_fill_one(c, sbuf[0], Rsz);
+    size_t n = Rsz, round = 0;
+    const uint32_t qh[2] = {v.g1, v.h_n};
+    Fr u = fr_zero(), ui = fr_zero();
+    while (n != 1) {
+        const int in = (int)(round & 1), out = in ^ 1;
+        unsigned long long tk = dev_bullet_round(c, DG, Rsz, n, round != 0, u, ui, abuf[in], bbuf[in], sbuf[in], abuf[out], bbuf[out], sbuf[out], B.extras + 4 * round, qh);
+        c.wait_points(tk);
+        CPoint Lp = point_at(c, 0), Rp = point_at(c, 1);
+        tr.append_point("L", Lp.b); tr.append_point("R", Rp.b);
+        pf.L_vec.push_back(Lp); pf.R_vec.push_back(Rp);
+        u = tr.challenge_scalar("u"); ui = fr_inv(u);
+        blind_fin = fr_add(blind_fin, fr_add(fr_mul(fr_mul(bv1[round], u), u), fr_mul(fr_mul(bv2[round], ui), ui)));
+        n /= 2; round++;
+    }
+    // last fold (length 2 -> 1) in place on the current set; s gets its final coefficients
+    Fr *afin = abuf[round & 1], *bvec = bbuf[round & 1], *sfin = sbuf[round & 1];
+    if (round) dev_bullet_step(c, afin, bvec, sfin, Rsz, 1, true, u, ui, B.rows, B.extras);
+    dev_fetch(c, afin, 13, 1); dev_fetch(c, bvec, 14, 1);
+    // delta = d * g_hat + r_delta * h with g_hat = sum_j s[j] P[j]
+    dev_scale(c, sfin, d, B.rows, Rsz);
+    OTTI_HIP(hipMemcpyAsync(B.extras, &r_delta, sizeof(Fr), hipMemcpyHostToDevice, c.stream));
+    unsigned long long tk_delta;
+    { uint32_t hb = v.h1; tk_delta = dev_msm_rows(c, DG, B.rows, Rsz, Rsz, 1, B.extras, &hb, 1); }
+    c.wait_points(tk_delta);
+    const Fr x_hat = c.h_results[13], a_hat = c.h_results[14];
+    pf.delta = point_at(c, 0);
+    tr.append_point("delta", pf.delta.b);
+    { Term t2[2] = {{v.g1, d}, {v.h1, r_beta}}; g.commit_terms_c(pf.beta.b, t2, 2); }
+    tr.append_point("beta", pf.beta.b);
+    Fr ch = tr.challenge_scalar("c");
+    Fr y_hat = fr_mul(x_hat, a_hat);
+    pf.z1 = fr_add(d, fr_mul(ch, y_hat));
+    pf.z2 = fr_add(fr_mul(a_hat, fr_add(fr_mul(ch, blind_fin), r_beta)), r_delta);
+    return pf;
+}
+
 // The last log2(g) rounds of a sharded sum-check: every rank holds the same g-element tables on the host (one element came from each
 // rank) and plays the rounds there.  Same arithmetic as k_sc_cubic_eval / k_sc_quad_eval / k_fold_top.
 static void host_cubic_evals(const std::vector<Fr> T[4], Fr e[3]) {
@@ -192,10 +259,10 @@ static void host_fold_top(std::vector<Fr> &t, const Fr &r) {
     t.resize(h);
 }
 
-std::vector<uint8_t> nizk_prove_resident(Instance &I, DeviceWitness &wit, Gens &g, const void *tlabel, size_t tlabel_len, const uint8_t *seed32,
-                                         ProveTimings *tm, ShardComm *sh) {
+// R1CSProof::prove on the device.  The transcript already carries the caller's protocol name (NIZK / SNARK) and whatever that caller
+// appends before the satisfiability proof; P receives the proof and the challenges (rx, ry); T.ms[0..5] the stage times.
+void r1cs_prove_device(Instance &I, DeviceWitness &wit, Gens &g, Transcript &tr, RandomTape &tape, NizkProof &P, ProveTimings &T, ShardComm *sh) {
     DevCtx &c = DevCtx::get();
-    SpinPool::Session pool_session;                               // helper threads spin for the duration of this proof
     ensure_device_objects(I, g);
     const DeviceInstance &DI = *I.dev; const DeviceGens &DG = *g.dev;
     const size_t N = I.num_cons, V = I.num_vars, nrx = ilog2(N), nry = ilog2(2 * V);
@@ -214,18 +281,14 @@ std::vector<uint8_t> nizk_prove_resident(Instance &I, DeviceWitness &wit, Gens &
     }
     const DeviceCsrSet &rows_set = sh ? I.shard->by_row : DI.by_row, &cols_set = sh ? I.shard->by_col : DI.by_col;
 
-    double t_start = now_ms(), t0; ProveTimings T{};
+    double t0;
     const size_t lgR = ilog2(Rsz);
     ProofScratch &S = workspace(c);
     S.reserve(N, V, Lsz, Rsz, lgR);
     c.ensure_points(std::max(Lsz, 4 * (nrx + nry)), 2 * std::max<size_t>(1, Rsz / 256));   // every MSM result buffer of this proof, before the first launch
     const Fr *d_vars = wit.z.p, *my_rows = d_vars + rk * Ll * Rsz;         // this rank's block of witness-matrix rows
 
-    Transcript tr(tlabel, tlabel_len);
-    RandomTape tape(seed32);
-    NizkProof P;
     SumcheckState early1, early2; RoundPointsJob round_points;       // tape-only parts of both sum-checks, started during polycommit
-    tr.append_protocol_name("Spartan NIZK proof");
     tr.append_protocol_name("R1CS proof");
 
     // ---- polycommit: DensePolynomial::commit (K8).  The witness terms of every row are summed first (no host input needed);
@@ -476,64 +539,9 @@ std::vector<uint8_t> nizk_prove_resident(Instance &I, DeviceWitness &wit, Gens &
         for (size_t i = 0; i < Lsz; i++) LZ_blind = fr_add(LZ_blind, fr_mul(blinds_vars[i], Lv_host[i]));
         blind_eval = tape.random_scalar("blind_eval");
         tr.append_protocol_name("polynomial evaluation proof");
-        // DotProductProofLog::prove
-        tr.append_protocol_name("dot product proof (log)");
-        Fr d = tape.random_scalar("d"), r_delta = tape.random_scalar("r_delta"), r_beta = tape.random_scalar("r_delta");   // sic: upstream reuses the label
-        std::vector<Fr> bv1 = tape.random_vector("blinds_vec_1", 2 * lgR), bv2 = tape.random_vector("blinds_vec_2", 2 * lgR);
-        unsigned long long tk_cx = 0;
-        {   // Cx = commit(LZ, LZ_blind) over gens_n
-            OTTI_HIP(hipMemcpyAsync(S.extras.p, &LZ_blind, sizeof(Fr), hipMemcpyHostToDevice, c.stream));
-            uint32_t hb = g.pc_n.h;
-            tk_cx = dev_msm_rows(c, DG, S.LZ.p, Rsz, Rsz, 1, S.extras.p, &hb, 1);
-        }
-        c.wait_points(tk_cx);
-        const Fr eval_vars_at_ry = c.h_results[12];
-        CPoint Cx = point_at(c, 0);
-        tr.append_point("Cx", Cx.b);
-        { Term t2[2] = {{g.pc_1.G[0], eval_vars_at_ry}, {g.pc_1.h, blind_eval}}; g.commit_terms_c(P.comm_vars_at_ry.b, t2, 2); }
-        tr.append_point("Cy", P.comm_vars_at_ry.b);
-        Fr blind_fin = fr_add(LZ_blind, blind_eval);
-        // BulletReductionProof::prove on the original generators (see k_msm.hip)
-        std::vector<Fr> ex(4 * (lgR + 1), fr_zero());
-        for (size_t k = 0; k < lgR; k++) { ex[4 * k + 1] = bv1[k]; ex[4 * k + 3] = bv2[k]; }
-        OTTI_HIP(hipMemcpyAsync(S.extras.p, ex.data(), ex.size() * sizeof(Fr), hipMemcpyHostToDevice, c.stream));
-        // round state ping-pongs between two buffer sets: launch k reads set k&1 and writes the folded state to set (k+1)&1
-        Fr *abuf[2] = {S.LZ.p, S.a.p}, *bbuf[2] = {S.Rv.p, S.b2.p}, *sbuf[2] = {S.s.p, S.s2.p};
-        dev_fill_one(c, sbuf[0], Rsz);
-        size_t n = Rsz, round = 0;
-        const uint32_t qh[2] = {g.pc_1.G[0], g.pc_n.h};
-        Fr u = fr_zero(), ui = fr_zero();
-        while (n != 1) {
-            const int in = (int)(round & 1), out = in ^ 1;
-            unsigned long long tk = dev_bullet_round(c, DG, Rsz, n, round != 0, u, ui, abuf[in], bbuf[in], sbuf[in], abuf[out], bbuf[out], sbuf[out],
-                                                     S.extras.p + 4 * round, qh);
-            c.wait_points(tk);
-            CPoint Lp = point_at(c, 0), Rp = point_at(c, 1);
-            tr.append_point("L", Lp.b); tr.append_point("R", Rp.b);
-            P.polyeval.L_vec.push_back(Lp); P.polyeval.R_vec.push_back(Rp);
-            u = tr.challenge_scalar("u"); ui = fr_inv(u);
-            blind_fin = fr_add(blind_fin, fr_add(fr_mul(fr_mul(bv1[round], u), u), fr_mul(fr_mul(bv2[round], ui), ui)));
-            n /= 2; round++;
-        }
-        // last fold (length 2 -> 1) in place on the current set; s gets its final coefficients
-        Fr *afin = abuf[round & 1], *bvec = bbuf[round & 1], *sfin = sbuf[round & 1];
-        if (round) dev_bullet_step(c, afin, bvec, sfin, Rsz, 1, true, u, ui, S.rows.p, S.extras.p);
-        dev_fetch(c, afin, 13, 1); dev_fetch(c, bvec, 14, 1);
-        // delta = d * g_hat + r_delta * h with g_hat = sum_j s[j] P[j]
-        dev_scale(c, sfin, d, S.rows.p, Rsz);
-        OTTI_HIP(hipMemcpyAsync(S.extras.p, &r_delta, sizeof(Fr), hipMemcpyHostToDevice, c.stream));
-        unsigned long long tk_delta;
-        { uint32_t hb = g.pc_1.h; tk_delta = dev_msm_rows(c, DG, S.rows.p, Rsz, Rsz, 1, S.extras.p, &hb, 1); }
-        c.wait_points(tk_delta);
-        const Fr x_hat = c.h_results[13], a_hat = c.h_results[14];
-        P.polyeval.delta = point_at(c, 0);
-        tr.append_point("delta", P.polyeval.delta.b);
-        { Term t2[2] = {{g.pc_1.G[0], d}, {g.pc_1.h, r_beta}}; g.commit_terms_c(P.polyeval.beta.b, t2, 2); }
-        tr.append_point("beta", P.polyeval.beta.b);
-        Fr ch = tr.challenge_scalar("c");
-        Fr y_hat = fr_mul(x_hat, a_hat);
-        P.polyeval.z1 = fr_add(d, fr_mul(ch, y_hat));
-        P.polyeval.z2 = fr_add(fr_mul(a_hat, fr_add(fr_mul(ch, blind_fin), r_beta)), r_delta);
+        const PcView pv = {g.pc_n.h, g.pc_1.G[0], g.pc_1.h, Rsz};
+        const PeBufs pb = {S.LZ.p, S.Rv.p, S.a.p, S.s.p, S.b2.p, S.s2.p, S.rows.p, S.extras.p};
+        P.polyeval = dplog_prove_device(c, DG, g, pv, pb, LZ_blind, nullptr, blind_eval, P.comm_vars_at_ry, tr, tape);
     }
     T.ms[5] = now_ms() - t0;
 
@@ -544,6 +552,18 @@ std::vector<uint8_t> nizk_prove_resident(Instance &I, DeviceWitness &wit, Gens &
         Fr claim_post = fr_mul(claims_phase2[0], claims_phase2[1]);
         P.eq2 = equality_prove(g, tr, tape, claim_post, blind_expected, claim_post, blind_claim_postsc2);
     }
+}
+
+std::vector<uint8_t> nizk_prove_resident(Instance &I, DeviceWitness &wit, Gens &g, const void *tlabel, size_t tlabel_len, const uint8_t *seed32,
+                                         ProveTimings *tm, ShardComm *sh) {
+    DevCtx &c = DevCtx::get();
+    SpinPool::Session pool_session;                               // helper threads spin for the duration of this proof
+    const double t_start = now_ms(); ProveTimings T{};
+    Transcript tr(tlabel, tlabel_len);
+    RandomTape tape(seed32);
+    NizkProof P;
+    tr.append_protocol_name("Spartan NIZK proof");
+    r1cs_prove_device(I, wit, g, tr, tape, P, T, sh);
     std::vector<uint8_t> out = P.serialize();
     T.ms[6] = now_ms() - t_start;
     OTTI_HIP(hipStreamSynchronize(c.stream));                    // already drained: every result above was waited for

@@ -1,0 +1,365 @@
+// SNARK mode on the MI355X: SNARK::encode (computation commitment) and SNARK::prove = R1CSProof (prover.cpp, the NIZK device path) +
+// R1CSEvalProof.  Follows upstream libspartan src/lib.rs, src/r1csinstance.rs, src/sparse_mlpoly.rs, src/product_tree.rs step for step
+// [RECALL; /root/reference/Spartan is an empty submodule]; see snark.h.
+//
+// Data flow of R1CSEvalProof: the dense representation of A, B, C (addresses, timestamps, values: 16 N + 2 M field elements) and the
+// two generator window tables stay in HBM; per proof the device builds eq(rx), eq(ry), dereferences them by address (6 N elements, committed
+// with the bulk MSM), hashes 12 operation vectors and 4 memory vectors into product circuits (about 24 N + 8 M elements with all layers),
+// and plays the layered sum-checks: every round is one evaluation launch over all tables of the batch plus one fold launch; the host
+// only hashes four scalars per round (this sum-check is not zero-knowledge: no commitments on the sequential path).  The three closing
+// polynomial-evaluation proofs reuse the log-size dot-product prover of NIZK mode (bullet rounds on the original generators).
+#include "snark.h"
+#include "snark_dev.h"
+#include "pool.h"
+#include <chrono>
+
+namespace otti {
+
+static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+constexpr int kSumSlot = 64;                                  // where a round's sums land in the pinned result buffer
+
+// the dense representation of sparse_mlpoly.rs MultiSparseMatPolynomialAsDense, resident in HBM
+struct DeviceDecomm {
+    size_t N = 0, M = 0;
+    DevBuf<uint32_t> row_addr[3], col_addr[3];
+    DevBuf<Fr> comb_ops;                                     // [row addr A,B,C | row read_ts A,B,C | col addr A,B,C | col read_ts A,B,C | val A,B,C | 0..]: 16 N
+    DevBuf<Fr> comb_mem;                                     // [row audit_ts | col audit_ts]: 2 M
+    Fr *part(int p, int k) const { return comb_ops.p + (size_t)(3 * p + k) * N; }
+};
+
+namespace {
+std::vector<CPoint> commit_poly(DevCtx &c, Gens &gens, const Fr *Z, const PcSet &s) {
+    ensure_gens_device(gens);
+    const bool sparse = dev_small_fraction(c, Z, s.L * s.R) > 0.25;
+    dev_msm_rows(c, *gens.dev, Z, s.R, s.R, s.L, nullptr, nullptr, 0, MSM_COMPRESSED, nullptr, sparse);
+    c.sync();
+    std::vector<CPoint> out(s.L);
+    memcpy(out.data(), c.h_points, 32 * s.L);
+    return out;
+}
+void append_poly_commitment(Transcript &tr, const char *label, const std::vector<CPoint> &C) {
+    tr.append_message(label, "poly_commitment_begin", 21);
+    for (auto &p : C) tr.append_point("poly_commitment_share", p.b);
+    tr.append_message(label, "poly_commitment_end", 19);
+}
+void append_unipoly(Transcript &tr, const Fr *c, size_t n) {
+    tr.append_message("poly", "UniPoly_begin", 13);
+    for (size_t i = 0; i < n; i++) tr.append_scalar("coeff", c[i]);
+    tr.append_message("poly", "UniPoly_end", 11);
+}
+Fr reduce_evals(std::vector<Fr> v, const std::vector<Fr> &ch) {    // bound_poly_var_bot, last challenge first
+    for (size_t i = ch.size(); i-- > 0;) { size_t h = v.size() / 2; for (size_t k = 0; k < h; k++) v[k] = fr_add(v[2 * k], fr_mul(ch[i], fr_sub(v[2 * k + 1], v[2 * k]))); v.resize(h); }
+    return v[0];
+}
+}  // namespace
+
+// ================================================================================================ SNARK::encode
+std::unique_ptr<CompComm> snark_encode_gpu(Instance &I, SnarkGens &g) {
+    DevCtx &c = DevCtx::get();
+    if (I.num_cons != g.num_cons || I.num_vars != g.num_vars) throw Error(OTTI_ERR_BAD_ARG, "SNARK generators were made for a different instance size");
+    size_t nz = 0; for (int k = 0; k < 3; k++) nz = std::max(nz, I.M[k].val.size() + ((I.given_cons < 2 && I.num_cons > I.M[k].val.size()) ? I.num_cons - I.M[k].val.size() : 0));
+    const size_t N = next_pow2(std::max<size_t>(nz, 2)), M = (size_t)1 << std::max(ilog2(I.num_cons), ilog2(2 * I.num_vars));
+    if (ilog2(16 * N) != g.ops.num_vars || ilog2(2 * M) != g.mem.num_vars) throw Error(OTTI_ERR_BAD_ARG, "SNARK generators were made for a different number of non-zero entries");
+    auto dec = std::make_shared<DeviceDecomm>(); dec->N = N; dec->M = M;
+    // MultiSparseMatPolynomialAsDense on the host (the timestamps are a sequential scan: read_ts = visits of that address so far), once per circuit
+    std::vector<Fr> comb_ops(16 * N, fr_zero()), comb_mem(2 * M, fr_zero());
+    std::vector<uint32_t> addr[2][3];
+    for (int k = 0; k < 3; k++) {
+        const SparseMat &m = I.M[k];
+        addr[0][k].assign(N, 0); addr[1][k].assign(N, 0);
+        for (size_t i = 0; i < m.val.size(); i++) { addr[0][k][i] = m.row[i]; addr[1][k][i] = m.col[i]; comb_ops[(size_t)(12 + k) * N + i] = m.val[i]; }
+        if (I.given_cons < 2)                                 // upstream pads 0 / 1 constraints with explicit zero entries (row i, column num_vars)
+            for (size_t i = m.val.size(); i < I.num_cons; i++) { addr[0][k][i] = (uint32_t)i; addr[1][k][i] = (uint32_t)I.num_vars; }
+    }
+    for (int side = 0; side < 2; side++) {                    // AddrTimestamps::new: audit_ts is shared by the three matrices
+        std::vector<uint32_t> audit(M, 0);
+        for (int k = 0; k < 3; k++)
+            for (size_t i = 0; i < N; i++) {
+                const uint32_t a = addr[side][k][i];
+                comb_ops[(size_t)(6 * side + k) * N + i] = fr_from_u64(a);
+                comb_ops[(size_t)(6 * side + 3 + k) * N + i] = fr_from_u64(audit[a]++);
+            }
+        for (size_t i = 0; i < M; i++) comb_mem[(size_t)side * M + i] = fr_from_u64(audit[i]);
+    }
+    dec->comb_ops.alloc(16 * N); dec->comb_mem.alloc(2 * M);
+    OTTI_HIP(hipMemcpyAsync(dec->comb_ops.p, comb_ops.data(), comb_ops.size() * sizeof(Fr), hipMemcpyHostToDevice, c.stream));
+    OTTI_HIP(hipMemcpyAsync(dec->comb_mem.p, comb_mem.data(), comb_mem.size() * sizeof(Fr), hipMemcpyHostToDevice, c.stream));
+    for (int k = 0; k < 3; k++) {
+        dec->row_addr[k].alloc(N); dec->col_addr[k].alloc(N);
+        OTTI_HIP(hipMemcpyAsync(dec->row_addr[k].p, addr[0][k].data(), N * 4, hipMemcpyHostToDevice, c.stream));
+        OTTI_HIP(hipMemcpyAsync(dec->col_addr[k].p, addr[1][k].data(), N * 4, hipMemcpyHostToDevice, c.stream));
+    }
+    c.sync();
+    auto cc = std::make_unique<CompComm>();
+    cc->num_cons = I.num_cons; cc->num_vars = I.num_vars; cc->num_inputs = I.num_inputs; cc->num_ops = N; cc->num_mem_cells = M;
+    cc->comm_ops = commit_poly(c, *g.eval, dec->comb_ops.p, g.ops);          // SparseMatPolynomial::multi_commit: comb_ops.commit(gens_ops, None), comb_mem.commit(gens_mem, None)
+    cc->comm_mem = commit_poly(c, *g.eval, dec->comb_mem.p, g.mem);
+    cc->dec = dec;
+    return cc;
+}
+
+// ================================================================================================ product circuits and their batched proof
+namespace {
+// a batch of product circuits of one size: layer k of circuit i is (left, right) = store + off[k] + {0, n >> (k + 1)}
+struct Circuits {
+    size_t n = 0, nl = 0; int count = 0;
+    std::vector<DevBuf<Fr>> store; std::vector<size_t> off;
+    void init(int cnt, size_t n_) {
+        n = n_; count = cnt; nl = std::max<size_t>(1, ilog2(n)); store.resize(cnt); off.assign(nl, 0);
+        size_t o = 0; for (size_t k = 0; k < nl; k++) { off[k] = o; o += n >> k; }
+        for (auto &s : store) s.alloc(o);
+    }
+    Fr *left(int i, size_t k) { return store[i].p + off[k]; }
+    Fr *right(int i, size_t k) { return store[i].p + off[k] + (n >> (k + 1)); }
+    Fr *input(int i) { return store[i].p; }                   // layer 0: the hashed vector itself, left half then right half
+    void build(DevCtx &c) {                                   // ProductCircuit::new: compute_layer, all circuits of the batch per launch
+        for (size_t k = 1; k < nl; k++) {
+            LayerList L; L.n = count;
+            for (int i = 0; i < count; i++) { L.in_left[i] = left(i, k - 1); L.in_right[i] = right(i, k - 1); L.out_left[i] = left(i, k); L.out_right[i] = right(i, k); }
+            dev_prod_layer(c, L, n >> (k + 1));
+        }
+    }
+};
+struct DotpTables { Fr *l[6], *r[6], *w[6]; size_t len = 0; int n = 0; };
+
+// ProductCircuitEvalProofBatched::prove.  evals: the circuits' outputs (already known to the caller).  The tables are folded in place.
+ProductCircuitEvalProofBatched pcbatch_prove(DevCtx &c, Circuits &C, const std::vector<Fr> &evals, DotpTables *D, const std::vector<Fr> &dotp_evals, Transcript &tr,
+                                             Fr *eq_buf, Fr *eq_scratch, Fr *partials, std::vector<Fr> &rand_out) {
+    const int np = C.count; const size_t nl = C.nl;
+    ProductCircuitEvalProofBatched pf; pf.layers.resize(nl);
+    std::vector<Fr> claims = evals, rand, rprod;
+    for (size_t li = 0; li < nl; li++) {
+        const size_t layer_id = nl - 1 - li, h = (size_t)1 << rand.size();       // elements per side in this layer
+        const bool with_dotp = layer_id == 0 && D && D->n;
+        if (with_dotp) { if (D->len != h) throw Error(OTTI_ERR_INTERNAL, "dot-product circuits do not match the input layer"); claims.insert(claims.end(), dotp_evals.begin(), dotp_evals.end()); }
+        dev_eq_evals(c, rand.data(), rand.size(), eq_buf, eq_scratch);           // poly_C_par = EqPolynomial(rand).evals()
+        std::vector<Fr> coeff = tr.challenge_vector("rand_coeffs_next_layer", claims.size());
+        Fr e = fr_zero(); for (size_t k = 0; k < claims.size(); k++) e = fr_add(e, fr_mul(claims[k], coeff[k]));
+        AbcList A; PtrList F; A.n = 0; F.n = 0;
+        for (int i = 0; i < np; i++) { A.A[A.n] = C.left(i, layer_id); A.B[A.n] = C.right(i, layer_id); A.C[A.n] = eq_buf; A.n++; F.p[F.n++] = C.left(i, layer_id); F.p[F.n++] = C.right(i, layer_id); }
+        F.p[F.n++] = eq_buf;
+        if (with_dotp) for (int i = 0; i < D->n; i++) { A.A[A.n] = D->l[i]; A.B[A.n] = D->r[i]; A.C[A.n] = D->w[i]; A.n++; F.p[F.n++] = D->l[i]; F.p[F.n++] = D->r[i]; F.p[F.n++] = D->w[i]; }
+        LayerProofBatched &L = pf.layers[li];
+        rprod.clear();
+        size_t len = h;
+        for (size_t j = 0; j < rand.size(); j++) {           // SumcheckInstanceProof::prove_cubic_batched
+            const size_t half = len / 2;
+            dev_abc_evals(c, A, half, partials, kSumSlot);
+            c.sync();
+            Fr c0 = fr_zero(), c2 = fr_zero(), c3 = fr_zero();
+            for (int k = 0; k < A.n; k++) {
+                const Fr *ev = &c.h_results[kSumSlot + 3 * k];
+                c0 = fr_add(c0, fr_mul(ev[0], coeff[k])); c2 = fr_add(c2, fr_mul(ev[1], coeff[k])); c3 = fr_add(c3, fr_mul(ev[2], coeff[k]));
+            }
+            Fr evals4[4] = {c0, fr_sub(e, c0), c2, c3}, poly[4];
+            unipoly_from_evals(poly, evals4, 4);
+            append_unipoly(tr, poly, 4);
+            const Fr r_j = tr.challenge_scalar("challenge_nextround");
+            rprod.push_back(r_j);
+            dev_fold_many(c, F, half, r_j);
+            e = unipoly_eval(poly, 4, r_j);
+            L.coeffs.push_back(poly[0]); L.coeffs.push_back(poly[2]); L.coeffs.push_back(poly[3]);      // UniPoly::compress
+            len = half;
+        }
+        // the tables' last elements: claims_prod (left, right per circuit; the eq table's is not sent), then the dot-product triples
+        PtrList pick; pick.n = 0;
+        for (int i = 0; i < np; i++) { pick.p[pick.n++] = C.left(i, layer_id); pick.p[pick.n++] = C.right(i, layer_id); }
+        if (with_dotp) for (int i = 0; i < D->n; i++) { pick.p[pick.n++] = D->l[i]; pick.p[pick.n++] = D->r[i]; pick.p[pick.n++] = D->w[i]; }
+        dev_pick0(c, pick, kSumSlot);
+        c.sync();
+        L.left.resize(np); L.right.resize(np);
+        for (int i = 0; i < np; i++) { L.left[i] = c.h_results[kSumSlot + 2 * i]; L.right[i] = c.h_results[kSumSlot + 2 * i + 1]; tr.append_scalar("claim_prod_left", L.left[i]); tr.append_scalar("claim_prod_right", L.right[i]); }
+        if (with_dotp) for (int i = 0; i < D->n; i++) {
+            const Fr *t = &c.h_results[kSumSlot + 2 * np + 3 * i];
+            pf.dotp_left.push_back(t[0]); pf.dotp_right.push_back(t[1]); pf.dotp_weight.push_back(t[2]);
+            tr.append_scalar("claim_dotp_left", t[0]); tr.append_scalar("claim_dotp_right", t[1]); tr.append_scalar("claim_dotp_weight", t[2]);
+        }
+        const Fr r_layer = tr.challenge_scalar("challenge_r_layer");
+        claims.resize(np);
+        for (int i = 0; i < np; i++) claims[i] = fr_add(L.left[i], fr_mul(r_layer, fr_sub(L.right[i], L.left[i])));
+        std::vector<Fr> ext = {r_layer}; ext.insert(ext.end(), rprod.begin(), rprod.end()); rand = ext;
+    }
+    rand_out = rand;
+    return pf;
+}
+
+// PolyEvalProof::prove(poly, None, r, Zr, None, gens, ..) on a polynomial resident in HBM
+DotProductProofLog polyeval_prove_plain(DevCtx &c, Gens &gens, const PcSet &s, const Fr *Z, const std::vector<Fr> &r, const Fr &Zr, Transcript &tr, RandomTape &tape) {
+    if (r.size() != s.num_vars) throw Error(OTTI_ERR_INTERNAL, "evaluation point of the wrong length");
+    tr.append_protocol_name("polynomial evaluation proof");
+    const size_t lv = s.num_vars / 2, lgR = ilog2(s.R);
+    DevBuf<Fr> Lv(s.L), Rv(s.R), LZ(s.R), a(s.R), sbuf(s.R), b2(s.R), s2(s.R), rows(2 * s.R), extras(4 * (lgR + 1)), eqs(5 * 4096), bound(64 * s.R);
+    dev_eq_evals(c, r.data(), lv, Lv.p, eqs.p);
+    dev_eq_evals(c, r.data() + lv, s.num_vars - lv, Rv.p, eqs.p);
+    dev_poly_bound(c, Z, s.L, s.R, Lv.p, LZ.p, bound.p);
+    const PcView pv = {s.h_n, s.g1, s.h1, s.R};
+    const PeBufs pb = {LZ.p, Rv.p, a.p, sbuf.p, b2.p, s2.p, rows.p, extras.p};
+    CPoint Cy;
+    DotProductProofLog pf = dplog_prove_device(c, *gens.dev, gens, pv, pb, fr_zero(), &Zr, fr_zero(), Cy, tr, tape);
+    c.sync();                                                  // the buffers above go out of scope
+    return pf;
+}
+}  // namespace
+
+// ================================================================================================ SNARK::prove
+std::vector<uint8_t> snark_prove_gpu(Instance &I, CompComm &comm, const uint8_t *vars32, size_t nvars, const std::vector<Fr> &inputs, SnarkGens &g,
+                                     const void *tlabel, size_t tlabel_len, const uint8_t *seed32, SnarkTimings *tm) {
+    DevCtx &c = DevCtx::get();
+    SpinPool::Session pool_session;
+    if (!comm.dec) throw Error(OTTI_ERR_BAD_ARG, "this computation commitment carries no decommitment (it was parsed from bytes): SNARK::prove needs the one SNARK::encode returned");
+    if (I.num_cons != comm.num_cons || I.num_vars != comm.num_vars || I.num_inputs != comm.num_inputs) throw Error(OTTI_ERR_BAD_ARG, "commitment belongs to another instance");
+    const double t_start = now_ms(); SnarkTimings T{}; double t0;
+    ensure_gens_device(*g.eval);
+    const DeviceDecomm &d = *comm.dec; const size_t N = d.N, M = d.M, H = N / 2;
+    DeviceWitness wit(I, vars32, nvars, inputs);
+    Transcript tr(tlabel, tlabel_len);
+    RandomTape tape(seed32);
+    SnarkProof S;
+    tr.append_protocol_name("Spartan SNARK proof");
+    snark_append_comm(tr, comm);
+    { ProveTimings pt{}; r1cs_prove_device(I, wit, *g.sat, tr, tape, S.r1cs, pt, nullptr); for (int k = 0; k < 6; k++) T.ms[k] = pt.ms[k]; }
+    instance_evaluate_gpu(I, S.r1cs.rx, S.r1cs.ry, S.inst_evals);                // inst.evaluate(rx, ry)
+    tr.append_scalar("Ar_claim", S.inst_evals[0]); tr.append_scalar("Br_claim", S.inst_evals[1]); tr.append_scalar("Cr_claim", S.inst_evals[2]);
+
+    // ---- R1CSEvalProof::prove -> SparseMatPolyEvalProof::prove
+    EvalProof &E = S.eval;
+    t0 = now_ms();
+    tr.append_protocol_name("Sparse polynomial evaluation proof");
+    const std::vector<Fr> &rx = S.r1cs.rx, &ry = S.r1cs.ry;
+    const size_t nm = std::max(rx.size(), ry.size());
+    if (((size_t)1 << nm) != M) throw Error(OTTI_ERR_INTERNAL, "memory size does not match the evaluation point");
+    std::vector<Fr> rxe(nm - rx.size(), fr_zero()), rye(nm - ry.size(), fr_zero());     // equalize: zeros in FRONT of the shorter point
+    rxe.insert(rxe.end(), rx.begin(), rx.end()); rye.insert(rye.end(), ry.begin(), ry.end());
+    DevBuf<Fr> mem_rx(M), mem_ry(M), eqs(5 * 4096), derefs((size_t)8 * N), partials((size_t)3 * 2048 + 64);                  // 3 sums x at most 2048 workgroups per launch (k_snark.hip many_grid)
+    dev_eq_evals(c, rxe.data(), nm, mem_rx.p, eqs.p);
+    dev_eq_evals(c, rye.data(), nm, mem_ry.p, eqs.p);
+    // dense.deref: row_ops_val[k][i] = mem_rx[row_addr[k][i]], col likewise; comb = merge(rows, cols), zero-padded to 8 N
+    OTTI_HIP(hipMemsetAsync(derefs.p + 6 * N, 0, 2 * N * sizeof(Fr), c.stream));
+    auto drow = [&](int k) { return derefs.p + (size_t)k * N; };
+    auto dcol = [&](int k) { return derefs.p + (size_t)(3 + k) * N; };
+    for (int k = 0; k < 3; k++) { dev_gather(c, mem_rx.p, d.row_addr[k].p, drow(k), N); dev_gather(c, mem_ry.p, d.col_addr[k].p, dcol(k), N); }
+    E.comm_derefs = commit_poly(c, *g.eval, derefs.p, g.derefs);
+    tr.append_message("derefs_commitment", "begin_derefs_commitment", 23);
+    append_poly_commitment(tr, "comm_poly_row_col_ops_val", E.comm_derefs);
+    tr.append_message("derefs_commitment", "end_derefs_commitment", 21);
+    T.ms[6] = now_ms() - t0;
+
+    t0 = now_ms();
+    const std::vector<Fr> r_mem_check = tr.challenge_vector("challenge_r_hash", 2);
+    // PolyEvalNetwork::new: hash layers -> product circuits.  ops: row reads A,B,C; row writes; col reads; col writes.  mem: row init, row audit, col init, col audit.
+    Circuits ops, mem;
+    ops.init(12, N); mem.init(4, M);
+    for (int k = 0; k < 3; k++) {
+        dev_hash_ops(c, d.part(0, k), drow(k), d.part(1, k), ops.input(k), ops.input(3 + k), N, r_mem_check[0], r_mem_check[1]);
+        dev_hash_ops(c, d.part(2, k), dcol(k), d.part(3, k), ops.input(6 + k), ops.input(9 + k), N, r_mem_check[0], r_mem_check[1]);
+    }
+    dev_hash_mem(c, mem_rx.p, d.comb_mem.p, mem.input(0), mem.input(1), M, r_mem_check[0], r_mem_check[1]);
+    dev_hash_mem(c, mem_ry.p, d.comb_mem.p + M, mem.input(2), mem.input(3), M, r_mem_check[0], r_mem_check[1]);
+    ops.build(c); mem.build(c);
+    // the dot-product circuits: halves of (row_ops_val, col_ops_val, val) per matrix — copies, because the sum-check folds them in place
+    DevBuf<Fr> dotp((size_t)9 * N);
+    DotpTables D; D.len = H; D.n = 6;
+    for (int k = 0; k < 3; k++) {
+        Fr *base = dotp.p + (size_t)3 * k * N;
+        OTTI_HIP(hipMemcpyAsync(base, drow(k), N * sizeof(Fr), hipMemcpyDeviceToDevice, c.stream));
+        OTTI_HIP(hipMemcpyAsync(base + N, dcol(k), N * sizeof(Fr), hipMemcpyDeviceToDevice, c.stream));
+        OTTI_HIP(hipMemcpyAsync(base + 2 * N, d.part(4, k), N * sizeof(Fr), hipMemcpyDeviceToDevice, c.stream));
+        for (int half = 0; half < 2; half++) { D.l[2 * k + half] = base + half * H; D.r[2 * k + half] = base + N + half * H; D.w[2 * k + half] = base + 2 * N + half * H; }
+    }
+    // PolyEvalNetworkProof::prove / ProductLayerProof::prove
+    tr.append_protocol_name("Sparse polynomial evaluation proof");
+    tr.append_protocol_name("Sparse polynomial product layer proof");
+    std::vector<Fr> ops_evals(12), mem_evals(4), dotp_evals(6);
+    {   // circuit outputs (left * right of the top layer) and the dot-product claims
+        PtrList pick; pick.n = 0;
+        for (int i = 0; i < 12; i++) { pick.p[pick.n++] = ops.left(i, ops.nl - 1); pick.p[pick.n++] = ops.right(i, ops.nl - 1); }
+        for (int i = 0; i < 4; i++) { pick.p[pick.n++] = mem.left(i, mem.nl - 1); pick.p[pick.n++] = mem.right(i, mem.nl - 1); }
+        dev_pick0(c, pick, kSumSlot);
+        AbcList A; A.n = 6; for (int i = 0; i < 6; i++) { A.A[i] = D.l[i]; A.B[i] = D.r[i]; A.C[i] = D.w[i]; }
+        dev_sum3(c, A, H, partials.p, kSumSlot + 40);
+        c.sync();
+        for (int i = 0; i < 12; i++) ops_evals[i] = fr_mul(c.h_results[kSumSlot + 2 * i], c.h_results[kSumSlot + 2 * i + 1]);
+        for (int i = 0; i < 4; i++) mem_evals[i] = fr_mul(c.h_results[kSumSlot + 24 + 2 * i], c.h_results[kSumSlot + 24 + 2 * i + 1]);
+        for (int i = 0; i < 6; i++) dotp_evals[i] = c.h_results[kSumSlot + 40 + i];
+    }
+    E.eval_row.init = mem_evals[0]; E.eval_row.audit = mem_evals[1]; E.eval_col.init = mem_evals[2]; E.eval_col.audit = mem_evals[3];
+    for (int k = 0; k < 3; k++) { E.eval_row.read[k] = ops_evals[k]; E.eval_row.write[k] = ops_evals[3 + k]; E.eval_col.read[k] = ops_evals[6 + k]; E.eval_col.write[k] = ops_evals[9 + k]; }
+    for (int side = 0; side < 2; side++) {
+        const Evals4 &e = side ? E.eval_col : E.eval_row;
+        tr.append_scalar(side ? "claim_col_eval_init" : "claim_row_eval_init", e.init);
+        tr.append_scalars(side ? "claim_col_eval_read" : "claim_row_eval_read", e.read, 3);
+        tr.append_scalars(side ? "claim_col_eval_write" : "claim_row_eval_write", e.write, 3);
+        tr.append_scalar(side ? "claim_col_eval_audit" : "claim_row_eval_audit", e.audit);
+    }
+    for (int k = 0; k < 3; k++) {
+        E.dotp_left[k] = dotp_evals[2 * k]; E.dotp_right[k] = dotp_evals[2 * k + 1];
+        tr.append_scalar("claim_eval_dotp_left", E.dotp_left[k]); tr.append_scalar("claim_eval_dotp_right", E.dotp_right[k]);
+        if (!fr_eq(fr_add(E.dotp_left[k], E.dotp_right[k]), S.inst_evals[k])) throw Error(OTTI_ERR_INTERNAL, "sparse polynomial evaluation does not match its dot-product circuits");
+    }
+    std::vector<Fr> rand_ops, rand_mem;
+    {
+        DevBuf<Fr> eq_buf(std::max(H, M / 2));
+        E.proof_ops = pcbatch_prove(c, ops, ops_evals, &D, dotp_evals, tr, eq_buf.p, eqs.p, partials.p, rand_ops);
+        E.proof_mem = pcbatch_prove(c, mem, mem_evals, nullptr, {}, tr, eq_buf.p, eqs.p, partials.p, rand_mem);
+    }
+    T.ms[7] = now_ms() - t0;
+
+    // ---- HashLayerProof::prove((rand_mem, rand_ops))
+    t0 = now_ms();
+    tr.append_protocol_name("Sparse polynomial hash layer proof");
+    {   // evaluations at rand_ops of the six dereferenced vectors and the fifteen committed ones, at rand_mem of the two audit vectors
+        DevBuf<Fr> Eo(N), Em(M);
+        dev_eq_evals(c, rand_ops.data(), rand_ops.size(), Eo.p, eqs.p);
+        dev_eq_evals(c, rand_mem.data(), rand_mem.size(), Em.p, eqs.p);
+        PtrList Lo; Lo.n = 0;
+        for (int k = 0; k < 3; k++) Lo.p[Lo.n++] = drow(k);
+        for (int k = 0; k < 3; k++) Lo.p[Lo.n++] = dcol(k);
+        for (int p = 0; p < 5; p++) for (int k = 0; k < 3; k++) Lo.p[Lo.n++] = d.part(p, k);
+        dev_dot_many(c, Eo.p, Lo, N, partials.p, kSumSlot);
+        c.sync();
+        for (int k = 0; k < 3; k++) {
+            E.h_deref_row[k] = c.h_results[kSumSlot + k]; E.h_deref_col[k] = c.h_results[kSumSlot + 3 + k];
+            E.h_row_addr[k] = c.h_results[kSumSlot + 6 + k]; E.h_row_read_ts[k] = c.h_results[kSumSlot + 9 + k];
+            E.h_col_addr[k] = c.h_results[kSumSlot + 12 + k]; E.h_col_read_ts[k] = c.h_results[kSumSlot + 15 + k]; E.h_val[k] = c.h_results[kSumSlot + 18 + k];
+        }
+        PtrList Lm; Lm.n = 2; Lm.p[0] = d.comb_mem.p; Lm.p[1] = d.comb_mem.p + M;
+        dev_dot_many(c, Em.p, Lm, M, partials.p, kSumSlot);
+        c.sync();
+        E.h_row_audit = c.h_results[kSumSlot]; E.h_col_audit = c.h_results[kSumSlot + 1];
+    }
+    auto joint = [&](std::vector<Fr> ev, const char *label_evals, const char *label_ch, const char *label_joint, const std::vector<Fr> &rand, std::vector<Fr> &r_joint) {
+        tr.append_scalars(label_evals, ev.data(), ev.size());
+        std::vector<Fr> ch = tr.challenge_vector(label_ch, ilog2(ev.size()));
+        const Fr j = reduce_evals(ev, ch);
+        r_joint = ch; r_joint.insert(r_joint.end(), rand.begin(), rand.end());
+        tr.append_scalar(label_joint, j);
+        return j;
+    };
+    {   // DerefsEvalProof::prove
+        tr.append_protocol_name("Derefs evaluation proof");
+        std::vector<Fr> ev(8, fr_zero()), rj;
+        for (int k = 0; k < 3; k++) { ev[k] = E.h_deref_row[k]; ev[3 + k] = E.h_deref_col[k]; }
+        const Fr j = joint(ev, "evals_ops_val", "challenge_combine_n_to_one", "joint_claim_eval", rand_ops, rj);
+        E.pe_derefs = polyeval_prove_plain(c, *g.eval, g.derefs, derefs.p, rj, j, tr, tape);
+    }
+    {
+        std::vector<Fr> ev(16, fr_zero()), rj;
+        for (int k = 0; k < 3; k++) { ev[k] = E.h_row_addr[k]; ev[3 + k] = E.h_row_read_ts[k]; ev[6 + k] = E.h_col_addr[k]; ev[9 + k] = E.h_col_read_ts[k]; ev[12 + k] = E.h_val[k]; }
+        const Fr j = joint(ev, "claim_evals_ops", "challenge_combine_n_to_one", "joint_claim_eval_ops", rand_ops, rj);
+        E.pe_ops = polyeval_prove_plain(c, *g.eval, g.ops, d.comb_ops.p, rj, j, tr, tape);
+    }
+    {
+        std::vector<Fr> rj;
+        const Fr j = joint({E.h_row_audit, E.h_col_audit}, "claim_evals_mem", "challenge_combine_two_to_one", "joint_claim_eval_mem", rand_mem, rj);
+        E.pe_mem = polyeval_prove_plain(c, *g.eval, g.mem, d.comb_mem.p, rj, j, tr, tape);
+    }
+    T.ms[8] = now_ms() - t0;
+    std::vector<uint8_t> out = S.serialize();
+    T.ms[9] = now_ms() - t_start;
+    OTTI_HIP(hipStreamSynchronize(c.stream));
+    KStats::get().flush();
+    if (tm) *tm = T;
+    return out;
+}
+
+}  // namespace otti

@@ -37,6 +37,7 @@ void build_csr(Csr &out, const std::vector<uint32_t> &major, const std::vector<u
 
 struct Instance {
     size_t num_cons = 0, num_vars = 0, num_inputs = 0;      // padded cons / vars (powers of two)
+    size_t given_cons = 0;                                  // num_cons as passed to Instance::new (SNARK mode: upstream pads 0 / 1 constraints with explicit entries)
     SparseMat M[3];                                         // A, B, C
     std::shared_ptr<DeviceInstance> dev;                    // uploaded lazily on the first GPU prove
     std::shared_ptr<DeviceShard> shard;                     // uploaded lazily on the first sharded prove
@@ -66,6 +67,8 @@ struct Gens {
     Pt commit_generic(const Fr *v, size_t n, const Fr &blind, const GensView &g) const;   // host MSM (verifier)
 };
 std::unique_ptr<Gens> gens_new(size_t num_cons, size_t num_vars, size_t num_inputs);
+// a DotProductProofGens inside a generator stream: gens_n.G = P[0 .. R), gens_n.h = P[h_n], gens_1 = (P[g1], h = P[h1])
+struct PcView { uint32_t h_n, g1, h1; size_t R; };
 std::vector<Pt> derive_generators(const char *label, size_t count);      // MultiCommitGens::new stream
 
 std::vector<Fr> eq_evals_host(const Fr *r, size_t ell);                  // EqPolynomial::evals

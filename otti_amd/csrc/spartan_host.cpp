@@ -1,6 +1,7 @@
 // Host-side objects of the proving path: instance building, generator derivation, proof (de)serialisation, sigma protocols,
 // verifier, synthetic instances.  See spartan.h for what each piece replaces upstream.
 #include "spartan.h"
+#include "snark.h"
 #include "pool.h"
 #include <algorithm>
 #include <numeric>
@@ -25,7 +26,7 @@ std::unique_ptr<Instance> instance_new(size_t num_cons, size_t num_vars, size_t 
     size_t ncp = num_cons < 2 ? 2 : next_pow2(num_cons);
     if (ncp > ((size_t)1 << 30) || nvp > ((size_t)1 << 30)) throw Error(OTTI_ERR_BAD_ARG, "instance too large for 32-bit indices");
     auto I = std::make_unique<Instance>();
-    I->num_cons = ncp; I->num_vars = nvp; I->num_inputs = num_inputs;
+    I->num_cons = ncp; I->num_vars = nvp; I->num_inputs = num_inputs; I->given_cons = num_cons;
     const otti_entry *src[3] = {A, B, C}; size_t cnt[3] = {nA, nB, nC};
     for (int k = 0; k < 3; k++) {
         SparseMat &m = I->M[k];
@@ -351,8 +352,7 @@ NizkProof NizkProof::parse(const uint8_t *p, size_t n) {
 }
 
 // ================================================================================================ verifier
-namespace {
-struct VerifyFail { int code; };
+// (external linkage: snark_host.cpp builds SNARK::verify from the same pieces; declared in snark.h)
 Pt dec(const CPoint &c) { Pt p; if (!pt_decode(p, c.b)) throw VerifyFail{OTTI_ERR_VERIFY_DECOMPRESS}; return p; }
 void require(bool ok) { if (!ok) throw VerifyFail{OTTI_ERR_VERIFY_INTERNAL}; }
 Pt commit_scalar_pt(const Gens &g, const GensView &g1, const Fr &x, const Fr &blind) { return g.commit_generic(&x, 1, blind, g1); }
@@ -454,7 +454,7 @@ CPoint sumcheck_verify(const ZKSumcheckProof &pf, const CPoint &comm_claim, size
 }
 // BulletReductionProof::verify
 void bullet_verify(const DotProductProofLog &pf, size_t n, const Fr *a, Transcript &tr, const Pt &Gamma, const Gens &g, Pt &g_hat,
-                   Pt &Gamma_hat, Fr &a_hat) {
+                   Pt &Gamma_hat, Fr &a_hat) {                                    // gens_n.G = the first n points of g's stream
     size_t lg = pf.L_vec.size();
     require(pf.R_vec.size() == lg && lg < 32 && n == ((size_t)1 << lg));
     std::vector<Fr> ch(lg), chi(lg);
@@ -464,8 +464,7 @@ void bullet_verify(const DotProductProofLog &pf, size_t n, const Fr *a, Transcri
     for (size_t i = 0; i < lg; i++) { ch[i] = fr_sqr(ch[i]); chi[i] = fr_sqr(chi[i]); }
     std::vector<Fr> s(n); s[0] = allinv;
     for (size_t i = 1; i < n; i++) { size_t lg_i = ilog2(i + 1) - 1; size_t k = (size_t)1 << lg_i; s[i] = fr_mul(s[i - k], ch[(lg - 1) - lg_i]); }
-    std::vector<Pt> G(n); for (size_t i = 0; i < n; i++) G[i] = g.P[g.pc_n.G[i]];
-    g_hat = host_msm_wide(s.data(), G.data(), n);
+    g_hat = host_msm_wide(s.data(), g.P.data(), n);
     a_hat = fr_zero(); for (size_t i = 0; i < n; i++) a_hat = fr_add(a_hat, fr_mul(a[i], s[i]));
     std::vector<Fr> sc; std::vector<Pt> pts;
     for (size_t i = 0; i < lg; i++) { sc.push_back(ch[i]); pts.push_back(dec(pf.L_vec[i])); }
@@ -473,8 +472,8 @@ void bullet_verify(const DotProductProofLog &pf, size_t n, const Fr *a, Transcri
     sc.push_back(fr_one()); pts.push_back(Gamma);
     Gamma_hat = host_msm(sc.data(), pts.data(), sc.size());
 }
-void dotproductlog_verify(const DotProductProofLog &pf, size_t n, const Gens &g, Transcript &tr, const Fr *a, const CPoint &Cx, const CPoint &Cy) {
-    require(g.pc_n.G.size() == n);
+void dotproductlog_verify(const DotProductProofLog &pf, size_t n, const Gens &g, const PcView &v, Transcript &tr, const Fr *a, const CPoint &Cx, const CPoint &Cy) {
+    require(v.R == n && g.P.size() >= n + 2);
     tr.append_protocol_name("dot product proof (log)");
     tr.append_point("Cx", Cx.b); tr.append_point("Cy", Cy.b);
     Pt Gamma = pt_add(dec(Cx), dec(Cy)), g_hat, Gamma_hat; Fr a_hat;
@@ -482,30 +481,23 @@ void dotproductlog_verify(const DotProductProofLog &pf, size_t n, const Gens &g,
     tr.append_point("delta", pf.delta.b); tr.append_point("beta", pf.beta.b);
     Fr c = tr.challenge_scalar("c");
     Pt lhs = pt_add(host_scalarmul(pt_add(host_scalarmul(Gamma_hat, c), dec(pf.beta)), a_hat), dec(pf.delta));
-    Pt rhs = pt_add(host_scalarmul(pt_add(g_hat, host_scalarmul(g.P[g.pc_1.G[0]], a_hat)), pf.z1), host_scalarmul(g.P[g.pc_1.h], pf.z2));
+    Pt rhs = pt_add(host_scalarmul(pt_add(g_hat, host_scalarmul(g.P[v.g1], a_hat)), pf.z1), host_scalarmul(g.P[v.h1], pf.z2));
     require(pt_eq(lhs, rhs));
 }
-}  // namespace
-
-int nizk_verify(const Instance &I, const std::vector<Fr> &inputs, const Gens &g, const void *tlabel, size_t tlabel_len, const uint8_t *proof,
-                size_t proof_len, const Fr *inst_evals_opt) {
+// R1CSProof::verify: `tr` already carries the caller's protocol name (NIZK / SNARK); returns the challenges the transcript produced
+int r1cs_verify_host(const NizkProof &P, size_t N, size_t V, const std::vector<Fr> &inputs, const Fr inst_evals[3], const Gens &g, Transcript &tr,
+                     std::vector<Fr> &rx, std::vector<Fr> &ry) {
     try {
-        if (inputs.size() != I.num_inputs) return OTTI_ERR_INVALID_NUM_INPUTS;
-        NizkProof P = NizkProof::parse(proof, proof_len);
-        size_t N = I.num_cons, V = I.num_vars, nrx = ilog2(N), nry = ilog2(2 * V);
+        const size_t nrx = ilog2(N), nry = ilog2(2 * V);
         size_t ell = ilog2(V), Lsz = (size_t)1 << (ell / 2), Rsz = (size_t)1 << (ell - ell / 2);
-        require(g.num_vars_padded == V && P.rx.size() == nrx && P.ry.size() == nry && P.comm_vars.size() == Lsz);
-        Transcript tr(tlabel, tlabel_len);
-        tr.append_protocol_name("Spartan NIZK proof");
-        Fr inst_evals[3];
-        if (inst_evals_opt) { inst_evals[0] = inst_evals_opt[0]; inst_evals[1] = inst_evals_opt[1]; inst_evals[2] = inst_evals_opt[2]; }
-        else I.evaluate(P.rx, P.ry, inst_evals);
+        require(g.num_vars_padded == V && P.comm_vars.size() == Lsz);
+        const Fr one = fr_one();
         // R1CSProof::verify
         tr.append_protocol_name("R1CS proof");
         tr.append_message("poly_commitment", "poly_commitment_begin", 21);
         for (auto &c : P.comm_vars) tr.append_point("poly_commitment_share", c.b);
         tr.append_message("poly_commitment", "poly_commitment_end", 19);
-        std::vector<Fr> tau = tr.challenge_vector("challenge_tau", nrx), rx, ry;
+        std::vector<Fr> tau = tr.challenge_vector("challenge_tau", nrx);
         CPoint claim_phase1; pt_encode(claim_phase1.b, commit_scalar_pt(g, g.sc_1, fr_zero(), fr_zero()));
         Deferred later;                                                   // P, g and the CPoints it captures live until run_deferred below
         SpinPool::Session pool_session;
@@ -515,7 +507,7 @@ int nizk_verify(const Instance &I, const std::vector<Fr> &inputs, const Gens &g,
         product_verify(P.prod, g, tr, cAz, cBz, cPr, later);
         tr.append_point("comm_Az_claim", cAz.b); tr.append_point("comm_Bz_claim", cBz.b);
         tr.append_point("comm_Cz_claim", cCz.b); tr.append_point("comm_prod_Az_Bz_claims", cPr.b);
-        Fr taus_bound = fr_one(), one = fr_one();
+        Fr taus_bound = fr_one();
         for (size_t i = 0; i < nrx; i++) taus_bound = fr_mul(taus_bound, fr_add(fr_mul(rx[i], tau[i]), fr_mul(fr_sub(one, rx[i]), fr_sub(one, tau[i]))));
         CPoint expected1; pt_encode(expected1.b, host_scalarmul(pt_sub(dec(cPr), dec(cCz)), taus_bound));
         equality_verify(P.eq1, g, tr, expected1, comm_post1, later);
@@ -540,7 +532,8 @@ int nizk_verify(const Instance &I, const std::vector<Fr> &inputs, const Gens &g,
             }
             CPoint C_LZ; pt_encode(C_LZ.b, host_msm_wide(Lv.data(), Cs.data(), Lsz));
             require(P.polyeval.L_vec.size() == ilog2(Rsz));
-            dotproductlog_verify(P.polyeval, Rsz, g, tr, Rv.data(), C_LZ, P.comm_vars_at_ry);
+            const PcView pv = {g.pc_n.h, g.pc_1.G[0], g.pc_1.h, Rsz};
+            dotproductlog_verify(P.polyeval, Rsz, g, pv, tr, Rv.data(), C_LZ, P.comm_vars_at_ry);
         }
         // SparsePolynomial over (1, inputs) evaluated at ry[1..], MSB-first index bits
         Fr poly_input_eval = fr_zero();
@@ -555,11 +548,29 @@ int nizk_verify(const Instance &I, const std::vector<Fr> &inputs, const Gens &g,
         CPoint expected2; pt_encode(expected2.b, host_scalarmul(comm_eval_Z, comb));
         equality_verify(P.eq2, g, tr, expected2, comm_post2, later);
         run_deferred(later);
-        for (size_t i = 0; i < nrx; i++) require(fr_eq(rx[i], P.rx[i]));
-        for (size_t i = 0; i < nry; i++) require(fr_eq(ry[i], P.ry[i]));
         return OTTI_OK;
     } catch (const VerifyFail &f) { return f.code; }
     catch (const Error &e) { return e.code; }
+}
+
+int nizk_verify(const Instance &I, const std::vector<Fr> &inputs, const Gens &g, const void *tlabel, size_t tlabel_len, const uint8_t *proof,
+                size_t proof_len, const Fr *inst_evals_opt) {
+    try {
+        if (inputs.size() != I.num_inputs) return OTTI_ERR_INVALID_NUM_INPUTS;
+        NizkProof P = NizkProof::parse(proof, proof_len);
+        size_t N = I.num_cons, V = I.num_vars, nrx = ilog2(N), nry = ilog2(2 * V);
+        if (P.rx.size() != nrx || P.ry.size() != nry) return OTTI_ERR_VERIFY_INTERNAL;
+        Transcript tr(tlabel, tlabel_len);
+        tr.append_protocol_name("Spartan NIZK proof");
+        Fr inst_evals[3];
+        if (inst_evals_opt) { inst_evals[0] = inst_evals_opt[0]; inst_evals[1] = inst_evals_opt[1]; inst_evals[2] = inst_evals_opt[2]; }
+        else I.evaluate(P.rx, P.ry, inst_evals);
+        std::vector<Fr> rx, ry;
+        if (int rc = r1cs_verify_host(P, N, V, inputs, inst_evals, g, tr, rx, ry)) return rc;
+        for (size_t i = 0; i < nrx; i++) if (!fr_eq(rx[i], P.rx[i])) return OTTI_ERR_VERIFY_INTERNAL;
+        for (size_t i = 0; i < nry; i++) if (!fr_eq(ry[i], P.ry[i])) return OTTI_ERR_VERIFY_INTERNAL;
+        return OTTI_OK;
+    } catch (const Error &e) { return e.code; }
 }
 
 // ================================================================================================ synthetic R1CS

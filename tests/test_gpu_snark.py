@@ -1,0 +1,56 @@
+"""SNARK mode on the GPU against the CPU oracle (oracle/snark.c): the computation commitment (SNARK::encode) and the whole proof
+(R1CSProof + R1CSEvalProof) must be byte-identical for the same instance, witness, label and random-tape seed; both verifiers accept."""
+import numpy as np
+import pytest
+
+import otti_amd as oa
+import orc
+
+pytestmark = pytest.mark.gpu
+SEED, LABEL = b"\x2a" * 32, b"snark_example"
+
+
+def _case(n, ni, kind, seed=7):
+    r = (oa.synth_r1cs if kind == "uniform" else oa.synth_r1cs_compiler_like)(n, ni, seed)
+    nz = max(r["A"].size, r["B"].size, r["C"].size)
+    return r, nz
+
+
+@pytest.mark.parametrize("n,ni,kind", [(2, 0, "uniform"), (16, 3, "uniform"), (64, 10, "uniform"), (200, 4, "compiler"), (1 << 10, 10, "uniform"),
+                                       (1 << 12, 10, "compiler"), (1 << 14, 10, "uniform")])
+def test_snark_commitment_and_proof_bytes_identical_to_oracle(n, ni, kind):
+    r, nz = _case(n, ni, kind)
+    oi = orc.OInstance(r["num_cons"], r["num_vars"], r["num_inputs"], r["A"], r["B"], r["C"])
+    og = orc.OSnarkGens(r["num_cons"], r["num_vars"], r["num_inputs"], nz)
+    oc = orc.OSnarkComm.encode(oi, og)
+    want, _ = orc.snark_prove(oi, oc, r["vars"], r["inputs"], og, LABEL, SEED)
+
+    inst = oa.Instance.new(r["num_cons"], r["num_vars"], r["num_inputs"], r["A"], r["B"], r["C"])
+    gens = oa.SNARKGens.new(r["num_cons"], r["num_vars"], r["num_inputs"], nz)
+    comm = oa.ComputationCommitment.encode(inst, gens)
+    assert comm.bytes == oc.bytes, "computation commitment differs"
+    inputs = oa.InputsAssignment.new(r["inputs"])
+    proof = oa.SNARK.prove(inst, comm, oa.VarsAssignment.new(r["vars"]), inputs, gens, LABEL, SEED)
+    assert len(proof.bytes) == len(want)
+    assert proof.bytes == want, "SNARK proof differs from the oracle's"
+    verifier_comm = oa.ComputationCommitment.from_bytes(comm.bytes)        # the verifier holds the commitment only
+    proof.verify(verifier_comm, inputs, gens, LABEL)
+    assert orc.snark_verify(orc.OSnarkComm.parse(comm.bytes), r["inputs"], og, proof.bytes, LABEL) == 0
+    bad = bytearray(proof.bytes); bad[len(bad) // 3] ^= 1
+    with pytest.raises(oa.ProofVerifyError):
+        oa.SNARK(bytes(bad)).verify(verifier_comm, inputs, gens, LABEL)
+    with pytest.raises(oa.SpartanError):
+        oa.SNARK.prove(inst, verifier_comm, oa.VarsAssignment.new(r["vars"]), inputs, gens, LABEL, SEED)   # no decommitment in a parsed commitment
+
+
+def test_snark_proofs_repeat_and_differ_by_seed():
+    r, nz = _case(256, 5, "uniform")
+    inst = oa.Instance.new(r["num_cons"], r["num_vars"], r["num_inputs"], r["A"], r["B"], r["C"])
+    gens = oa.SNARKGens.new(r["num_cons"], r["num_vars"], r["num_inputs"], nz)
+    comm = oa.ComputationCommitment.encode(inst, gens)
+    v, i = oa.VarsAssignment.new(r["vars"]), oa.InputsAssignment.new(r["inputs"])
+    a = oa.SNARK.prove(inst, comm, v, i, gens, LABEL, SEED).bytes
+    assert a == oa.SNARK.prove(inst, comm, v, i, gens, LABEL, SEED).bytes
+    b = oa.SNARK.prove(inst, comm, v, i, gens, LABEL, b"\x07" * 32)
+    assert b.bytes != a
+    b.verify(comm, i, gens, LABEL)
