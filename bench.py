@@ -23,6 +23,8 @@ Extras in the same line (all measured in this run, none of them the headline):
                 per launch / average launch duration (HIP events on the library's stream over the timed region) against the HBM
                 peak; for the MSM classes additionally mixed point additions per second against the ALU roof measured in this run
   cpu_baseline  the CPU oracle (the reference Rust prover cannot be built here) on the same workload, host cores stated
+  snark         SNARK mode on the same workload: SNARK::encode once (untimed: preprocessing of the circuit), then SNARK::prove = the
+                headline's R1CSProof + R1CSEvalProof against the computation commitment; CPU oracle on a bounded 2^16 sample
   spzk_e2e      the path run.py actually executes: `spzk verify --nizk` on a zkInterface triple of the workload, one process
                 (parse + Instance::new + generators + device tables + prove + verify), next to the oracle's prove + verify
 Every timed proof is checked: identical bytes across steps (fixed seed), accepted by the verifier; rank 0 also compares a 2^12 proof
@@ -100,6 +102,7 @@ def main():
     ap.add_argument("--log2-constraints", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the one-shot `spzk verify --nizk` figure")
+    ap.add_argument("--no-snark", action="store_true", help="skip the SNARK-mode figure (SNARK::encode once, then SNARK::prove)")
     ap.add_argument("--dist", choices=("uniform", "compiler"), default="uniform", help="synthetic instance distribution (SURVEY 8d); the metric is quoted on 'uniform'")
     ap.add_argument("--cpu-log2", type=int, default=None, help="size of the CPU-baseline sample (default: same workload)")
     ap.add_argument("--replicas", action="store_true", help="N > 1: primary line = one independent proof per GPU (weak scaling) instead of one proof sharded over all GPUs")
@@ -383,6 +386,41 @@ def main():
                         "cpu_prove_plus_verify_ms": None if cpu_e2e_ms is None else round(cpu_e2e_ms, 1),
                         "cpu_note": "CPU oracle NIZK::prove + NIZK::verify of the same instance on the host cores above, instance already parsed (no zkif reader in the oracle)"}
 
+    # ---- SNARK mode (BASELINE.json's metric names it; run.py itself only invokes --nizk): SNARK::encode once, then SNARK::prove of the same workload
+    snark = None
+    if not args.no_snark and world == 1:
+        slabel = b"snark_example"
+        t0 = time.perf_counter()
+        sgens = oa.SNARKGens.new(r["num_cons"], r["num_vars"], r["num_inputs"], nnz // 3 if args.dist == "uniform" else int(max(r["A"].size, r["B"].size, r["C"].size)))
+        scomm = oa.ComputationCommitment.encode(inst, sgens)
+        t_encode = time.perf_counter() - t0
+        sp_list, sms = [], []
+        for k in range(4):                                      # the first one warms up (workspace allocation)
+            t0 = time.perf_counter(); spf = oa.SNARK.prove(inst, scomm, vars_, inputs, sgens, slabel, seed); sms.append(1e3 * (time.perf_counter() - t0)); sp_list.append(spf)
+        assert len({hashlib.sha256(p.bytes).hexdigest() for p in sp_list}) == 1
+        t0 = time.perf_counter(); sp_list[-1].verify(oa.ComputationCommitment.from_bytes(scomm.bytes), inputs, sgens, slabel); t_sverify = time.perf_counter() - t0
+        best = min(sms[1:])
+        # oracle parity at 2^12 and the CPU figure on a bounded sample (2^16: the oracle's SNARK prover is minutes at 2^20)
+        rs2 = oa.synth_r1cs(1 << 12, ni, 1)
+        si2 = oa.Instance.new(1 << 12, 1 << 12, ni, rs2["A"], rs2["B"], rs2["C"]); sg2 = oa.SNARKGens.new(1 << 12, 1 << 12, ni, 1 << 12)
+        sp2 = oa.SNARK.prove(si2, oa.ComputationCommitment.encode(si2, sg2), oa.VarsAssignment.new(rs2["vars"]), oa.InputsAssignment.new(rs2["inputs"]), sg2, slabel, seed)
+        oi2 = orc.OInstance(1 << 12, 1 << 12, ni, rs2["A"], rs2["B"], rs2["C"]); og2 = orc.OSnarkGens(1 << 12, 1 << 12, ni, 1 << 12)
+        op2, _ = orc.snark_prove(oi2, orc.OSnarkComm.encode(oi2, og2), rs2["vars"], rs2["inputs"], og2, slabel, seed)
+        cpu_s = None
+        if not args.no_cpu_baseline:
+            slg2 = min(lg, 16)
+            rs3 = gen(1 << slg2, ni, 1); nz3 = int(max(rs3["A"].size, rs3["B"].size, rs3["C"].size))
+            oi3 = orc.OInstance(rs3["num_cons"], rs3["num_vars"], rs3["num_inputs"], rs3["A"], rs3["B"], rs3["C"]); og3 = orc.OSnarkGens(rs3["num_cons"], rs3["num_vars"], rs3["num_inputs"], nz3)
+            oc3 = orc.OSnarkComm.encode(oi3, og3)
+            t0 = time.perf_counter(); orc.snark_prove(oi3, oc3, rs3["vars"], rs3["inputs"], og3, slabel, seed); ct3 = time.perf_counter() - t0
+            cpu_s = {"value": round((1 << slg2) / ct3, 1), "unit": "constraints/s", "cores": orc.lib.orc_get_threads(), "kind": "port",
+                     "sample": f"one SNARK::prove of the 2^{slg2} instance by the plain-C oracle, {ct3:.2f} s"}
+        snark = {"value": round(n / (best * 1e-3), 1), "unit": "constraints/s", "ms_per_proof": round(best, 3), "encode_ms": round(1e3 * t_encode, 1),
+                 "verify_ms": round(1e3 * t_sverify, 2), "proof_bytes": len(sp_list[-1].bytes), "commitment_bytes": len(scomm.bytes),
+                 "stage_ms": {k: round(v, 3) for k, v in sp_list[-1].stage_ms.items()}, "oracle_parity_2^12": sp2.bytes == op2, "cpu_baseline": cpu_s,
+                 "note": "SNARK::prove = R1CSProof (the headline's NIZK path) + R1CSEvalProof against the computation commitment made once by SNARK::encode (encode_ms includes building the "
+                         "second generator window table); host pointers for the witness (uploaded inside the call)"}
+
     out = {
         "metric": "R1CS constraints/sec proved (Spartan NIZK) at 2^%d" % lg, "value": round(value, 1), "unit": "constraints/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
@@ -397,6 +435,7 @@ def main():
         "roofline": roofline,
         "cpu_baseline": cpu_baseline,
         "in_flight": in_flight,
+        "snark": snark,
         "spzk_e2e": spzk_e2e,
         "stage_ms": {k: round(v / steps, 3) for k, v in stage_acc.items()},
         "kernel_ms_per_proof": {k: round(v[1], 3) for k, v in breakdown.items() if v[0]},

@@ -2,6 +2,8 @@
 //   spzk verify --nizk <X.zkif> <X.inp.zkif> <X.wit.zkif>      [REF /root/reference/run.py:58 (via cargo run), run.py:100 (binary)]
 // Reads the three zkInterface files, builds the R1CS instance, proves it on the MI355X, verifies the proof, prints
 // "Verification successful" plus stage runtimes [REF /root/reference/README.md:46-48], exit status 0 on success.
+// Without --nizk the same files go through SNARK mode (upstream spartan-zkinterface's default [RECALL]): SNARK::encode commits to the
+// circuit, SNARK::prove adds the R1CSEvalProof, SNARK::verify checks it against the commitment alone.
 // Additive options: --seed <hex32>, --proof-out <file>, --label <transcript label>, `spzk synth <n> <prefix>` to emit a
 // synthetic zkif triple.
 #include <stdio.h>
@@ -11,6 +13,7 @@
 #include <string>
 #include <vector>
 #include <chrono>
+#include <algorithm>
 #include "../../include/otti_spartan.h"
 
 static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -20,8 +23,8 @@ static int fail(const char *what, int rc) {
     return 1;
 }
 static int usage() {
-    fprintf(stderr, "usage: spzk verify --nizk <circuit.zkif> <inputs.inp.zkif> <witness.wit.zkif> [--seed HEX64] [--proof-out FILE] [--label STR]\n"
-                    "            (the reference's invocation: prove, then verify, in one process)\n"
+    fprintf(stderr, "usage: spzk verify [--nizk] <circuit.zkif> <inputs.inp.zkif> <witness.wit.zkif> [--seed HEX64] [--proof-out FILE] [--label STR]\n"
+                    "            (the reference's invocation: prove, then verify, in one process; without --nizk: SNARK mode)\n"
                     "       spzk prove  --nizk <circuit.zkif> <inputs.inp.zkif> <witness.wit.zkif> --proof-out FILE [--seed HEX64] [--label STR]\n"
                     "       spzk verify --nizk <circuit.zkif> <inputs.inp.zkif> --proof-in FILE [--label STR]\n"
                     "       spzk synth <num_constraints> <out_prefix> [num_inputs] [seed]\n");
@@ -45,17 +48,18 @@ int main(int argc, char **argv) {
     // one proof per process: the generator window table is built and used once, so a narrow window (small table, ~7 ms to build for
     // R = 1024) beats the wide one a long-lived prover process amortises (see prover.cpp device_window_bits); an explicit setting wins
     setenv("OTTI_MSM_WINDOW", "10", 0);
-    bool nizk = false; std::vector<const char *> files; const char *seed_hex = nullptr, *proof_out = nullptr, *proof_in = nullptr, *label = "nizk_example";
+    bool nizk = false, label_given = false; std::vector<const char *> files; const char *seed_hex = nullptr, *proof_out = nullptr, *proof_in = nullptr, *label = "nizk_example";
     for (int i = 2; i < argc; i++) {
         if (!strcmp(argv[i], "--nizk")) nizk = true;
         else if (!strcmp(argv[i], "--seed") && i + 1 < argc) seed_hex = argv[++i];
         else if (!strcmp(argv[i], "--proof-out") && i + 1 < argc) proof_out = argv[++i];
         else if (!strcmp(argv[i], "--proof-in") && i + 1 < argc) proof_in = argv[++i];
-        else if (!strcmp(argv[i], "--label") && i + 1 < argc) label = argv[++i];
+        else if (!strcmp(argv[i], "--label") && i + 1 < argc) { label = argv[++i]; label_given = true; }
         else files.push_back(argv[i]);
     }
-    if (!nizk) { fprintf(stderr, "spzk: only --nizk mode is implemented (SNARK mode is out of this path's scope)\n"); return 2; }
     const bool verify_only = proof_in != nullptr;
+    if (!nizk && (prove_only || verify_only)) { fprintf(stderr, "spzk: separate prove / verify processes are offered in --nizk mode only\n"); return 2; }
+    if (!nizk && !label_given) label = "snark_example";
     if (prove_only && (verify_only || !proof_out)) return usage();
     if (verify_only ? (files.size() != 2 && files.size() != 3) : files.size() != 3) return usage();
     uint8_t seed[32]; const uint8_t *seedp = nullptr;
@@ -72,6 +76,37 @@ int main(int argc, char **argv) {
     double t_load = now_ms() - t0; t0 = now_ms();
     otti_instance *inst = nullptr;
     rc = otti_instance_new(r->num_cons, r->num_vars, r->num_inputs, r->A, r->nA, r->B, r->nB, r->C, r->nC, &inst); if (rc) return fail("Instance::new", rc);
+    if (!nizk) {                                               // ---- SNARK mode: encode, prove, verify
+        const uint64_t nnz = std::max<uint64_t>({(uint64_t)r->nA, (uint64_t)r->nB, (uint64_t)r->nC});
+        otti_snark_gens *sg = nullptr; rc = otti_snark_gens_new(r->num_cons, r->num_vars, r->num_inputs, nnz, &sg); if (rc) return fail("SNARKGens::new", rc);
+        double t_setup = now_ms() - t0; t0 = now_ms();
+        otti_comp_comm *cc = nullptr; rc = otti_snark_encode(inst, sg, &cc); if (rc) return fail("SNARK::encode", rc);
+        double t_encode = now_ms() - t0; t0 = now_ms();
+        uint8_t *proof = nullptr; size_t proof_len = 0; double st[10] = {0};
+        rc = otti_snark_prove(inst, cc, r->vars32, r->nvars, r->inputs32, r->ninputs, sg, (const uint8_t *)label, strlen(label), seedp, OTTI_FLAG_GPU, &proof, &proof_len, st);
+        if (rc) return fail("SNARK::prove", rc);
+        double t_prove = now_ms() - t0; t0 = now_ms();
+        // the verifier's copy of the commitment: its bytes only
+        uint8_t *cb = nullptr; size_t cb_len = 0; rc = otti_comp_comm_bytes(cc, &cb, &cb_len); if (rc) return fail("commitment bytes", rc);
+        otti_comp_comm *vc = nullptr; rc = otti_comp_comm_from_bytes(cb, cb_len, &vc); if (rc) return fail("commitment parse", rc);
+        rc = otti_snark_verify(vc, r->inputs32, r->ninputs, sg, (const uint8_t *)label, strlen(label), proof, proof_len);
+        double t_verify = now_ms() - t0;
+        uint64_t nc, nv, ni; otti_instance_dims(inst, &nc, &nv, &ni);
+        printf("* instance: %llu constraints (padded %llu), %llu variables (padded %llu), %llu inputs, %llu non-zero entries in the largest matrix\n", (unsigned long long)r->num_cons,
+               (unsigned long long)nc, (unsigned long long)r->num_vars, (unsigned long long)nv, (unsigned long long)ni, (unsigned long long)nnz);
+        printf("* zkif_load %.3f ms\n* setup (Instance::new, SNARKGens::new) %.3f ms\n* SNARK::encode %.3f ms (computation commitment %zu bytes)\n", t_load, t_setup, t_encode, cb_len);
+        printf("* SNARK::prove %.3f ms\n  * polycommit %.3f ms\n  * multiply_vec %.3f ms\n  * prove_sc_phase_one %.3f ms\n  * eval_table_sparse %.3f ms\n  * prove_sc_phase_two %.3f ms\n"
+               "  * polyeval %.3f ms\n  * R1CSEvalProof: derefs commitment %.3f ms, product circuits %.3f ms, hash layer %.3f ms\n  * len_snark_proof %zu\n",
+               t_prove, st[0], st[1], st[2], st[3], st[4], st[5], st[6], st[7], st[8], proof_len);
+        printf("* SNARK::verify %.3f ms\n", t_verify);
+        int wrc = 0;
+        if (proof_out && !rc) { FILE *f = fopen(proof_out, "wb"); if (!f || fwrite(proof, 1, proof_len, f) != proof_len) { fprintf(stderr, "spzk: cannot write %s\n", proof_out); wrc = 1; } if (f) fclose(f); }
+        otti_buf_free(proof); otti_buf_free(cb); otti_comp_comm_free(vc); otti_comp_comm_free(cc); otti_snark_gens_free(sg); otti_instance_free(inst); otti_r1cs_free(r);
+        if (rc) { printf("Verification FAILED (%d)\n", rc); return 1; }
+        if (wrc) return 1;
+        printf("Verification successful\n");
+        return 0;
+    }
     otti_gens *gens = nullptr; rc = otti_gens_new(r->num_cons, r->num_vars, r->num_inputs, &gens); if (rc) return fail("NIZKGens::new", rc);
     if (!verify_only) { rc = otti_prepare_device(inst, gens); if (rc) return fail("device setup", rc); }
     double t_setup = now_ms() - t0; t0 = now_ms();

@@ -54,3 +54,21 @@ def test_snark_proofs_repeat_and_differ_by_seed():
     b = oa.SNARK.prove(inst, comm, v, i, gens, LABEL, b"\x07" * 32)
     assert b.bytes != a
     b.verify(comm, i, gens, LABEL)
+
+
+def test_spzk_without_nizk_runs_snark_mode(tmp_path):
+    """`spzk verify <three zkif files>` (no --nizk): SNARK::encode + prove + verify in one process; the proof equals the oracle's"""
+    import os, subprocess
+    spzk = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "otti_amd", "spzk")
+    r = oa.synth_r1cs_compiler_like(3000, 5, 11)
+    pre = str(tmp_path / "c")
+    oa.zkif_write(r, pre + ".zkif", pre + ".inp.zkif", pre + ".wit.zkif")
+    res = subprocess.run([spzk, "verify", pre + ".zkif", pre + ".inp.zkif", pre + ".wit.zkif", "--seed", "2a" * 32, "--proof-out", pre + ".proof"],
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and "Verification successful" in res.stdout and "SNARK::prove" in res.stdout, res.stdout + res.stderr
+    back = oa.zkif_load(pre + ".zkif", pre + ".inp.zkif", pre + ".wit.zkif")
+    nz = max(back["A"].size, back["B"].size, back["C"].size)
+    oi = orc.OInstance(back["num_cons"], back["num_vars"], back["num_inputs"], back["A"], back["B"], back["C"])
+    og = orc.OSnarkGens(back["num_cons"], back["num_vars"], back["num_inputs"], nz)
+    want, _ = orc.snark_prove(oi, orc.OSnarkComm.encode(oi, og), back["vars"], back["inputs"], og, LABEL, SEED)
+    assert open(pre + ".proof", "rb").read() == want
