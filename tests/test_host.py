@@ -269,3 +269,30 @@ def test_host_parsers_under_address_and_ub_sanitizers(tmp_path):
 def test_host_fast_paths_agree_with_the_generic_field_code():
     """five-limb GF(2^255-19) point compression and the fixed-base window tables of the prover's per-round host work (hostfast.h)"""
     oa.host_selftest(300)
+
+
+@pytest.mark.parametrize("n,ni,kind", [(16, 3, "uniform"), (200, 4, "compiler"), (1 << 10, 10, "uniform")])
+def test_product_snark_verifier_accepts_oracle_proofs_and_rejects_tampering(n, ni, kind):
+    """SNARK::verify of the product (host code, needs no GPU) on proofs and commitments made by the CPU oracle: two independently
+    written implementations of the SNARK-mode protocol agree; the commitment round-trips through its wire form"""
+    import orc
+    r = (oa.synth_r1cs if kind == "uniform" else oa.synth_r1cs_compiler_like)(n, ni, 7)
+    nz = max(r["A"].size, r["B"].size, r["C"].size)
+    oi = orc.OInstance(r["num_cons"], r["num_vars"], r["num_inputs"], r["A"], r["B"], r["C"])
+    og = orc.OSnarkGens(r["num_cons"], r["num_vars"], r["num_inputs"], nz)
+    oc = orc.OSnarkComm.encode(oi, og)
+    proof, _ = orc.snark_prove(oi, oc, r["vars"], r["inputs"], og)
+    gens = oa.SNARKGens.new(r["num_cons"], r["num_vars"], r["num_inputs"], nz)
+    comm = oa.ComputationCommitment.from_bytes(oc.bytes)
+    assert comm.bytes == oc.bytes
+    inputs = oa.InputsAssignment.new(r["inputs"])
+    oa.SNARK(proof).verify(comm, inputs, gens)
+    rng = np.random.default_rng(n)
+    for pos in rng.integers(0, len(proof), 12):
+        bad = bytearray(proof); bad[int(pos)] ^= 1 << int(rng.integers(0, 8))
+        with pytest.raises(oa.ProofVerifyError):
+            oa.SNARK(bytes(bad)).verify(comm, inputs, gens)
+    with pytest.raises(oa.ProofVerifyError):
+        oa.SNARK(proof).verify(comm, inputs, gens, b"another label")
+    with pytest.raises(oa.SpartanError):
+        oa.ComputationCommitment.from_bytes(oc.bytes[:-3])
