@@ -133,7 +133,8 @@ void    otti_buf_free(void *p);
 /* copies the calling thread's last error message (NUL-terminated, truncated to cap) */
 size_t  otti_last_error(char *buf, size_t cap);
 
-/* upload instance / build the generator window table ahead of the first prove (both are otherwise lazy) */
+/* upload instance / build the generator window table ahead of the first prove (both are otherwise lazy); with both NULL: only bring
+   the HIP runtime and the device context up (a one-shot caller does this on a side thread while it parses its input) */
 int32_t otti_prepare_device(otti_instance *inst, otti_gens *gens);
 /* number of visible gfx950 devices (0 when none; never initialises a context) */
 int32_t otti_device_count(void);

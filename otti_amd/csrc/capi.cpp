@@ -136,6 +136,7 @@ int32_t otti_prepare_device(otti_instance *inst, otti_gens *gens) {
         if (inst) ensure_instance_device(*inst->I);
         if (inst && gens) ensure_device_objects(*inst->I, *gens->g);
         else if (gens) ensure_gens_device(*gens->g);
+        else if (!inst) DevCtx::get();                              // neither: just bring the HIP runtime and this process's device context up
         return OTTI_OK;
     });
 }

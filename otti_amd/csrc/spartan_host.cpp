@@ -28,21 +28,48 @@ std::unique_ptr<Instance> instance_new(size_t num_cons, size_t num_vars, size_t 
     auto I = std::make_unique<Instance>();
     I->num_cons = ncp; I->num_vars = nvp; I->num_inputs = num_inputs; I->given_cons = num_cons;
     const otti_entry *src[3] = {A, B, C}; size_t cnt[3] = {nA, nB, nC};
+    // validation and conversion to Montgomery form (one field multiplication per entry) in blocks over the host cores; the error a
+    // sequential walk would meet first is the one reported
+    const unsigned nt = (nA + nB + nC) < 8192 ? 1u : std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
     for (int k = 0; k < 3; k++) {
         SparseMat &m = I->M[k];
-        m.row.reserve(cnt[k]); m.col.reserve(cnt[k]); m.val.reserve(cnt[k]);
-        for (size_t i = 0; i < cnt[k]; i++) {
-            const otti_entry &e = src[k][i];
+        m.row.resize(cnt[k]); m.col.resize(cnt[k]); m.val.resize(cnt[k]);
+        std::vector<size_t> bad_at(nt, SIZE_MAX); std::vector<int> bad_code(nt, 0);
+        auto work = [&](unsigned t) {
+            const size_t i0 = cnt[k] * t / nt, i1 = cnt[k] * (t + 1) / nt;
+            for (size_t i = i0; i < i1; i++) {
+                const otti_entry &e = src[k][i];
+                int code = 0;
+                if (e.row >= num_cons || e.col >= num_vars + 1 + num_inputs) code = OTTI_ERR_INVALID_INDEX;
+                Fr v = fr_zero();
+                if (!code && !fr_from_bytes(v, e.val)) code = OTTI_ERR_INVALID_SCALAR;
+                if (code) { bad_at[t] = i; bad_code[t] = code; return; }
+                // columns >= num_vars reference the constant 1 or an input: shift by the padding of the variable block
+                const size_t col = e.col >= num_vars ? e.col + nvp - num_vars : e.col;
+                m.row[i] = (uint32_t)e.row; m.col[i] = (uint32_t)col; m.val[i] = v;
+            }
+        };
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < nt; t++) th.emplace_back(work, t);
+        work(0);
+        for (auto &x : th) x.join();
+        for (unsigned t = 0; t < nt; t++) if (bad_at[t] != SIZE_MAX) {
+            const otti_entry &e = src[k][bad_at[t]];
             if (e.row >= num_cons) throw Error(OTTI_ERR_INVALID_INDEX, "row index out of range");
             if (e.col >= num_vars + 1 + num_inputs) throw Error(OTTI_ERR_INVALID_INDEX, "column index out of range");
-            Fr v; if (!fr_from_bytes(v, e.val)) throw Error(OTTI_ERR_INVALID_SCALAR, "non-canonical scalar in matrix");
-            // columns >= num_vars reference the constant 1 or an input: shift by the padding of the variable block
-            size_t col = e.col >= num_vars ? e.col + nvp - num_vars : e.col;
-            m.row.push_back((uint32_t)e.row); m.col.push_back((uint32_t)col); m.val.push_back(v);
+            throw Error(OTTI_ERR_INVALID_SCALAR, "non-canonical scalar in matrix");
         }
-        // (upstream also appends explicit zero entries when num_cons < 2; zeros change nothing and are not stored)
-        build_csr(m.by_row, m.row, m.col, m.val, ncp);
-        build_csr(m.by_col, m.col, m.row, m.val, 2 * nvp);
+    }
+    // (upstream also appends explicit zero entries when num_cons < 2; zeros change nothing for the satisfiability proof and are not stored)
+    {   // the six CSR copies (by row and by column, three matrices) are independent counting sorts
+        std::vector<std::thread> th;
+        for (int k = 0; k < 3; k++) {
+            SparseMat *m = &I->M[k];
+            auto by_row = [m, ncp] { build_csr(m->by_row, m->row, m->col, m->val, ncp); };
+            auto by_col = [m, nvp] { build_csr(m->by_col, m->col, m->row, m->val, 2 * nvp); };
+            if (nt > 1) { th.emplace_back(by_row); th.emplace_back(by_col); } else { by_row(); by_col(); }
+        }
+        for (auto &x : th) x.join();
     }
     return I;
 }
@@ -95,8 +122,15 @@ static const uint8_t kBasepointCompressed[32] = {
 
 std::vector<Pt> derive_generators(const char *label, size_t count) {
     Shake256 xof; xof.absorb(label, strlen(label)); xof.absorb(kBasepointCompressed, 32);
+    std::vector<uint8_t> u(64 * count);
+    xof.squeeze(u.data(), u.size());                                 // the stream is sequential; the one-way maps (two Elligator maps + an addition each) are not
     std::vector<Pt> out(count);
-    for (auto &p : out) { uint8_t u[64]; xof.squeeze(u, 64); p = pt_from_uniform_bytes(u); }
+    const unsigned nt = count < 64 ? 1u : std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    auto work = [&](unsigned t) { for (size_t i = count * t / nt; i < count * (t + 1) / nt; i++) out[i] = pt_from_uniform_bytes(&u[64 * i]); };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; t++) th.emplace_back(work, t);
+    work(0);
+    for (auto &x : th) x.join();
     return out;
 }
 
@@ -115,10 +149,16 @@ std::unique_ptr<Gens> gens_new(size_t num_cons, size_t num_vars, size_t num_inpu
     g->sc_4.G = {0, 1, 2, 3}; g->sc_4.h = 4;
     g->small_slot.assign(g->P.size(), -1);
     const size_t small[7] = {0, 1, 2, 3, 4, R, R + 1};
+    std::vector<size_t> uniq;
     for (size_t idx : small) {
         if (g->small_slot[idx] >= 0) continue;
         g->small_slot[idx] = (int)g->small_tables.size();
-        g->small_tables.emplace_back(); g->small_tables.back().build(g->P[idx]);
+        g->small_tables.emplace_back(); uniq.push_back(idx);
+    }
+    {   // the host window tables of these (up to seven) points are independent builds
+        std::vector<std::thread> th;
+        for (size_t idx : uniq) { Gens *gp = g.get(); th.emplace_back([gp, idx] { gp->small_tables[gp->small_slot[idx]].build(gp->P[idx]); }); }
+        for (auto &x : th) x.join();
     }
     return g;
 }

@@ -16,6 +16,9 @@
 #include <sys/stat.h>
 #include <map>
 #include <algorithm>
+#include <thread>
+#include <exception>
+#include <chrono>
 
 namespace otti {
 
@@ -63,7 +66,8 @@ VarList read_variables(const Table &t) {
         if (n == 0 || vn % n) throw Error(OTTI_ERR_IO, "zkif: values length not a multiple of the variable count");
         size_t w = vn / n; t.b->chk(vs, vn);
         v.vals.resize(n); v.has_vals = true;
-        for (size_t i = 0; i < n; i++) {
+        if (w == 32) memcpy(v.vals.data(), t.b->p + vs, vn);                  // the common case: one block copy
+        else for (size_t i = 0; i < n; i++) {
             v.vals[i].fill(0);
             for (size_t k = 0; k < w; k++) {
                 uint8_t byte = t.b->p[vs + i * w + k];
@@ -85,10 +89,11 @@ struct FileView {
         if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) { close(fd); throw Error(OTTI_ERR_IO, std::string("not a regular file: ") + path); }
         n = (size_t)st.st_size;
         if (n) {
-            void *m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+            // MAP_POPULATE: the parser's threads walk the file in parallel; one batched population of the mapping is several times
+            // cheaper than a minor fault per 4 KiB page taken by sixteen threads contending for the address-space lock
+            void *m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
             if (m == MAP_FAILED) { close(fd); throw Error(OTTI_ERR_IO, std::string("cannot map ") + path); }
             p = (const uint8_t *)m;
-            madvise(m, n, MADV_SEQUENTIAL);
         }
     }
     FileView(const FileView &) = delete; FileView &operator=(const FileView &) = delete;
@@ -253,16 +258,21 @@ static void append_lc(std::vector<otti_entry> &out, const Table &vars, uint64_t 
     if (!vars.vec(1, vs, vn) || vn == 0 || vn % in) throw Error(OTTI_ERR_IO, "zkif: linear combination without (well-formed) coefficients");
     const size_t w = vn / in; vars.b->chk(vs, vn);
     for (size_t i = 0; i < in; i++) {
-        otti_entry e; e.row = row; e.col = map.col(vars.b->u64(is + 8 * i)); memset(e.val, 0, 32);
-        for (size_t k = 0; k < w; k++) {
-            uint8_t byte = vars.b->p[vs + i * w + k];
-            if (k < 32) e.val[k] = byte; else if (byte) throw Error(OTTI_ERR_INVALID_SCALAR, "zkif: coefficient wider than 32 bytes");
+        otti_entry e; e.row = row; e.col = map.col(vars.b->u64(is + 8 * i));
+        const uint8_t *src = vars.b->p + vs + i * w;
+        if (w == 32) memcpy(e.val, src, 32);
+        else {
+            memset(e.val, 0, 32); memcpy(e.val, src, std::min<size_t>(w, 32));
+            for (size_t k = 32; k < w; k++) if (src[k]) throw Error(OTTI_ERR_INVALID_SCALAR, "zkif: coefficient wider than 32 bytes");
         }
         out.push_back(e);
     }
 }
 
+static double zk_now() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 otti_r1cs *zkif_load_impl(const char *circuit_path, const char *inputs_path, const char *witness_path) {
+    const bool trace = getenv("OTTI_TRACE") != nullptr; double tt = zk_now();
+    auto lap = [&](const char *what) { if (trace) { double n = zk_now(); fprintf(stderr, "[otti] zkif_load %-28s %.2f ms\n", what, n - tt); tt = n; } };
     Messages m;
     FileView circuit(circuit_path);
     parse_headers(circuit, m);
@@ -284,33 +294,83 @@ otti_r1cs *zkif_load_impl(const char *circuit_path, const char *inputs_path, con
     // Untrusted header: every variable id a file declares occupies at least eight bytes somewhere in the files (its assignment, or its
     // uses in constraints), so a free_variable_id beyond that is either garbage or an attempt to make the loader allocate gigabytes.
     if (free_id > file_bytes / 8 + 2) throw Error(OTTI_ERR_IO, "zkif: free_variable_id is larger than the files can account for");
+    lap("headers + witness message");
     IdMap map; map.build(m.instance.ids, free_id);
+    lap("id map");
     if (m.have_witness && m.witness.ids.size() != map.num_vars) throw Error(OTTI_ERR_IO, "zkif: witness does not assign every variable exactly once");
-    // pass 2: constraints of the circuit file, message by message
-    std::vector<otti_entry> M[3]; uint64_t row = 0;
-    for (auto &v : M) v.reserve(circuit.size() / 96);                   // about one entry per 80-90 file bytes per matrix: avoids most regrowth copies
+    // pass 2: constraints of the circuit file.  A quick walk over the messages finds every ConstraintSystem's offset vector; the rows are
+    // then cut into contiguous blocks, one per host thread, each parsed into its own entry lists (a FlatBuffers vector of tables is
+    // random access), and the lists are concatenated in row order — the same entries in the same order as a sequential walk.
+    struct Chunk { Buf b; size_t s, n; uint64_t first_row; };
+    std::vector<Chunk> chunks; uint64_t row = 0;
     for_each_message(circuit, [&](uint8_t type, const Table &msg, const Buf &b) {
         if (type != 2) return;
         size_t s, n; msg.vec(0, s, n); b.chk(s, n * 4);
-        for (size_t i = 0; i < n; i++, row++) {
-            Table bc; bc.b = &b; bc.pos = s + 4 * i + b.u32(s + 4 * i); bc.present = true; b.chk(bc.pos, 4);
-            for (int t = 0; t < 3; t++) append_lc(M[t], bc.sub(t), row, map);
-        }
+        chunks.push_back({b, s, n, row}); row += n;
     });
-    std::vector<uint8_t> vars(m.have_witness ? 32 * map.num_vars : 0, 0), inputs(32 * map.num_inputs, 0);   // no witness file (verifier): no assignment
-    if (m.instance.has_vals) for (size_t i = 0; i < map.num_inputs; i++) memcpy(&inputs[32 * i], m.instance.vals[i].data(), 32);
+    lap("message walk");
+    unsigned nt = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    if (const char *e = getenv("OTTI_PARSE_THREADS")) { int v = atoi(e); if (v >= 1 && v <= 64) nt = (unsigned)v; }
+    if (row < 4096) nt = 1;
+    std::vector<std::vector<otti_entry>> part[3]; for (auto &p : part) p.resize(nt);
+    std::vector<std::exception_ptr> err(nt);
+    auto work = [&](unsigned t) {
+        try {
+            const uint64_t r0 = row * t / nt, r1 = row * (t + 1) / nt;
+            for (auto &v : part) v[t].reserve((size_t)((r1 - r0) * 5 / 4 + 16));
+            for (const Chunk &ch : chunks) {
+                if (ch.first_row + ch.n <= r0 || ch.first_row >= r1) continue;
+                const size_t i0 = r0 > ch.first_row ? (size_t)(r0 - ch.first_row) : 0, i1 = (size_t)std::min<uint64_t>(ch.n, r1 - ch.first_row);
+                for (size_t i = i0; i < i1; i++) {
+                    Table bc; bc.b = &ch.b; bc.pos = ch.s + 4 * i + ch.b.u32(ch.s + 4 * i); bc.present = true; ch.b.chk(bc.pos, 4);
+                    for (int k = 0; k < 3; k++) append_lc(part[k][t], bc.sub(k), ch.first_row + i, map);
+                }
+            }
+        } catch (...) { err[t] = std::current_exception(); }
+    };
+    {
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < nt; t++) th.emplace_back(work, t);
+        work(0);
+        for (auto &x : th) x.join();
+        for (auto &e : err) if (e) std::rethrow_exception(e);
+    }
+    lap("constraints (threads)");
+    otti_r1cs *out = (otti_r1cs *)calloc(1, sizeof *out);
+    struct Guard { otti_r1cs *r; ~Guard() { if (r) otti_r1cs_free(r); } } guard{out};
+    otti_entry **dst[3] = {&out->A, &out->B, &out->C}; size_t *cnt[3] = {&out->nA, &out->nB, &out->nC};
+    for (int k = 0; k < 3; k++) {                                         // the threads' parts go straight into the arrays the caller will own
+        size_t total = 0; for (auto &v : part[k]) total += v.size();
+        otti_entry *arr = (otti_entry *)malloc(std::max<size_t>(1, total) * sizeof(otti_entry));
+        if (!arr) throw std::bad_alloc();
+        *dst[k] = arr; *cnt[k] = total;
+        std::vector<size_t> at(nt); size_t o = 0; for (unsigned t = 0; t < nt; t++) { at[t] = o; o += part[k][t].size(); }
+        std::vector<std::thread> th;
+        auto cp = [&, k, arr](unsigned t) { if (!part[k][t].empty()) memcpy(arr + at[t], part[k][t].data(), part[k][t].size() * sizeof(otti_entry)); std::vector<otti_entry>().swap(part[k][t]); };
+        for (unsigned t = 1; t < nt; t++) th.emplace_back(cp, t);
+        cp(0);
+        for (auto &x : th) x.join();
+    }
+    lap("concatenate");
+    out->num_cons = row; out->num_vars = map.num_vars; out->num_inputs = map.num_inputs;
+    out->nvars = m.have_witness ? map.num_vars : 0; out->ninputs = map.num_inputs;      // no witness file (verifier): no assignment
+    out->vars32 = (uint8_t *)calloc(std::max<size_t>(1, 32 * out->nvars), 1); out->inputs32 = (uint8_t *)calloc(std::max<size_t>(1, 32 * out->ninputs), 1);
+    if (!out->vars32 || !out->inputs32) throw std::bad_alloc();
+    if (m.instance.has_vals) for (size_t i = 0; i < map.num_inputs; i++) memcpy(out->inputs32 + 32 * i, m.instance.vals[i].data(), 32);
     else if (map.num_inputs && inputs_path) throw Error(OTTI_ERR_IO, "zkif: inputs file carries no instance values");
     if (m.have_witness) {
         if (m.witness.ids.size() != m.witness.vals.size()) throw Error(OTTI_ERR_IO, "zkif: witness without values");
-        std::vector<bool> seen(map.num_vars, false);
+        std::vector<uint8_t> seen(map.num_vars, 0);
         for (size_t i = 0; i < m.witness.ids.size(); i++) {
             size_t pos = m.witness.ids[i] == 0 ? SIZE_MAX : map.wit_pos(m.witness.ids[i]);
             if (pos == SIZE_MAX) throw Error(OTTI_ERR_INVALID_INDEX, "zkif: witness assigns an instance or unknown variable");
-            memcpy(&vars[32 * pos], m.witness.vals[i].data(), 32); seen[pos] = true;
+            memcpy(out->vars32 + 32 * pos, m.witness.vals[i].data(), 32); seen[pos] = 1;
         }
-        for (bool sn : seen) if (!sn) throw Error(OTTI_ERR_IO, "zkif: witness does not assign every variable");
+        for (uint8_t sn : seen) if (!sn) throw Error(OTTI_ERR_IO, "zkif: witness does not assign every variable");
     }
-    return otti_r1cs_from(row, map.num_vars, map.num_inputs, M[0], M[1], M[2], vars, inputs);
+    lap("assignment");
+    guard.r = nullptr;
+    return out;
 }
 
 void zkif_write_impl(const otti_r1cs *r, const char *circuit_path, const char *inputs_path, const char *witness_path) {
