@@ -143,6 +143,11 @@ int32_t otti_device_count(void);
    pseudo-random inputs.  0 = consistent.  Needs no GPU; the prover itself only runs on one, so this is how the CPU test suite
    reaches that code. */
 int32_t otti_host_selftest(uint32_t iterations);
+/* Measurement aid: nanoseconds per operation of the host primitives on the provers' sequential path, on the calling machine:
+ * [0] fixed-base scalar multiplication (8-bit windows), [1] ristretto compression, [2] Keccak-f[1600], [3] transcript append of a point
+ * + challenge scalar, [4] GF(l) multiplication, [5] GF(l) inversion, [6] hand-off of an empty task to a helper thread and back,
+ * [7] / [8] the two halves of one zero-knowledge sum-check round's host work (up to the challenge / after it), [9] threads used. */
+int32_t otti_host_microbench(double out[10]);
 
 /* ---- zkInterface ingest (replaces spartan-zkinterface's reader; schema zkinterface 1.x) ---- */
 typedef struct {

@@ -63,6 +63,7 @@ _sig("otti_last_error", _sz, ctypes.c_char_p, _sz)
 _sig("otti_buf_free", None, _vp)
 _sig("otti_device_count", _i32)
 _sig("otti_host_selftest", _i32, ctypes.c_uint32)
+_sig("otti_host_microbench", _i32, ctypes.POINTER(ctypes.c_double))
 _sig("otti_instance_new", _i32, _u64, _u64, _u64, _vp, _sz, _vp, _sz, _vp, _sz, ctypes.POINTER(_vp))
 _sig("otti_instance_free", None, _vp)
 _sig("otti_instance_dims", _i32, _vp, ctypes.POINTER(_u64), ctypes.POINTER(_u64), ctypes.POINTER(_u64))
@@ -185,6 +186,17 @@ def device_count():
 def host_selftest(iterations=200):
     """host-side fast paths of the prover (five-limb field, fixed-base tables) against the generic code; raises on a mismatch"""
     _check(lib.otti_host_selftest(iterations))
+
+
+HOST_OPS = ("fixed_base_mul", "compress", "keccak_f1600", "append_point+challenge", "fr_mul", "fr_inv", "helper_thread_handoff",
+            "zk_round_begin", "zk_round_finish", "threads")
+
+
+def host_microbench():
+    """nanoseconds per host-side primitive on this machine (no GPU needed); the last entry is the thread count used"""
+    out = (ctypes.c_double * 10)()
+    _check(lib.otti_host_microbench(out))
+    return dict(zip(HOST_OPS, out))
 
 
 # ---------------------------------------------------------------------------------------------- libspartan mirror

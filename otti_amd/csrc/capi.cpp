@@ -3,6 +3,9 @@
 #include "shard.h"
 #include "snark.h"
 #include <array>
+#include <atomic>
+#include <chrono>
+#include "pool.h"
 #include <mutex>
 
 using namespace otti;
@@ -80,6 +83,48 @@ int32_t otti_host_selftest(uint32_t iterations) {
             pt_encode_fast(a, pt_identity()); pt_encode_ref(b, pt_identity());
             if (memcmp(a, b, 32)) throw Error(OTTI_ERR_INTERNAL, "identity encodes differently");
         }
+        return OTTI_OK;
+    });
+}
+
+// nanoseconds per operation of the host-side primitives on the sequential path (measurement aid: tools/hostbench.py)
+int32_t otti_host_microbench(double out[10]) {
+    return guarded([&] {
+        if (!out) throw Error(OTTI_ERR_BAD_ARG, "null out pointer");
+        auto g = gens_new(16, 16, 1);
+        auto now = [] { return std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        Shake256 xof; xof.absorb("otti-host-microbench", 20);
+        uint8_t w[64]; xof.squeeze(w, 64); Fr s = fr_from_bytes_wide(w); xof.squeeze(w, 64); Fr s2 = fr_from_bytes_wide(w);
+        xof.squeeze(w, 64); const Pt rnd = pt_from_uniform_bytes(w);
+        const int R = 2000; double t0; volatile uint8_t sink = 0;
+        { PtFe acc = ptfe_from(rnd); t0 = now(); for (int i = 0; i < R; i++) { g->small_tables[0].accumulate(acc, s); s = fr_add(s, s2); } out[0] = (now() - t0) / R; uint8_t b[32]; pt_encode(b, ptfe_to(acc)); sink ^= b[0]; }
+        { uint8_t b[32]; Pt p = rnd; t0 = now(); for (int i = 0; i < R; i++) { pt_encode(b, p); p.X.v[0] ^= b[0] & 1; } out[1] = (now() - t0) / R; sink ^= b[1]; }
+        { uint64_t st[25] = {1}; t0 = now(); for (int i = 0; i < 10 * R; i++) keccak_f1600(st); out[2] = (now() - t0) / (10 * R); sink ^= (uint8_t)st[3]; }
+        { Transcript tr("bench", 5); uint8_t b[32] = {7}; t0 = now(); for (int i = 0; i < R; i++) { tr.append_point("comm_poly", b); Fr c = tr.challenge_scalar("challenge_nextround"); b[0] ^= (uint8_t)c.v[0]; } out[3] = (now() - t0) / R; sink ^= b[0]; }
+        { Fr a = s, b = s2; t0 = now(); for (int i = 0; i < 100 * R; i++) a = fr_mul(a, b); out[4] = (now() - t0) / (100 * R); sink ^= (uint8_t)a.v[0]; }
+        { Fr a = s; t0 = now(); for (int i = 0; i < R / 10; i++) a = fr_inv(fr_add(a, s2)); out[5] = (now() - t0) / (R / 10); sink ^= (uint8_t)a.v[0]; }
+        {   // hand one empty task to a helper thread and wait for it
+            SpinPool::Session session; SpinPool &pool = SpinPool::get();
+            out[6] = 0;
+            if (pool.workers() > 0) { std::atomic<int> n{0}; std::function<void()> f = [&] { n.fetch_add(1, std::memory_order_relaxed); }; for (int i = 0; i < 100; i++) { pool.submit(0, f); pool.wait(0); }
+                t0 = now(); for (int i = 0; i < R; i++) { pool.submit(0, f); pool.wait(0); } out[6] = (now() - t0) / R; }
+            // one zero-knowledge sum-check round's host work as the prover runs it (cubic round, 4 coefficients), without a device
+            const int rounds = 200;
+            Transcript tr("bench", 5); RandomTape tape(w);
+            SumcheckState st; sumcheck_draw_tape(st, tape, rounds, 4);
+            for (auto &p : st.pre) { Term t = {g->sc_4.h, st.blinds_poly[0]}; p.bp_h = g->commit_terms(&t, 1); p.be_h = p.bp_h; p.rb_h = p.bp_h; p.delta = p.bp_h; pt_encode(p.delta_c.b, p.delta); }
+            st.claim = s; st.blind_claim = s2; pt_encode(st.comm_claim.b, rnd);
+            ZKSumcheckProof pf; pf.comm_polys.resize(rounds); pf.comm_evals.resize(rounds); pf.proofs.resize(rounds);
+            double tb = 0, tf = 0;
+            for (int j = 0; j < rounds; j++) {
+                Fr ev[4] = {s, fr_sub(st.claim, s), s2, fr_mul(s, s2)};
+                t0 = now(); RoundPart1 p1 = sumcheck_round_begin(pf, j, ev, 4, st, *g, g->sc_4, tr); tb += now() - t0;
+                t0 = now(); sumcheck_round_finish(pf, j, p1, st, *g, g->sc_4, tr); tf += now() - t0;
+                s = fr_add(s, p1.r_j);
+            }
+            out[7] = tb / rounds; out[8] = tf / rounds; out[9] = pool.workers() + 1;
+        }
+        (void)sink;
         return OTTI_OK;
     });
 }

@@ -48,6 +48,14 @@ struct DeviceGens {
 // where a sum-check kernel's last workgroup delivers the round's totals (see finish_in_kernel)
 struct Mailbox { Fr *partials; unsigned *counter; Fr *host_results; unsigned long long *host_flag; unsigned long long seq; int slot; };
 
+// Armed launches.  The sequential rounds cost a launch + dispatch (10-15 us) on top of the kernel itself when the kernel can only be
+// launched once the host knows the round's challenge.  An ARMED kernel is queued before that: its first workgroup spins on a pinned host
+// word until the host publishes the value (DevCtx::go), copies it to HBM for the other workgroups, and the round starts within a PCIe
+// read of the challenge being known.  Every spin has a deadline (3 s of s_memrealtime) and an abort value, so a grid always drains.
+struct GoBox { unsigned long long seq, pad[3]; Fr v[2]; };
+struct Armed { const GoBox *host; GoBox *dev; unsigned long long want; };   // want == 0: not armed (values come as kernel arguments)
+constexpr size_t kArmMaxLen = 65536;                         // sum-check tables up to this length fold in <= 64 workgroups: only those launches are armed
+
 struct DevCtx {
     hipStream_t stream = nullptr;
     int device = 0, num_cu = 256;
@@ -59,6 +67,11 @@ struct DevCtx {
     unsigned long long *h_flag = nullptr, *d_flag_alias = nullptr, seq = 0;   // host-visible completion flag of the latest mailbox launch
     DevBuf<unsigned> d_counter;                               // arrival counter of the publishing workgroups
     Mailbox next_mailbox(int slot);
+    GoBox *h_go = nullptr, *d_go_alias = nullptr; DevBuf<GoBox> d_go; unsigned long long go_issued = 0, go_published = 0;
+    bool armed_ok() const;                                    // off under OTTI_ARMED=0 and while kernel classes are being timed (a spinning kernel's duration includes the host)
+    Armed arm();                                              // for the next launch; the k-th armed launch consumes the k-th go()
+    void go(const Fr *v, int n);                              // publish up to two values to the oldest armed launch that has none yet
+    void go_abort();                                          // release every armed launch still waiting (they exit without touching their data) and drain the stream
     void wait_ticket(unsigned long long ticket);              // spin until the launch with that sequence number has delivered
     DevBuf<Pt> msm_keep;                                      // row sums parked on the device (MSM_KEEP)
     DevBuf<Pt> msm_partial, msm_final;                        // [rows][chunks] partial sums, [rows] row sums
@@ -76,7 +89,7 @@ struct DevCtx {
     Pt *d_pts_alias = nullptr; DevBuf<unsigned> d_counter2;
     void ensure_points(size_t rows, size_t splits);
 };
-constexpr int kResultSlots = 256;
+constexpr int kResultSlots = 2048;                          // 64 KB pinned: round sums, sum-check tails (SNARK: up to 18 x 3 tables x 16 elements)
 constexpr size_t kHostEncodeRows = 8;
 constexpr size_t kHostPtsCap = 512;
 
@@ -144,6 +157,9 @@ struct EqSrc { const Fr *hi, *lo; int lo_bits; };
 void dev_eq_pyramid(DevCtx &c, const Fr *r_host, size_t n, Fr *out /* 2^(n+1) - 1 elements: level k at out + 2^k - 1 */);
 unsigned long long dev_sc_cubic3_eval(DevCtx &c, const Fr *B, const Fr *C, const Fr *D, size_t len, const EqSrc &E, int slot);
 unsigned long long dev_sc_cubic3_fold_eval(DevCtx &c, Fr *B, Fr *C, Fr *D, size_t len, const Fr &r, const EqSrc &E, int slot);
+// armed variants (see Armed above): the fold challenge is the next value published with c.go()
+unsigned long long dev_sc_cubic3_fold_eval_armed(DevCtx &c, Fr *B, Fr *C, Fr *D, size_t len, const EqSrc &E, int slot);
+unsigned long long dev_sc_quad_fold_eval_armed(DevCtx &c, Fr *A, Fr *B, size_t len, int slot);
 unsigned long long dev_sc_quad_eval(DevCtx &c, const Fr *A, const Fr *B, size_t len, int slot);
 unsigned long long dev_sc_quad_fold_eval(DevCtx &c, Fr *A, Fr *B, size_t len, const Fr &r, int slot);
 void dev_fold_top(DevCtx &c, Fr *Z, size_t len, const Fr &r);

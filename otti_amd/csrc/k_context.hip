@@ -78,6 +78,11 @@ DevCtx &DevCtx::get() {
     OTTI_HIP(hipHostGetDevicePointer((void **)&c->d_flag_alias, c->h_flag, 0));
     c->d_counter.alloc(1);
     OTTI_HIP(hipMemset(c->d_counter.p, 0, sizeof(unsigned)));
+    OTTI_HIP(hipHostMalloc((void **)&c->h_go, sizeof(GoBox), hipHostMallocDefault));
+    memset(c->h_go, 0, sizeof(GoBox));
+    OTTI_HIP(hipHostGetDevicePointer((void **)&c->d_go_alias, c->h_go, 0));
+    c->d_go.alloc(1);
+    OTTI_HIP(hipMemset(c->d_go.p, 0, sizeof(GoBox)));
     OTTI_HIP(hipEventCreate(&c->ev0)); OTTI_HIP(hipEventCreate(&c->ev1));
     lease.c = c.release();
     return *lease.c;
@@ -126,6 +131,23 @@ void KStats::reset() { used = 0; for (int k = 0; k < KC_COUNT; k++) { total_ms[k
 Mailbox DevCtx::next_mailbox(int slot) {
     Mailbox mb; mb.partials = partials.p; mb.counter = d_counter.p; mb.host_results = d_results_alias; mb.host_flag = d_flag_alias;
     mb.seq = ++seq; mb.slot = slot; return mb;
+}
+bool DevCtx::armed_ok() const {
+    static const bool env_on = [] { const char *e = getenv("OTTI_ARMED"); return !(e && e[0] == '0'); }();
+    return env_on && !KStats::get().on;
+}
+Armed DevCtx::arm() { Armed a; a.host = d_go_alias; a.dev = d_go.p; a.want = ++go_issued; return a; }
+void DevCtx::go(const Fr *v, int n) {
+    if (go_published >= go_issued) throw Error(OTTI_ERR_INTERNAL, "go() without an armed launch");
+    for (int i = 0; i < n && i < 2; i++) h_go->v[i] = v[i];
+    __atomic_store_n(&h_go->seq, ++go_published, __ATOMIC_RELEASE);
+}
+void DevCtx::go_abort() {
+    if (go_published >= go_issued) return;
+    __atomic_store_n(&h_go->seq, ~0ull, __ATOMIC_RELEASE);
+    (void)hipStreamSynchronize(stream);
+    go_published = go_issued;
+    __atomic_store_n(&h_go->seq, go_published, __ATOMIC_RELEASE);
 }
 void DevCtx::wait_ticket(unsigned long long ticket) {
     volatile unsigned long long *f = h_flag;

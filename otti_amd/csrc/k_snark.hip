@@ -97,6 +97,126 @@ void dev_abc_evals(DevCtx &c, const AbcList &L, size_t half, Fr *partials, int s
     hipLaunchKernelGGL(k_abc_evals, dim3((unsigned)g, (unsigned)L.n), kBlock, 0, c.stream, L, half, partials);
     hipLaunchKernelGGL(k_reduce_many<3>, L.n, kBlock, 0, c.stream, (const Fr *)partials, g, c.d_results_alias + slot);
 }
+// ---- the same round as ONE launch (fold by the previous challenge + sums of the next round), results mailed to the host by the last
+// workgroup (finish_in_kernel of k_sumcheck.hip, here for every instance of the batch at once).
+__device__ __forceinline__ void finish_many(Fr (&acc)[3], const Mailbox &mb) {
+    block_reduce<3>(acc);
+    const unsigned total = gridDim.x * gridDim.y, ny = gridDim.y;
+    if (total == 1) {
+        if (threadIdx.x == 0) {
+            for (int k = 0; k < 3; k++) mb.host_results[mb.slot + k] = acc[k];
+            __threadfence_system();
+            __hip_atomic_store(mb.host_flag, mb.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return;
+    }
+    if (threadIdx.x == 0) for (int k = 0; k < 3; k++) store_words_sc1(&mb.partials[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 3 + k], acc[k].v, 8);
+    if (!arrive_and_check_last(mb.counter, total)) return;
+    // last workgroup: output o = (instance, t) is summed by four adjacent lanes
+    const unsigned o = threadIdx.x >> 2, sub = threadIdx.x & 3;
+    Fr s = fr_zero();
+    if (o < 3 * ny) {
+        const unsigned y = o / 3, k = o % 3;
+        for (unsigned b = sub; b < gridDim.x; b += 4) { Fr t; load_words_sc1(t.v, &mb.partials[((size_t)y * gridDim.x + b) * 3 + k], 8); s = fr_add(s, t); }
+    }
+    s = fr_add(s, shfl_xor_fr(s, 1)); s = fr_add(s, shfl_xor_fr(s, 2));
+    if (o < 3 * ny && sub == 0) mb.host_results[mb.slot + o] = s;
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(mb.host_flag, mb.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void abc_accum(Fr (&acc)[3], const Pair &a, const Pair &b, const Pair &c) {
+    acc[0] = fr_add(acc[0], fr_mul(fr_mul(a.lo, b.lo), c.lo));
+    const Fr da = fr_sub(a.hi, a.lo), db = fr_sub(b.hi, b.lo), dc = fr_sub(c.hi, c.lo);
+    Fr x = fr_add(a.hi, da), y = fr_add(b.hi, db), z = fr_add(c.hi, dc);
+    acc[1] = fr_add(acc[1], fr_mul(fr_mul(x, y), z));
+    x = fr_add(x, da); y = fr_add(y, db); z = fr_add(z, dc);
+    acc[2] = fr_add(acc[2], fr_mul(fr_mul(x, y), z));
+}
+__device__ __forceinline__ void abe_accum(Fr (&acc)[3], const Pair &a, const Pair &b, const Fr &e) {
+    acc[0] = fr_add(acc[0], fr_mul(fr_mul(a.lo, b.lo), e));
+    const Fr da = fr_sub(a.hi, a.lo), db = fr_sub(b.hi, b.lo);
+    Fr x = fr_add(a.hi, da), y = fr_add(b.hi, db);
+    acc[1] = fr_add(acc[1], fr_mul(fr_mul(x, y), e));
+    x = fr_add(x, da); y = fr_add(y, db);
+    acc[2] = fr_add(acc[2], fr_mul(fr_mul(x, y), e));
+}
+// kFold: the tables have 4q entries and are folded by r to 2q (pairs (i, i + q)); otherwise they have 2q entries as they are
+template <bool kFold> __global__ __launch_bounds__(kBlock) void k_pc_round(PcList L, size_t q, Fr r, EqSrc E, Mailbox mb, Armed go) {
+    if (kFold && go.want) { Fr v[2]; if (!armed_fetch(go, v)) return; r = v[0]; }
+    Fr *A = L.A[blockIdx.y], *B = L.B[blockIdx.y], *C = L.C[blockIdx.y];
+    Fr acc[3] = {fr_zero(), fr_zero(), fr_zero()};
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < q; i += (size_t)gridDim.x * blockDim.x) {
+        Pair a, b;
+        if (kFold) {
+            const Fr a0 = A[i], a1 = A[i + q], a2 = A[i + 2 * q], a3 = A[i + 3 * q];
+            const Fr b0 = B[i], b1 = B[i + q], b2 = B[i + 2 * q], b3 = B[i + 3 * q];
+            __builtin_amdgcn_sched_barrier(0);
+            a = fold_regs(a0, a1, a2, a3, r); A[i] = a.lo; A[i + q] = a.hi;
+            b = fold_regs(b0, b1, b2, b3, r); B[i] = b.lo; B[i + q] = b.hi;
+        } else { a.lo = A[i]; a.hi = A[i + q]; b.lo = B[i]; b.hi = B[i + q]; }
+        if (C) {
+            Pair c;
+            if (kFold) { const Fr c0 = C[i], c1 = C[i + q], c2 = C[i + 2 * q], c3 = C[i + 3 * q]; c = fold_regs(c0, c1, c2, c3, r); C[i] = c.lo; C[i + q] = c.hi; }
+            else { c.lo = C[i]; c.hi = C[i + q]; }
+            abc_accum(acc, a, b, c);
+        } else abe_accum(acc, a, b, eq_at(E, i));
+    }
+    finish_many(acc, mb);
+}
+static Mailbox pc_mailbox(DevCtx &c, int slot, int nblocks) {
+    if ((size_t)nblocks * 3 > c.partials.n) throw Error(OTTI_ERR_INTERNAL, "round partials exceed the context's buffer");
+    return c.next_mailbox(slot);
+}
+unsigned long long dev_pc_eval(DevCtx &c, const PcList &L, size_t len, const EqSrc &E, int slot) {
+    const size_t half = len / 2; const int g = many_grid(half, L.n); Mailbox mb = pc_mailbox(c, slot, g * L.n);
+    KScope ks(c, KC_SC_CUBIC);
+    hipLaunchKernelGGL(k_pc_round<false>, dim3((unsigned)g, (unsigned)L.n), kBlock, 0, c.stream, L, half, fr_zero(), E, mb, Armed{nullptr, nullptr, 0});
+    return mb.seq;
+}
+unsigned long long dev_pc_fold_eval(DevCtx &c, const PcList &L, size_t len, const Fr *r, const EqSrc &E, int slot) {
+    if (len < 4) throw Error(OTTI_ERR_INTERNAL, "fold_eval needs len >= 4");
+    const size_t q = len / 4; const int g = many_grid(q, L.n); Mailbox mb = pc_mailbox(c, slot, g * L.n);
+    const Armed go = r ? Armed{nullptr, nullptr, 0} : c.arm();
+    KScope ks(c, KC_SC_CUBIC);
+    hipLaunchKernelGGL(k_pc_round<true>, dim3((unsigned)g, (unsigned)L.n), kBlock, 0, c.stream, L, q, r ? *r : fr_zero(), E, mb, go);
+    return mb.seq;
+}
+// tail hand-over: every table of the batch (folded by r when fold is set) into pinned host memory; the flag follows the last workgroup
+__global__ __launch_bounds__(64) void k_pc_export(PcList L, size_t n_out, int fold, Fr r, Mailbox mb, Armed go) {
+    if (go.want) { Fr v[2]; if (!armed_fetch(go, v)) return; r = v[0]; }
+    const Fr *T[3] = {L.A[blockIdx.y], L.B[blockIdx.y], L.C[blockIdx.y]};
+    for (int t = 0; t < 3; t++) {
+        if (!T[t]) continue;
+        Fr *out = mb.host_results + mb.slot + ((size_t)3 * blockIdx.y + t) * n_out;
+        for (size_t i = threadIdx.x; i < n_out; i += blockDim.x) {
+            Fr v = T[t][i];
+            if (fold) v = fr_add(v, fr_mul(r, fr_sub(T[t][i + n_out], v)));
+            out[i] = v;
+        }
+    }
+    __threadfence_system();
+    __syncthreads();
+    __shared__ int s_last;
+    if (threadIdx.x == 0) {
+        unsigned old = __hip_atomic_fetch_add(mb.counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = old == gridDim.y - 1;
+        if (s_last) {
+            __hip_atomic_store(mb.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __threadfence_system();
+            __hip_atomic_store(mb.host_flag, mb.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+unsigned long long dev_pc_export(DevCtx &c, const PcList &L, size_t len, bool fold, const Fr *r, int slot) {
+    const size_t n_out = fold ? len / 2 : len;
+    if (slot + (size_t)3 * L.n * n_out > (size_t)kResultSlots) throw Error(OTTI_ERR_INTERNAL, "sum-check tail does not fit the pinned result buffer");
+    Mailbox mb = c.next_mailbox(slot);
+    const Armed go = (fold && !r) ? c.arm() : Armed{nullptr, nullptr, 0};
+    KScope ks(c, KC_SC_CUBIC);
+    hipLaunchKernelGGL(k_pc_export, dim3(1, (unsigned)L.n), 64, 0, c.stream, L, n_out, fold ? 1 : 0, r ? *r : fr_zero(), mb, go);
+    return mb.seq;
+}
 __global__ __launch_bounds__(kBlock) void k_fold_many(PtrList L, size_t half, Fr r) {
     Fr *Z = L.p[blockIdx.y];
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x) { const Fr a = Z[i], b = Z[i + half]; Z[i] = fr_add(a, fr_mul(r, fr_sub(b, a))); }

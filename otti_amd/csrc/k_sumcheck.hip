@@ -40,7 +40,6 @@ void dev_eq_evals(DevCtx &c, const Fr *r, size_t ell, Fr *out, Fr *scratch) {
 }
 
 // ------------------------------------------------------------------------------------------------ K3/K4/K7 sum-check rounds
-struct Pair { Fr lo, hi; };
 __device__ __forceinline__ void cubic_accum(Fr (&acc)[3], const Pair &a, const Pair &b, const Pair &c, const Pair &d) {
     // comb = A * (B * C - D) at t = 0, 2, 3 with X(2) = 2 X[hi] - X[lo], X(3) = X(2) + X[hi] - X[lo]
     acc[0] = fr_add(acc[0], fr_mul(a.lo, fr_sub(fr_mul(b.lo, c.lo), d.lo)));
@@ -97,9 +96,6 @@ __global__ __launch_bounds__(kBlock) void k_sc_cubic_eval(const Fr *A, const Fr 
     }
     finish_in_kernel<3>(acc, mb);
 }
-__device__ __forceinline__ Pair fold_regs(const Fr &x0, const Fr &x1, const Fr &x2, const Fr &x3, const Fr &r) {
-    Pair p; p.lo = fr_add(x0, fr_mul(r, fr_sub(x2, x0))); p.hi = fr_add(x1, fr_mul(r, fr_sub(x3, x1))); return p;
-}
 __global__ __launch_bounds__(kBlock) void k_sc_cubic_fold_eval(Fr *A, Fr *B, Fr *C, Fr *D, size_t q, Fr r, Mailbox mb) {
     Fr acc[3] = {fr_zero(), fr_zero(), fr_zero()};
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < q; i += (size_t)gridDim.x * blockDim.x) {
@@ -124,10 +120,6 @@ __global__ __launch_bounds__(kBlock) void k_sc_cubic_fold_eval(Fr *A, Fr *B, Fr 
 // S_t = sum_i E_j[i] * (A_t[i] B_t[i] - C_t[i]); the kernels below return S_t (three tables instead of four: a quarter less HBM
 // traffic and register pressure), the host applies the two scalar factors.  E_j[i] itself is hi[i >> lo_bits] * lo[i & mask] from the
 // two small "pyramids" of k_eq_pyramid (L2-resident), or lo[i] once at most lo_bits variables are left.
-__device__ __forceinline__ Fr eq_at(const EqSrc &e, size_t i) {
-    if (!e.hi) return e.lo[i];
-    return fr_mul(e.hi[i >> e.lo_bits], e.lo[i & (((size_t)1 << e.lo_bits) - 1)]);
-}
 __device__ __forceinline__ void cubic3_accum(Fr (&acc)[3], const Fr &e, const Pair &b, const Pair &c, const Pair &d) {
     acc[0] = fr_add(acc[0], fr_mul(e, fr_sub(fr_mul(b.lo, c.lo), d.lo)));
     Fr db = fr_sub(b.hi, b.lo), dc = fr_sub(c.hi, c.lo), dd = fr_sub(d.hi, d.lo);
@@ -147,7 +139,8 @@ __global__ __launch_bounds__(kBlock, 4) void k_sc_cubic3_eval(const Fr *B, const
     }
     finish_in_kernel<3>(acc, mb);
 }
-__global__ __launch_bounds__(kBlock) void k_sc_cubic3_fold_eval(Fr *B, Fr *C, Fr *D, size_t q, Fr r, EqSrc E, Mailbox mb) {
+__global__ __launch_bounds__(kBlock) void k_sc_cubic3_fold_eval(Fr *B, Fr *C, Fr *D, size_t q, Fr r, EqSrc E, Mailbox mb, Armed go) {
+    if (go.want) { Fr v[2]; if (!armed_fetch(go, v)) return; r = v[0]; }
     Fr acc[3] = {fr_zero(), fr_zero(), fr_zero()};
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < q; i += (size_t)gridDim.x * blockDim.x) {
         Fr b0 = B[i], b1 = B[i + q], b2 = B[i + 2 * q], b3 = B[i + 3 * q];
@@ -185,7 +178,8 @@ __global__ __launch_bounds__(kBlock) void k_sc_quad_eval(const Fr *A, const Fr *
     }
     finish_in_kernel<2>(acc, mb);
 }
-__global__ __launch_bounds__(kBlock) void k_sc_quad_fold_eval(Fr *A, Fr *B, size_t q, Fr r, Mailbox mb) {
+__global__ __launch_bounds__(kBlock) void k_sc_quad_fold_eval(Fr *A, Fr *B, size_t q, Fr r, Mailbox mb, Armed go) {
+    if (go.want) { Fr v[2]; if (!armed_fetch(go, v)) return; r = v[0]; }
     Fr acc[2] = {fr_zero(), fr_zero()};
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < q; i += (size_t)gridDim.x * blockDim.x) {
         Fr a0 = A[i], a1 = A[i + q], a2 = A[i + 2 * q], a3 = A[i + 3 * q];
@@ -236,23 +230,29 @@ unsigned long long dev_sc_cubic3_eval(DevCtx &c, const Fr *B, const Fr *C, const
     KScope ks(c, KC_SC_CUBIC); hipLaunchKernelGGL(k_sc_cubic3_eval, g, kBlock, 0, c.stream, B, C, D, half, E, mb);
     return mb.seq;
 }
-unsigned long long dev_sc_cubic3_fold_eval(DevCtx &c, Fr *B, Fr *C, Fr *D, size_t len, const Fr &r, const EqSrc &E, int slot) {
+static unsigned long long cubic3_fold_eval(DevCtx &c, Fr *B, Fr *C, Fr *D, size_t len, const Fr *r, const EqSrc &E, int slot) {
     if (len < 4) throw Error(OTTI_ERR_INTERNAL, "fold_eval needs len >= 4");
     size_t q = len / 4; int g = sc_grid(q); Mailbox mb = c.next_mailbox(slot);
-    KScope ks(c, KC_SC_CUBIC); hipLaunchKernelGGL(k_sc_cubic3_fold_eval, g, kBlock, 0, c.stream, B, C, D, q, r, E, mb);
+    const Armed go = r ? Armed{nullptr, nullptr, 0} : c.arm();
+    KScope ks(c, KC_SC_CUBIC); hipLaunchKernelGGL(k_sc_cubic3_fold_eval, g, kBlock, 0, c.stream, B, C, D, q, r ? *r : fr_zero(), E, mb, go);
     return mb.seq;
 }
+unsigned long long dev_sc_cubic3_fold_eval(DevCtx &c, Fr *B, Fr *C, Fr *D, size_t len, const Fr &r, const EqSrc &E, int slot) { return cubic3_fold_eval(c, B, C, D, len, &r, E, slot); }
+unsigned long long dev_sc_cubic3_fold_eval_armed(DevCtx &c, Fr *B, Fr *C, Fr *D, size_t len, const EqSrc &E, int slot) { return cubic3_fold_eval(c, B, C, D, len, nullptr, E, slot); }
 unsigned long long dev_sc_quad_eval(DevCtx &c, const Fr *A, const Fr *B, size_t len, int slot) {
     size_t half = len / 2; int g = sc_grid(half); Mailbox mb = c.next_mailbox(slot);
     KScope ks(c, KC_SC_QUAD); hipLaunchKernelGGL(k_sc_quad_eval, g, kBlock, 0, c.stream, A, B, half, mb);
     return mb.seq;
 }
-unsigned long long dev_sc_quad_fold_eval(DevCtx &c, Fr *A, Fr *B, size_t len, const Fr &r, int slot) {
+static unsigned long long quad_fold_eval(DevCtx &c, Fr *A, Fr *B, size_t len, const Fr *r, int slot) {
     if (len < 4) throw Error(OTTI_ERR_INTERNAL, "fold_eval needs len >= 4");
     size_t q = len / 4; int g = sc_grid(q); Mailbox mb = c.next_mailbox(slot);
-    KScope ks(c, KC_SC_QUAD); hipLaunchKernelGGL(k_sc_quad_fold_eval, g, kBlock, 0, c.stream, A, B, q, r, mb);
+    const Armed go = r ? Armed{nullptr, nullptr, 0} : c.arm();
+    KScope ks(c, KC_SC_QUAD); hipLaunchKernelGGL(k_sc_quad_fold_eval, g, kBlock, 0, c.stream, A, B, q, r ? *r : fr_zero(), mb, go);
     return mb.seq;
 }
+unsigned long long dev_sc_quad_fold_eval(DevCtx &c, Fr *A, Fr *B, size_t len, const Fr &r, int slot) { return quad_fold_eval(c, A, B, len, &r, slot); }
+unsigned long long dev_sc_quad_fold_eval_armed(DevCtx &c, Fr *A, Fr *B, size_t len, int slot) { return quad_fold_eval(c, A, B, len, nullptr, slot); }
 void dev_fold_top(DevCtx &c, Fr *Z, size_t len, const Fr &r) { size_t h = len / 2; if (h) hipLaunchKernelGGL(k_fold_top, grid_for(h), kBlock, 0, c.stream, Z, h, r); }
 void dev_fold_bot(DevCtx &c, const Fr *Z, Fr *out, size_t len, const Fr &r) { size_t h = len / 2; if (h) hipLaunchKernelGGL(k_fold_bot, grid_for(h), kBlock, 0, c.stream, Z, out, h, r); }
 

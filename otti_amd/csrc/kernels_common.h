@@ -49,6 +49,49 @@ __device__ __forceinline__ bool arrive_and_check_last(unsigned *counter, unsigne
     return s_is_last != 0;
 }
 
+// ------------------------------------------------------------------------------------------------ armed launches (device.h)
+// Every workgroup calls this first.  Workgroup (0,0) waits for the host's value in pinned memory and republishes it in HBM, the others
+// wait for that copy.  Returns false in every thread of the workgroup when the launch was aborted or a deadline passed: the kernel then
+// returns at once.
+__device__ __forceinline__ bool armed_fetch(const Armed &a, Fr (&v)[2]) {
+    __shared__ Fr s_v[2]; __shared__ int s_ok;
+    if (threadIdx.x == 0) {
+        const bool leader = (blockIdx.x | blockIdx.y | blockIdx.z) == 0;
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime(), abort_bit = 1ull << 63, deadline = 300000000ull;   // 100 MHz
+        int ok = -1;
+        Fr t[2] = {fr_zero(), fr_zero()};
+        if (leader) {
+            while (ok < 0) {
+                const unsigned long long s = __hip_atomic_load(&a.host->seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (s == a.want) ok = 1;
+                else if (s == ~0ull || __builtin_amdgcn_s_memrealtime() - t0 > deadline) ok = 0;
+                else __builtin_amdgcn_s_sleep(2);
+            }
+            if (ok) {
+                for (int k = 0; k < 2; k++) {
+                    const unsigned long long *src = reinterpret_cast<const unsigned long long *>(&a.host->v[k]);
+                    for (int i = 0; i < 4; i++) { const unsigned long long w = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); t[k].v[2 * i] = (uint32_t)w; t[k].v[2 * i + 1] = (uint32_t)(w >> 32); }
+                    store_words_sc1(&a.dev->v[k], t[k].v, 8);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(&a.dev->seq, ok ? a.want : (a.want | abort_bit), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            while (ok < 0) {
+                const unsigned long long s = __hip_atomic_load(&a.dev->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (s == a.want) ok = 1;
+                else if (s == (a.want | abort_bit) || __builtin_amdgcn_s_memrealtime() - t0 > deadline) ok = 0;
+                else __builtin_amdgcn_s_sleep(1);
+            }
+            if (ok) for (int k = 0; k < 2; k++) load_words_sc1(t[k].v, &a.dev->v[k], 8);
+        }
+        s_v[0] = t[0]; s_v[1] = t[1]; s_ok = ok;
+    }
+    __syncthreads();
+    v[0] = s_v[0]; v[1] = s_v[1];
+    return s_ok != 0;
+}
+
 // ------------------------------------------------------------------------------------------------ wave / block reductions of Fr
 __device__ __forceinline__ Fr shfl_xor_fr(const Fr &x, int mask) {
     Fr r;
@@ -79,5 +122,16 @@ template <int K> __global__ __launch_bounds__(kBlock) void k_reduce_partials(con
     if (threadIdx.x == 0) for (int k = 0; k < K; k++) out[k] = acc[k];
 }
 
+// ------------------------------------------------------------------------------------------------ shared by the sum-check kernels
+struct Pair { Fr lo, hi; };
+// entries (i, i + q) of a table of length 4q folded by r (bound_poly_var_top): the pair i of the folded table
+__device__ __forceinline__ Pair fold_regs(const Fr &x0, const Fr &x1, const Fr &x2, const Fr &x3, const Fr &r) {
+    Pair p; p.lo = fr_add(x0, fr_mul(r, fr_sub(x2, x0))); p.hi = fr_add(x1, fr_mul(r, fr_sub(x3, x1))); return p;
+}
+// eq table given as the tensor product of two small tables (k_eq_pyramid levels), or as one table once few variables are left
+__device__ __forceinline__ Fr eq_at(const EqSrc &e, size_t i) {
+    if (!e.hi) return e.lo[i];
+    return fr_mul(e.hi[i >> e.lo_bits], e.lo[i & (((size_t)1 << e.lo_bits) - 1)]);
+}
 
 }  // namespace otti

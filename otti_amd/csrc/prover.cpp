@@ -288,6 +288,7 @@ void r1cs_prove_device(Instance &I, DeviceWitness &wit, Gens &g, Transcript &tr,
     c.ensure_points(std::max(Lsz, 4 * (nrx + nry)), 2 * std::max<size_t>(1, Rsz / 256));   // every MSM result buffer of this proof, before the first launch
     const Fr *d_vars = wit.z.p, *my_rows = d_vars + rk * Ll * Rsz;         // this rank's block of witness-matrix rows
 
+    struct Release { DevCtx &c; ~Release() { c.go_abort(); } } release{c};      // an exception must not leave an armed kernel waiting
     SumcheckState early1, early2; RoundPointsJob round_points;       // tape-only parts of both sum-checks, started during polycommit
     tr.append_protocol_name("R1CS proof");
 
@@ -388,8 +389,22 @@ void r1cs_prove_device(Instance &I, DeviceWitness &wit, Gens &g, Transcript &tr,
             for (auto &x : tail1[0]) x = fr_mul(x, cj);
             tail_built = true;
         };
-        unsigned long long ticket = dev_sc_cubic3_eval(c, S.T[1].p, S.T[2].p, S.T[3].p, Nl, eq_src(s_loc - 1), 0);
-        if (ndev == 0) fetch_tail();
+        // fold launch k (1..ndev) folds the tables of length Nl >> (k-1) by r_{k-1} and sums round k.  Armed (device.h), it is queued a
+        // round ahead and starts the moment the host publishes r_{k-1}; otherwise it is launched once r_{k-1} is known.
+        // Only launches of at most 64 workgroups are armed: those rounds are pure latency, and a waiting grid that small leaves the chip to
+        // the other proofs in flight (and to the other ranks when several share one GPU).
+        const bool arm_ok = c.armed_ok() && T1 >= 2;
+        auto armed = [&](size_t k) { return arm_ok && k >= 1 && k <= ndev && (Nl >> (k - 1)) <= kArmMaxLen; };
+        std::vector<unsigned long long> tk(ndev + 2, 0);
+        auto fold_launch = [&](size_t k, const Fr *r) {
+            const size_t len = Nl >> (k - 1);
+            if (len >= 4) tk[k] = r ? dev_sc_cubic3_fold_eval(c, S.T[1].p, S.T[2].p, S.T[3].p, len, *r, eq_src(s_loc - k - 1), 0)
+                                    : dev_sc_cubic3_fold_eval_armed(c, S.T[1].p, S.T[2].p, S.T[3].p, len, eq_src(s_loc - k - 1), 0);
+            else for (int t = 1; t < 4; t++) dev_fold_top(c, S.T[t].p, len, *r);
+            if (k == ndev) fetch_tail();
+        };
+        tk[0] = dev_sc_cubic3_eval(c, S.T[1].p, S.T[2].p, S.T[3].p, Nl, eq_src(s_loc - 1), 0);
+        if (ndev == 0) fetch_tail(); else if (armed(1)) fold_launch(1, nullptr);
         const Fr one = fr_one();
         double tw = 0, tb = 0, tl = 0, tf = 0, ta;
         for (size_t j = 0; j < nrx; j++) {
@@ -397,7 +412,7 @@ void r1cs_prove_device(Instance &I, DeviceWitness &wit, Gens &g, Transcript &tr,
             ta = now_ms();
             if (j >= dsum && !tail_built) build_tail();
             if (j < dsum) {
-                c.wait_ticket(ticket);
+                c.wait_ticket(tk[j]);
                 e[0] = c.h_results[0]; e[1] = c.h_results[1]; e[2] = c.h_results[2];       // S_t = sum_i E_j[i] (Az_t Bz_t - Cz_t)[i], t = 0, 2, 3
                 if (sh) { for (auto &x : e) x = fr_mul(x, eq_ranks[rk]); sh->allreduce_fr(e, 3); }   // per-round exchange: 96 bytes per rank
                 // e_t = c_j * w_t * S_t with w_t = (1 - tau_j) + t (2 tau_j - 1): the eq factor of the variable bound in this round
@@ -411,10 +426,8 @@ void r1cs_prove_device(Instance &I, DeviceWitness &wit, Gens &g, Transcript &tr,
             tb += now_ms() - ta; ta = now_ms();
             P.rx[j] = p1.r_j;
             if (j < ndev) {
-                const size_t len = Nl >> j;
-                if (len >= 4) ticket = dev_sc_cubic3_fold_eval(c, S.T[1].p, S.T[2].p, S.T[3].p, len, p1.r_j, eq_src(s_loc - j - 2), 0);
-                else for (int k = 1; k < 4; k++) dev_fold_top(c, S.T[k].p, len, p1.r_j);
-                if (j + 1 == ndev) fetch_tail();
+                if (armed(j + 1)) c.go(&p1.r_j, 1); else fold_launch(j + 1, &p1.r_j);
+                if (armed(j + 2)) fold_launch(j + 2, nullptr);
                 // eq(tau_j, r_j) = tau_j r_j + (1 - tau_j)(1 - r_j)
                 cj = fr_mul(cj, fr_add(fr_mul(tau[j], p1.r_j), fr_mul(fr_sub(one, tau[j]), fr_sub(one, p1.r_j))));
             }
@@ -488,13 +501,22 @@ void r1cs_prove_device(Instance &I, DeviceWitness &wit, Gens &g, Transcript &tr,
             }
             tail_built = true;
         };
-        unsigned long long ticket = dev_sc_quad_eval(c, S.zw.p, S.ABC.p, V2l, 0);
-        if (ndev == 0) fetch_tail();
+        const bool arm_ok = c.armed_ok() && T2 >= 2;
+        auto armed = [&](size_t k) { return arm_ok && k >= 1 && k <= ndev && (V2l >> (k - 1)) <= kArmMaxLen; };
+        std::vector<unsigned long long> tk(ndev + 2, 0);
+        auto fold_launch = [&](size_t k, const Fr *r) {                     // as in phase one
+            const size_t len = V2l >> (k - 1);
+            if (len >= 4) tk[k] = r ? dev_sc_quad_fold_eval(c, S.zw.p, S.ABC.p, len, *r, 0) : dev_sc_quad_fold_eval_armed(c, S.zw.p, S.ABC.p, len, 0);
+            else { dev_fold_top(c, S.zw.p, len, *r); dev_fold_top(c, S.ABC.p, len, *r); }
+            if (k == ndev) fetch_tail();
+        };
+        tk[0] = dev_sc_quad_eval(c, S.zw.p, S.ABC.p, V2l, 0);
+        if (ndev == 0) fetch_tail(); else if (armed(1)) fold_launch(1, nullptr);
         for (size_t j = 0; j < nry; j++) {
             Fr e[2];
             if (j >= dsum && !tail_built) build_tail();
             if (j < dsum) {
-                c.wait_ticket(ticket);
+                c.wait_ticket(tk[j]);
                 e[0] = c.h_results[0]; e[1] = c.h_results[1];
                 if (sh) sh->allreduce_fr(e, 2);
             } else host_quad_evals(tail2, e);
@@ -502,10 +524,8 @@ void r1cs_prove_device(Instance &I, DeviceWitness &wit, Gens &g, Transcript &tr,
             RoundPart1 p1 = sumcheck_round_begin(P.sc2, j, ev, 3, st, g, g.sc_3, tr);
             P.ry[j] = p1.r_j;
             if (j < ndev) {
-                const size_t len = V2l >> j;
-                if (len >= 4) ticket = dev_sc_quad_fold_eval(c, S.zw.p, S.ABC.p, len, p1.r_j, 0);
-                else { dev_fold_top(c, S.zw.p, len, p1.r_j); dev_fold_top(c, S.ABC.p, len, p1.r_j); }
-                if (j + 1 == ndev) fetch_tail();
+                if (armed(j + 1)) c.go(&p1.r_j, 1); else fold_launch(j + 1, &p1.r_j);
+                if (armed(j + 2)) fold_launch(j + 2, nullptr);
             }
             sumcheck_round_finish(P.sc2, j, p1, st, g, g.sc_3, tr);
             if (j >= ndev && !tail_built) build_tail();

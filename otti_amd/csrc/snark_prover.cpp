@@ -123,54 +123,130 @@ struct Circuits {
 struct DotpTables { Fr *l[6], *r[6], *w[6]; size_t len = 0; int n = 0; };
 
 // ProductCircuitEvalProofBatched::prove.  evals: the circuits' outputs (already known to the caller).  The tables are folded in place.
+//
+// One layer = one SumcheckInstanceProof::prove_cubic_batched over (left, right, eq(rand)) of every circuit (+ the dot-product triples at
+// the input layer).  Per round ONE launch (k_pc_round: fold by the previous challenge + this round's sums, mailed to the host by the
+// last workgroup).  The eq table is never stored: eq(rand, .) is a tensor product, so after j rounds it is
+//   c_j * (b ? rand_j : 1 - rand_j) * E_j[i],  E_j = eq(rand[j+1..), .),  c_j = prod_{k<j} eq(rand_k, r_k)
+// (two L2-resident pyramids of small tables, as phase one of the R1CS proof); the kernel returns S_t = sum_i E_j[i] (A_t B_t)[i] and the
+// host applies c_j * ((1 - rand_j) + t (2 rand_j - 1)).  Once the tables are down to T elements they are exported to pinned memory and
+// the host plays the last rounds itself: a launch + hand-off costs more than the arithmetic of such a round on a host core.
+constexpr int kPcTailSlot = 128;
 ProductCircuitEvalProofBatched pcbatch_prove(DevCtx &c, Circuits &C, const std::vector<Fr> &evals, DotpTables *D, const std::vector<Fr> &dotp_evals, Transcript &tr,
-                                             Fr *eq_buf, Fr *eq_scratch, Fr *partials, std::vector<Fr> &rand_out) {
+                                             Fr *pyr, std::vector<Fr> &rand_out) {
     const int np = C.count; const size_t nl = C.nl;
     ProductCircuitEvalProofBatched pf; pf.layers.resize(nl);
     std::vector<Fr> claims = evals, rand, rprod;
+    const Fr one = fr_one();
+    struct Release { DevCtx &c; ~Release() { c.go_abort(); } } release{c};      // an exception below must not leave an armed kernel waiting
     for (size_t li = 0; li < nl; li++) {
-        const size_t layer_id = nl - 1 - li, h = (size_t)1 << rand.size();       // elements per side in this layer
+        const size_t layer_id = nl - 1 - li, nr = rand.size(), h = (size_t)1 << nr;      // elements per side in this layer, one round per variable
         const bool with_dotp = layer_id == 0 && D && D->n;
         if (with_dotp) { if (D->len != h) throw Error(OTTI_ERR_INTERNAL, "dot-product circuits do not match the input layer"); claims.insert(claims.end(), dotp_evals.begin(), dotp_evals.end()); }
-        dev_eq_evals(c, rand.data(), rand.size(), eq_buf, eq_scratch);           // poly_C_par = EqPolynomial(rand).evals()
+        PcList P; P.n = 0;
+        for (int i = 0; i < np; i++) { P.A[P.n] = C.left(i, layer_id); P.B[P.n] = C.right(i, layer_id); P.C[P.n] = nullptr; P.n++; }
+        if (with_dotp) for (int i = 0; i < D->n; i++) { P.A[P.n] = D->l[i]; P.B[P.n] = D->r[i]; P.C[P.n] = D->w[i]; P.n++; }
+        const int ni = P.n;
+        const size_t lgT = std::min<size_t>(nr, ni >= 8 ? 4 : 5), T = (size_t)1 << lgT, ndev = nr - lgT;
+        // eq(rand, .) on the device: pyramids over the last n_lo variables and the n_hi before them
+        const size_t n_lo = std::min<size_t>(nr, 12), n_hi = nr - n_lo;
+        if (n_hi > 13) throw Error(OTTI_ERR_BAD_ARG, "product circuit over more than 2^25 elements");
+        Fr *pyr_lo = pyr, *pyr_hi = pyr + 8192;
+        if (ndev) { dev_eq_pyramid(c, rand.data() + n_hi, n_lo, pyr_lo); if (n_hi) dev_eq_pyramid(c, rand.data(), n_hi, pyr_hi); }
+        auto eq_src = [&](size_t m) {
+            EqSrc e;
+            if (m <= n_lo) { e.hi = nullptr; e.lo = pyr_lo + (((size_t)1 << m) - 1); e.lo_bits = 0; }
+            else { e.hi = pyr_hi + (((size_t)1 << (m - n_lo)) - 1); e.lo = pyr_lo + (((size_t)1 << n_lo) - 1); e.lo_bits = (int)n_lo; }
+            return e;
+        };
+        // launch k >= 1 folds by r_{k-1} and yields the sums of round k (k < ndev) or the exported tail (k == ndev).  Armed (device.h), it is
+        // queued one round ahead and starts the moment the host publishes r_{k-1}.
+        const bool arm_ok = c.armed_ok();
+        auto armed = [&](size_t k) { return arm_ok && k >= 1 && k <= ndev && (h >> (k - 1)) * (size_t)ni <= kArmMaxLen; };   // small grids only (device.h)
+        std::vector<unsigned long long> tick(ndev + 2, 0);
+        auto launch_for = [&](size_t k, const Fr *r) {
+            const size_t len_in = h >> (k - 1);
+            tick[k] = k < ndev ? dev_pc_fold_eval(c, P, len_in, r, eq_src(nr - k - 1), kSumSlot) : dev_pc_export(c, P, len_in, true, r, kPcTailSlot);
+        };
+        if (ndev) { tick[0] = dev_pc_eval(c, P, h, eq_src(nr - 1), kSumSlot); if (armed(1)) launch_for(1, nullptr); }
+        else tick[0] = dev_pc_export(c, P, h, false, nullptr, kPcTailSlot);
         std::vector<Fr> coeff = tr.challenge_vector("rand_coeffs_next_layer", claims.size());
         Fr e = fr_zero(); for (size_t k = 0; k < claims.size(); k++) e = fr_add(e, fr_mul(claims[k], coeff[k]));
-        AbcList A; PtrList F; A.n = 0; F.n = 0;
-        for (int i = 0; i < np; i++) { A.A[A.n] = C.left(i, layer_id); A.B[A.n] = C.right(i, layer_id); A.C[A.n] = eq_buf; A.n++; F.p[F.n++] = C.left(i, layer_id); F.p[F.n++] = C.right(i, layer_id); }
-        F.p[F.n++] = eq_buf;
-        if (with_dotp) for (int i = 0; i < D->n; i++) { A.A[A.n] = D->l[i]; A.B[A.n] = D->r[i]; A.C[A.n] = D->w[i]; A.n++; F.p[F.n++] = D->l[i]; F.p[F.n++] = D->r[i]; F.p[F.n++] = D->w[i]; }
         LayerProofBatched &L = pf.layers[li];
         rprod.clear();
+        std::vector<std::vector<Fr>> tA(ni), tB(ni), tC(ni); std::vector<Fr> tE; bool tail_built = false;   // host tail: T elements per table
+        Fr cj = one;
         size_t len = h;
-        for (size_t j = 0; j < rand.size(); j++) {           // SumcheckInstanceProof::prove_cubic_batched
-            const size_t half = len / 2;
-            dev_abc_evals(c, A, half, partials, kSumSlot);
-            c.sync();
+        for (size_t j = 0; j < nr; j++) {                    // SumcheckInstanceProof::prove_cubic_batched
             Fr c0 = fr_zero(), c2 = fr_zero(), c3 = fr_zero();
-            for (int k = 0; k < A.n; k++) {
-                const Fr *ev = &c.h_results[kSumSlot + 3 * k];
-                c0 = fr_add(c0, fr_mul(ev[0], coeff[k])); c2 = fr_add(c2, fr_mul(ev[1], coeff[k])); c3 = fr_add(c3, fr_mul(ev[2], coeff[k]));
+            if (j < ndev) {
+                c.wait_ticket(tick[j]);
+                const Fr &tau = rand[j];
+                const Fr w0 = fr_sub(one, tau), dw = fr_sub(fr_add(tau, tau), one), w2 = fr_add(w0, fr_add(dw, dw)), w3 = fr_add(w2, dw);
+                const Fr f0 = fr_mul(cj, w0), f2 = fr_mul(cj, w2), f3 = fr_mul(cj, w3);
+                Fr p0 = fr_zero(), p2 = fr_zero(), p3 = fr_zero();                  // the product circuits share the eq factor
+                for (int k = 0; k < ni; k++) {
+                    const Fr *ev = &c.h_results[kSumSlot + 3 * k];
+                    Fr &a0 = k < np ? p0 : c0, &a2 = k < np ? p2 : c2, &a3 = k < np ? p3 : c3;
+                    a0 = fr_add(a0, fr_mul(ev[0], coeff[k])); a2 = fr_add(a2, fr_mul(ev[1], coeff[k])); a3 = fr_add(a3, fr_mul(ev[2], coeff[k]));
+                }
+                c0 = fr_add(c0, fr_mul(f0, p0)); c2 = fr_add(c2, fr_mul(f2, p2)); c3 = fr_add(c3, fr_mul(f3, p3));
+            } else {
+                if (!tail_built) {
+                    c.wait_ticket(tick[ndev]);
+                    for (int k = 0; k < ni; k++) {
+                        const Fr *base = &c.h_results[kPcTailSlot + (size_t)3 * k * T];
+                        tA[k].assign(base, base + T); tB[k].assign(base + T, base + 2 * T);
+                        if (k >= np) tC[k].assign(base + 2 * T, base + 3 * T);
+                    }
+                    tE = eq_evals_host(rand.data() + ndev, nr - ndev);
+                    for (auto &x : tE) x = fr_mul(x, cj);
+                    tail_built = true;
+                }
+                const size_t half = len / 2;
+                for (int k = 0; k < ni; k++) {
+                    const std::vector<Fr> &A = tA[k], &B = tB[k], &Cc = k < np ? tE : tC[k];
+                    Fr s0 = fr_zero(), s2 = fr_zero(), s3 = fr_zero();
+                    for (size_t i = 0; i < half; i++) {
+                        const Fr da = fr_sub(A[i + half], A[i]), db = fr_sub(B[i + half], B[i]), dc = fr_sub(Cc[i + half], Cc[i]);
+                        s0 = fr_add(s0, fr_mul(fr_mul(A[i], B[i]), Cc[i]));
+                        Fr x = fr_add(A[i + half], da), y = fr_add(B[i + half], db), z = fr_add(Cc[i + half], dc);
+                        s2 = fr_add(s2, fr_mul(fr_mul(x, y), z));
+                        x = fr_add(x, da); y = fr_add(y, db); z = fr_add(z, dc);
+                        s3 = fr_add(s3, fr_mul(fr_mul(x, y), z));
+                    }
+                    c0 = fr_add(c0, fr_mul(s0, coeff[k])); c2 = fr_add(c2, fr_mul(s2, coeff[k])); c3 = fr_add(c3, fr_mul(s3, coeff[k]));
+                }
             }
             Fr evals4[4] = {c0, fr_sub(e, c0), c2, c3}, poly[4];
             unipoly_from_evals(poly, evals4, 4);
             append_unipoly(tr, poly, 4);
             const Fr r_j = tr.challenge_scalar("challenge_nextround");
             rprod.push_back(r_j);
-            dev_fold_many(c, F, half, r_j);
+            if (j < ndev) {
+                if (armed(j + 1)) c.go(&r_j, 1); else launch_for(j + 1, &r_j);
+                if (armed(j + 2)) launch_for(j + 2, nullptr);
+            }
+            if (j < ndev) cj = fr_mul(cj, fr_add(fr_mul(rand[j], r_j), fr_mul(fr_sub(one, rand[j]), fr_sub(one, r_j))));
+            else {
+                const size_t half = len / 2;
+                auto fold = [&](std::vector<Fr> &t) { for (size_t i = 0; i < half; i++) t[i] = fr_add(t[i], fr_mul(r_j, fr_sub(t[i + half], t[i]))); t.resize(half); };
+                for (int k = 0; k < ni; k++) { fold(tA[k]); fold(tB[k]); if (k >= np) fold(tC[k]); }
+                fold(tE);
+            }
             e = unipoly_eval(poly, 4, r_j);
             L.coeffs.push_back(poly[0]); L.coeffs.push_back(poly[2]); L.coeffs.push_back(poly[3]);      // UniPoly::compress
-            len = half;
+            len /= 2;
+        }
+        if (!tail_built) {                                   // a layer without rounds: the tables are single elements
+            c.wait_ticket(tick[0]);
+            for (int k = 0; k < ni; k++) { const Fr *base = &c.h_results[kPcTailSlot + (size_t)3 * k * T]; tA[k].assign(base, base + 1); tB[k].assign(base + T, base + T + 1); if (k >= np) tC[k].assign(base + 2 * T, base + 2 * T + 1); }
         }
         // the tables' last elements: claims_prod (left, right per circuit; the eq table's is not sent), then the dot-product triples
-        PtrList pick; pick.n = 0;
-        for (int i = 0; i < np; i++) { pick.p[pick.n++] = C.left(i, layer_id); pick.p[pick.n++] = C.right(i, layer_id); }
-        if (with_dotp) for (int i = 0; i < D->n; i++) { pick.p[pick.n++] = D->l[i]; pick.p[pick.n++] = D->r[i]; pick.p[pick.n++] = D->w[i]; }
-        dev_pick0(c, pick, kSumSlot);
-        c.sync();
         L.left.resize(np); L.right.resize(np);
-        for (int i = 0; i < np; i++) { L.left[i] = c.h_results[kSumSlot + 2 * i]; L.right[i] = c.h_results[kSumSlot + 2 * i + 1]; tr.append_scalar("claim_prod_left", L.left[i]); tr.append_scalar("claim_prod_right", L.right[i]); }
+        for (int i = 0; i < np; i++) { L.left[i] = tA[i][0]; L.right[i] = tB[i][0]; tr.append_scalar("claim_prod_left", L.left[i]); tr.append_scalar("claim_prod_right", L.right[i]); }
         if (with_dotp) for (int i = 0; i < D->n; i++) {
-            const Fr *t = &c.h_results[kSumSlot + 2 * np + 3 * i];
+            const Fr t[3] = {tA[np + i][0], tB[np + i][0], tC[np + i][0]};
             pf.dotp_left.push_back(t[0]); pf.dotp_right.push_back(t[1]); pf.dotp_weight.push_back(t[2]);
             tr.append_scalar("claim_dotp_left", t[0]); tr.append_scalar("claim_dotp_right", t[1]); tr.append_scalar("claim_dotp_weight", t[2]);
         }
@@ -209,9 +285,12 @@ std::vector<uint8_t> snark_prove_gpu(Instance &I, CompComm &comm, const uint8_t 
     if (!comm.dec) throw Error(OTTI_ERR_BAD_ARG, "this computation commitment carries no decommitment (it was parsed from bytes): SNARK::prove needs the one SNARK::encode returned");
     if (I.num_cons != comm.num_cons || I.num_vars != comm.num_vars || I.num_inputs != comm.num_inputs) throw Error(OTTI_ERR_BAD_ARG, "commitment belongs to another instance");
     const double t_start = now_ms(); SnarkTimings T{}; double t0;
+    const bool trace = getenv("OTTI_TRACE") != nullptr; double t_lap = now_ms();
+    auto lap = [&](const char *what) { if (!trace) return; c.sync(); const double t = now_ms(); fprintf(stderr, "[otti] snark_prove %-34s %.3f ms\n", what, t - t_lap); t_lap = t; };
     ensure_gens_device(*g.eval);
     const DeviceDecomm &d = *comm.dec; const size_t N = d.N, M = d.M, H = N / 2;
     DeviceWitness wit(I, vars32, nvars, inputs);
+    lap("witness upload");
     Transcript tr(tlabel, tlabel_len);
     RandomTape tape(seed32);
     SnarkProof S;
@@ -219,6 +298,7 @@ std::vector<uint8_t> snark_prove_gpu(Instance &I, CompComm &comm, const uint8_t 
     snark_append_comm(tr, comm);
     { ProveTimings pt{}; r1cs_prove_device(I, wit, *g.sat, tr, tape, S.r1cs, pt, nullptr); for (int k = 0; k < 6; k++) T.ms[k] = pt.ms[k]; }
     instance_evaluate_gpu(I, S.r1cs.rx, S.r1cs.ry, S.inst_evals);                // inst.evaluate(rx, ry)
+    lap("r1cs proof + inst.evaluate");
     tr.append_scalar("Ar_claim", S.inst_evals[0]); tr.append_scalar("Br_claim", S.inst_evals[1]); tr.append_scalar("Cr_claim", S.inst_evals[2]);
 
     // ---- R1CSEvalProof::prove -> SparseMatPolyEvalProof::prove
@@ -237,11 +317,14 @@ std::vector<uint8_t> snark_prove_gpu(Instance &I, CompComm &comm, const uint8_t 
     OTTI_HIP(hipMemsetAsync(derefs.p + 6 * N, 0, 2 * N * sizeof(Fr), c.stream));
     auto drow = [&](int k) { return derefs.p + (size_t)k * N; };
     auto dcol = [&](int k) { return derefs.p + (size_t)(3 + k) * N; };
+    lap("allocations, eq tables");
     for (int k = 0; k < 3; k++) { dev_gather(c, mem_rx.p, d.row_addr[k].p, drow(k), N); dev_gather(c, mem_ry.p, d.col_addr[k].p, dcol(k), N); }
+    lap("deref gathers");
     E.comm_derefs = commit_poly(c, *g.eval, derefs.p, g.derefs);
     tr.append_message("derefs_commitment", "begin_derefs_commitment", 23);
     append_poly_commitment(tr, "comm_poly_row_col_ops_val", E.comm_derefs);
     tr.append_message("derefs_commitment", "end_derefs_commitment", 21);
+    lap("derefs commitment");
     T.ms[6] = now_ms() - t0;
 
     t0 = now_ms();
@@ -249,13 +332,16 @@ std::vector<uint8_t> snark_prove_gpu(Instance &I, CompComm &comm, const uint8_t 
     // PolyEvalNetwork::new: hash layers -> product circuits.  ops: row reads A,B,C; row writes; col reads; col writes.  mem: row init, row audit, col init, col audit.
     Circuits ops, mem;
     ops.init(12, N); mem.init(4, M);
+    lap("circuit allocations");
     for (int k = 0; k < 3; k++) {
         dev_hash_ops(c, d.part(0, k), drow(k), d.part(1, k), ops.input(k), ops.input(3 + k), N, r_mem_check[0], r_mem_check[1]);
         dev_hash_ops(c, d.part(2, k), dcol(k), d.part(3, k), ops.input(6 + k), ops.input(9 + k), N, r_mem_check[0], r_mem_check[1]);
     }
     dev_hash_mem(c, mem_rx.p, d.comb_mem.p, mem.input(0), mem.input(1), M, r_mem_check[0], r_mem_check[1]);
     dev_hash_mem(c, mem_ry.p, d.comb_mem.p + M, mem.input(2), mem.input(3), M, r_mem_check[0], r_mem_check[1]);
+    lap("hash layer kernels");
     ops.build(c); mem.build(c);
+    lap("product layers");
     // the dot-product circuits: halves of (row_ops_val, col_ops_val, val) per matrix — copies, because the sum-check folds them in place
     DevBuf<Fr> dotp((size_t)9 * N);
     DotpTables D; D.len = H; D.n = 6;
@@ -297,10 +383,13 @@ std::vector<uint8_t> snark_prove_gpu(Instance &I, CompComm &comm, const uint8_t 
         if (!fr_eq(fr_add(E.dotp_left[k], E.dotp_right[k]), S.inst_evals[k])) throw Error(OTTI_ERR_INTERNAL, "sparse polynomial evaluation does not match its dot-product circuits");
     }
     std::vector<Fr> rand_ops, rand_mem;
+    lap("dotp copies, circuit outputs");
     {
-        DevBuf<Fr> eq_buf(std::max(H, M / 2));
-        E.proof_ops = pcbatch_prove(c, ops, ops_evals, &D, dotp_evals, tr, eq_buf.p, eqs.p, partials.p, rand_ops);
-        E.proof_mem = pcbatch_prove(c, mem, mem_evals, nullptr, {}, tr, eq_buf.p, eqs.p, partials.p, rand_mem);
+        DevBuf<Fr> pyr(2 * 8192);
+        E.proof_ops = pcbatch_prove(c, ops, ops_evals, &D, dotp_evals, tr, pyr.p, rand_ops);
+        lap("batched proof: ops");
+        E.proof_mem = pcbatch_prove(c, mem, mem_evals, nullptr, {}, tr, pyr.p, rand_mem);
+        lap("batched proof: mem");
     }
     T.ms[7] = now_ms() - t0;
 
@@ -327,6 +416,7 @@ std::vector<uint8_t> snark_prove_gpu(Instance &I, CompComm &comm, const uint8_t 
         c.sync();
         E.h_row_audit = c.h_results[kSumSlot]; E.h_col_audit = c.h_results[kSumSlot + 1];
     }
+    lap("hash layer evaluations");
     auto joint = [&](std::vector<Fr> ev, const char *label_evals, const char *label_ch, const char *label_joint, const std::vector<Fr> &rand, std::vector<Fr> &r_joint) {
         tr.append_scalars(label_evals, ev.data(), ev.size());
         std::vector<Fr> ch = tr.challenge_vector(label_ch, ilog2(ev.size()));
@@ -342,17 +432,20 @@ std::vector<uint8_t> snark_prove_gpu(Instance &I, CompComm &comm, const uint8_t 
         const Fr j = joint(ev, "evals_ops_val", "challenge_combine_n_to_one", "joint_claim_eval", rand_ops, rj);
         E.pe_derefs = polyeval_prove_plain(c, *g.eval, g.derefs, derefs.p, rj, j, tr, tape);
     }
+    lap("polyeval derefs");
     {
         std::vector<Fr> ev(16, fr_zero()), rj;
         for (int k = 0; k < 3; k++) { ev[k] = E.h_row_addr[k]; ev[3 + k] = E.h_row_read_ts[k]; ev[6 + k] = E.h_col_addr[k]; ev[9 + k] = E.h_col_read_ts[k]; ev[12 + k] = E.h_val[k]; }
         const Fr j = joint(ev, "claim_evals_ops", "challenge_combine_n_to_one", "joint_claim_eval_ops", rand_ops, rj);
         E.pe_ops = polyeval_prove_plain(c, *g.eval, g.ops, d.comb_ops.p, rj, j, tr, tape);
     }
+    lap("polyeval ops");
     {
         std::vector<Fr> rj;
         const Fr j = joint({E.h_row_audit, E.h_col_audit}, "claim_evals_mem", "challenge_combine_two_to_one", "joint_claim_eval_mem", rand_mem, rj);
         E.pe_mem = polyeval_prove_plain(c, *g.eval, g.mem, d.comb_mem.p, rj, j, tr, tape);
     }
+    lap("polyeval mem");
     T.ms[8] = now_ms() - t0;
     std::vector<uint8_t> out = S.serialize();
     T.ms[9] = now_ms() - t_start;
