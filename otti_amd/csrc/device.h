@@ -68,7 +68,8 @@ struct DevCtx {
     DevBuf<unsigned> d_counter;                               // arrival counter of the publishing workgroups
     Mailbox next_mailbox(int slot);
     GoBox *h_go = nullptr, *d_go_alias = nullptr; DevBuf<GoBox> d_go; unsigned long long go_issued = 0, go_published = 0;
-    bool armed_ok() const;                                    // off under OTTI_ARMED=0 and while kernel classes are being timed (a spinning kernel's duration includes the host)
+    bool armed_ok() const;                                    // off under OTTI_ARMED=0, while kernel classes are being timed (a waiting kernel's duration includes the host), and
+                                                              // while another proof is in flight in this process (a waiting grid holds wave slots the other proof's kernels could use: measured -15 % throughput with six in flight)
     Armed arm();                                              // for the next launch; the k-th armed launch consumes the k-th go()
     void go(const Fr *v, int n);                              // publish up to two values to the oldest armed launch that has none yet
     void go_abort();                                          // release every armed launch still waiting (they exit without touching their data) and drain the stream
@@ -89,6 +90,7 @@ struct DevCtx {
     Pt *d_pts_alias = nullptr; DevBuf<unsigned> d_counter2;
     void ensure_points(size_t rows, size_t splits);
 };
+struct ActiveProof { ActiveProof(); ~ActiveProof(); };       // RAII around one prove call: counts the proofs in flight in this process
 constexpr int kResultSlots = 2048;                          // 64 KB pinned: round sums, sum-check tails (SNARK: up to 18 x 3 tables x 16 elements)
 constexpr size_t kHostEncodeRows = 8;
 constexpr size_t kHostPtsCap = 512;

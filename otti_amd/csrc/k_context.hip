@@ -13,6 +13,7 @@
 //   k_poly_bound_*       K9 DensePolynomial::bound
 //   k_bullet_step        K10 nizk/bullet.rs BulletReductionProof::prove scalar bookkeeping
 #include "kernels_common.h"
+#include <atomic>
 
 namespace otti {
 
@@ -132,9 +133,12 @@ Mailbox DevCtx::next_mailbox(int slot) {
     Mailbox mb; mb.partials = partials.p; mb.counter = d_counter.p; mb.host_results = d_results_alias; mb.host_flag = d_flag_alias;
     mb.seq = ++seq; mb.slot = slot; return mb;
 }
+static std::atomic<int> g_active_proofs{0};
+ActiveProof::ActiveProof() { g_active_proofs.fetch_add(1, std::memory_order_relaxed); }
+ActiveProof::~ActiveProof() { g_active_proofs.fetch_sub(1, std::memory_order_relaxed); }
 bool DevCtx::armed_ok() const {
     static const bool env_on = [] { const char *e = getenv("OTTI_ARMED"); return !(e && e[0] == '0'); }();
-    return env_on && !KStats::get().on;
+    return env_on && !KStats::get().on && g_active_proofs.load(std::memory_order_relaxed) <= 1;
 }
 Armed DevCtx::arm() { Armed a; a.host = d_go_alias; a.dev = d_go.p; a.want = ++go_issued; return a; }
 void DevCtx::go(const Fr *v, int n) {

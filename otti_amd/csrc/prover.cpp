@@ -577,6 +577,7 @@ void r1cs_prove_device(Instance &I, DeviceWitness &wit, Gens &g, Transcript &tr,
 std::vector<uint8_t> nizk_prove_resident(Instance &I, DeviceWitness &wit, Gens &g, const void *tlabel, size_t tlabel_len, const uint8_t *seed32,
                                          ProveTimings *tm, ShardComm *sh) {
     DevCtx &c = DevCtx::get();
+    ActiveProof active;
     SpinPool::Session pool_session;                               // helper threads spin for the duration of this proof
     const double t_start = now_ms(); ProveTimings T{};
     Transcript tr(tlabel, tlabel_len);

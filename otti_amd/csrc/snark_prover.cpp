@@ -281,6 +281,7 @@ DotProductProofLog polyeval_prove_plain(DevCtx &c, Gens &gens, const PcSet &s, c
 std::vector<uint8_t> snark_prove_gpu(Instance &I, CompComm &comm, const uint8_t *vars32, size_t nvars, const std::vector<Fr> &inputs, SnarkGens &g,
                                      const void *tlabel, size_t tlabel_len, const uint8_t *seed32, SnarkTimings *tm) {
     DevCtx &c = DevCtx::get();
+    ActiveProof active;
     SpinPool::Session pool_session;
     if (!comm.dec) throw Error(OTTI_ERR_BAD_ARG, "this computation commitment carries no decommitment (it was parsed from bytes): SNARK::prove needs the one SNARK::encode returned");
     if (I.num_cons != comm.num_cons || I.num_vars != comm.num_vars || I.num_inputs != comm.num_inputs) throw Error(OTTI_ERR_BAD_ARG, "commitment belongs to another instance");
