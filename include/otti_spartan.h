@@ -192,6 +192,11 @@ int32_t otti_k_sc_cubic_fold_round(const uint8_t *h_A, const uint8_t *h_B, const
 int32_t otti_k_sc_quad_round(const uint8_t *h_A, const uint8_t *h_B, size_t len, uint8_t *h_e2, float *kernel_ms);
 int32_t otti_k_sc_quad_fold_round(const uint8_t *h_A, const uint8_t *h_B, size_t len, const uint8_t *h_r, uint8_t *h_out2, uint8_t *h_e2, float *kernel_ms);
 /* DensePolynomial::commit_inner: L rows of R scalars -> L compressed points C_i = sum_j Z[iR+j] P[j] + blinds[i] P[R+1] */
+/* Self-test of the "armed" launches the provers use for their small sequential rounds (a kernel queued before its challenge is known
+ * and released through pinned host memory): the quadratic fold + sums round on the caller's tables (length len, a power of two >= 8),
+ * plain, armed + released after hold_us microseconds, and armed + aborted.  out2 (len/2 + len/2 elements) and e2 (2 elements) are the
+ * plain launch's results; any disagreement between the three ways is OTTI_ERR_INTERNAL. */
+int32_t otti_k_armed_selftest(const uint8_t *A, const uint8_t *B, size_t len, const uint8_t *r, uint32_t hold_us, uint8_t *out2, uint8_t *e2);
 int32_t otti_k_msm_rows(otti_gens *gens, const uint8_t *h_Z, size_t L, size_t R, const uint8_t *h_blinds, uint8_t *h_out32, float *kernel_ms);
 
 /* ---- the kernels the prover actually launches for phase one, the evaluation proof and the bullet reduction (host pointers, as above).

@@ -120,6 +120,7 @@ _sig("otti_k_sc_cubic_round", _i32, _vp, _vp, _vp, _vp, _sz, _vp, _fp)
 _sig("otti_k_sc_cubic_fold_round", _i32, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _fp)
 _sig("otti_k_sc_quad_round", _i32, _vp, _vp, _sz, _vp, _fp)
 _sig("otti_k_sc_quad_fold_round", _i32, _vp, _vp, _sz, _vp, _vp, _vp, _fp)
+_sig("otti_k_armed_selftest", _i32, _vp, _vp, _sz, _vp, ctypes.c_uint32, _vp, _vp)
 _sig("otti_k_msm_rows", _i32, _vp, _vp, _sz, _sz, _vp, _vp, _fp)
 _sig("otti_k_eq_pyramid", _i32, _vp, _sz, _vp)
 _sig("otti_k_sc_cubic3_round", _i32, _vp, _vp, _vp, _sz, _vp, _vp, _fp)
@@ -666,6 +667,14 @@ class kernels:
         out = np.zeros((2, n // 2, 32), dtype=np.uint8); e = np.zeros((2, 32), dtype=np.uint8); ms = ctypes.c_float(0)
         _check(lib.otti_k_sc_quad_fold_round(_ptr(A), _ptr(B), n, _ptr(r), _ptr(out), _ptr(e), ctypes.byref(ms)))
         return out, e, ms.value
+
+    @staticmethod
+    def armed_selftest(A, B, r, hold_us=200):
+        """plain / armed + released / armed + aborted runs of the quadratic fold round; returns the plain run's (folded tables, sums)"""
+        A, B, r = (_scalars(x, "t") for x in (A, B, r)); n = A.shape[0]
+        out = np.zeros((2, n // 2, 32), dtype=np.uint8); e = np.zeros((2, 32), dtype=np.uint8)
+        _check(lib.otti_k_armed_selftest(_ptr(A), _ptr(B), n, _ptr(r), hold_us, _ptr(out), _ptr(e)))
+        return out, e
 
     @staticmethod
     def msm_rows(gens, Z, L, R, blinds):

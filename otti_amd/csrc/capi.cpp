@@ -464,6 +464,42 @@ int32_t otti_k_sc_quad_fold_round(const uint8_t *A, const uint8_t *B, size_t len
         c.sync(); c.wait_ticket(tk); memcpy(e2, c.h_results, 64); return OTTI_OK;
     });
 }
+// Armed launches (device.h): the same fold + sums round three ways on the caller's tables — plain; armed and released by go() after
+// `hold_us` microseconds of the kernel waiting; armed and ABORTED (the tables must come back untouched and the stream must drain),
+// followed by another armed round that must still work.  out2/e2: the plain launch's folded tables and sums, for the caller's oracle.
+int32_t otti_k_armed_selftest(const uint8_t *A, const uint8_t *B, size_t len, const uint8_t *r, uint32_t hold_us, uint8_t *out2, uint8_t *e2) {
+    return guarded([&] {
+        if (len < 8 || (len & (len - 1))) throw Error(OTTI_ERR_BAD_ARG, "table length must be a power of two >= 8");
+        DevCtx &c = DevCtx::get();
+        const Fr rr = fr_load(r); const size_t h = len / 2;
+        Staged a0(c, A, len), b0(c, B, len), a1(c, A, len), b1(c, B, len);
+        auto tk = dev_sc_quad_fold_eval(c, a0.d.p, b0.d.p, len, rr, 0);
+        c.wait_ticket(tk); Fr e_plain[2] = {c.h_results[0], c.h_results[1]};
+        download(c, out2, a0.d.p, h); download(c, out2 + 32 * h, b0.d.p, h); c.sync(); memcpy(e2, e_plain, 64);
+        // armed, released late
+        tk = dev_sc_quad_fold_eval_armed(c, a1.d.p, b1.d.p, len, 0);
+        { const auto t0 = std::chrono::steady_clock::now(); while (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(hold_us)) {} }
+        c.go(&rr, 1);
+        c.wait_ticket(tk);
+        if (memcmp(e_plain, c.h_results, 64)) throw Error(OTTI_ERR_INTERNAL, "armed round: sums differ from the plain launch");
+        std::vector<uint8_t> got(64 * h);
+        download(c, got.data(), a1.d.p, h); download(c, got.data() + 32 * h, b1.d.p, h); c.sync();
+        if (memcmp(got.data(), out2, 64 * h)) throw Error(OTTI_ERR_INTERNAL, "armed round: folded tables differ from the plain launch");
+        // armed, aborted: nothing may be written, the stream must drain, the next armed launch must work
+        std::vector<uint8_t> before(32 * h), after(32 * h);
+        download(c, before.data(), a1.d.p, h); c.sync();
+        tk = dev_sc_quad_fold_eval_armed(c, a1.d.p, b1.d.p, h, 0);
+        c.go_abort();
+        download(c, after.data(), a1.d.p, h); c.sync();
+        if (memcmp(before.data(), after.data(), 32 * h)) throw Error(OTTI_ERR_INTERNAL, "aborted armed round wrote to its tables");
+        if (*c.h_flag >= tk) throw Error(OTTI_ERR_INTERNAL, "aborted armed round delivered a result");
+        tk = dev_sc_quad_fold_eval(c, a0.d.p, b0.d.p, h, rr, 0); c.wait_ticket(tk); e_plain[0] = c.h_results[0]; e_plain[1] = c.h_results[1];
+        tk = dev_sc_quad_fold_eval_armed(c, a1.d.p, b1.d.p, h, 0); c.go(&rr, 1); c.wait_ticket(tk);
+        if (memcmp(e_plain, c.h_results, 64)) throw Error(OTTI_ERR_INTERNAL, "armed round after an abort: sums differ from the plain launch");
+        c.sync();
+        return OTTI_OK;
+    });
+}
 int32_t otti_k_msm_rows(otti_gens *gens, const uint8_t *Z, size_t L, size_t R, const uint8_t *blinds, uint8_t *out32, float *ms) {
     return guarded([&] {
         DevCtx &c = DevCtx::get(); Gens &g = *gens->g;

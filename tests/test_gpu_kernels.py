@@ -165,3 +165,15 @@ def test_device_pointer_entry_points_match_the_staged_ones(rng):
             assert eq(dpts.to_host(), orc.commit_rows(og, Zm, Lr, Rr, bl))
     finally:
         KD.stream_destroy(stream)
+
+
+# ------------------------------------------------------------------------------------------------ armed launches (device.h)
+@pytest.mark.parametrize("n,hold_us", [(8, 0), (1 << 10, 300), (1 << 16, 2000)])
+def test_armed_round_released_aborted_and_reused(rng, n, hold_us):
+    """A round queued before its challenge is known: released after the kernel has waited hold_us, aborted (tables untouched, stream
+    drains, nothing delivered), and armed again afterwards.  The library compares the three ways among themselves; the plain run is
+    checked against the oracle here.  n = 2^16 folds in 64 workgroups (the widest grid the provers arm): the non-leader path."""
+    A, B = orc.rand_fr(rng, n), orc.rand_fr(rng, n); r = orc.rand_fr(rng, 1)
+    out, e = K.armed_selftest(A, B, r, hold_us)
+    fa, fb = orc.fold_top(A, r), orc.fold_top(B, r)
+    assert eq(out[0], fa) and eq(out[1], fb) and eq(e, orc.sc_quad_evals(fa, fb))
