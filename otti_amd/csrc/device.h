@@ -52,7 +52,7 @@ struct Mailbox { Fr *partials; unsigned *counter; Fr *host_results; unsigned lon
 // launched once the host knows the round's challenge.  An ARMED kernel is queued before that: its first workgroup spins on a pinned host
 // word until the host publishes the value (DevCtx::go), copies it to HBM for the other workgroups, and the round starts within a PCIe
 // read of the challenge being known.  Every spin has a deadline (3 s of s_memrealtime) and an abort value, so a grid always drains.
-struct GoBox { unsigned long long seq, pad[3]; Fr v[2]; };
+struct GoBox { unsigned long long seq, pad[3]; Fr v[4]; };
 struct Armed { const GoBox *host; GoBox *dev; unsigned long long want; };   // want == 0: not armed (values come as kernel arguments)
 constexpr size_t kArmMaxLen = 65536;                         // sum-check tables up to this length fold in <= 64 workgroups: only those launches are armed
 
@@ -71,7 +71,7 @@ struct DevCtx {
     bool armed_ok() const;                                    // off under OTTI_ARMED=0, while kernel classes are being timed (a waiting kernel's duration includes the host), and
                                                               // while another proof is in flight in this process (a waiting grid holds wave slots the other proof's kernels could use: measured -15 % throughput with six in flight)
     Armed arm();                                              // for the next launch; the k-th armed launch consumes the k-th go()
-    void go(const Fr *v, int n);                              // publish up to two values to the oldest armed launch that has none yet
+    void go(const Fr *v, int n);                              // publish up to four values to the oldest armed launch that has none yet
     void go_abort();                                          // release every armed launch still waiting (they exit without touching their data) and drain the stream
     void wait_ticket(unsigned long long ticket);              // spin until the launch with that sequence number has delivered
     DevBuf<Pt> msm_keep;                                      // row sums parked on the device (MSM_KEEP)
@@ -90,7 +90,7 @@ struct DevCtx {
     Pt *d_pts_alias = nullptr; DevBuf<unsigned> d_counter2;
     void ensure_points(size_t rows, size_t splits);
 };
-struct ActiveProof { ActiveProof(); ~ActiveProof(); };       // RAII around one prove call: counts the proofs in flight in this process
+struct ActiveProof { ActiveProof(); ~ActiveProof(); static int count(); };       // RAII around one prove call: counts the proofs in flight in this process
 constexpr int kResultSlots = 2048;                          // 64 KB pinned: round sums, sum-check tails (SNARK: up to 18 x 3 tables x 16 elements)
 constexpr size_t kHostEncodeRows = 8;
 constexpr size_t kHostPtsCap = 512;
@@ -191,8 +191,10 @@ void dev_bullet_step(DevCtx &c, Fr *a, Fr *b, Fr *s, size_t R, size_t n_cur, boo
 // One bullet-reduction round as ONE launch: applies the previous challenge (fold), derives the scalars of L and R from the round state
 // and sums both rows (fused finish; compressed L, R arrive in c.h_points[0..64) after c.wait_points(ticket)).  extra_s: 4 scalars
 // {unused, blind_L, unused, blind_R} (the c_L / c_R terms are computed in the kernel); extra_base: {Q, H}.
+// armed (device.h): u and u_inv are not known yet; the launch takes {u, u_inv, raw(u), raw(u_inv)} from the next c.go()
 unsigned long long dev_bullet_round(DevCtx &c, const DeviceGens &g, size_t R, size_t n_cur, bool fold, const Fr &u, const Fr &u_inv, const Fr *a_in,
-                                    const Fr *b_in, const Fr *s_in, Fr *a_out, Fr *b_out, Fr *s_out, const Fr *extra_s, const uint32_t *extra_base);
+                                    const Fr *b_in, const Fr *s_in, Fr *a_out, Fr *b_out, Fr *s_out, const Fr *extra_s, const uint32_t *extra_base,
+                                    bool armed = false);
 double dev_madd_peak(DevCtx &c);                                          // mixed point additions per second, whole chip (the MSM's ALU roof)
 void dev_scale(DevCtx &c, const Fr *in, const Fr &k, Fr *out, size_t n);
 void dev_fill_one(DevCtx &c, Fr *p, size_t n);

@@ -135,6 +135,7 @@ Mailbox DevCtx::next_mailbox(int slot) {
 }
 static std::atomic<int> g_active_proofs{0};
 ActiveProof::ActiveProof() { g_active_proofs.fetch_add(1, std::memory_order_relaxed); }
+int ActiveProof::count() { return g_active_proofs.load(std::memory_order_relaxed); }
 ActiveProof::~ActiveProof() { g_active_proofs.fetch_sub(1, std::memory_order_relaxed); }
 bool DevCtx::armed_ok() const {
     static const bool env_on = [] { const char *e = getenv("OTTI_ARMED"); return !(e && e[0] == '0'); }();
@@ -143,7 +144,7 @@ bool DevCtx::armed_ok() const {
 Armed DevCtx::arm() { Armed a; a.host = d_go_alias; a.dev = d_go.p; a.want = ++go_issued; return a; }
 void DevCtx::go(const Fr *v, int n) {
     if (go_published >= go_issued) throw Error(OTTI_ERR_INTERNAL, "go() without an armed launch");
-    for (int i = 0; i < n && i < 2; i++) h_go->v[i] = v[i];
+    for (int i = 0; i < n && i < 4; i++) h_go->v[i] = v[i];
     __atomic_store_n(&h_go->seq, ++go_published, __ATOMIC_RELEASE);
 }
 void DevCtx::go_abort() {

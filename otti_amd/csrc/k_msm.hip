@@ -30,6 +30,7 @@ struct MsmArgs {
     // row sums to pinned host memory, then raises the host flag — no finish launch, no copy, no stream synchronise
     int fuse; uint32_t rows; unsigned *counter; Pt *host_pts; unsigned long long *host_flag; unsigned long long seq;
     BulletArgs bul;
+    Armed go;                                                       // armed bullet round: {u, u_inv, raw(u), raw(u_inv)} arrive through the GoBox
     unsigned long long *stamps;                                     // OTTI_MSM_STAMPS: s_memrealtime (100 MHz) at the phase boundaries of k_msm_small
 };
 __device__ __forceinline__ Fr bullet_fold_a(const BulletArgs &U, size_t x) { return U.fold ? fr_add(fr_mul_shared(U.a_in[x], U.u), fr_mul_shared(U.uinv, U.a_in[U.n + x])) : U.a_in[x]; }
@@ -181,7 +182,8 @@ __global__ __launch_bounds__(kBlock) void k_msm_small(MsmArgs A) {
     const size_t j0 = (size_t)chunk_id * A.chunk;
     const uint32_t n_here = j0 < A.n_dense ? (uint32_t)min((size_t)A.chunk, A.n_dense - j0) : 0u;
     const bool bullet = A.bul.on != 0;
-    const BulletArgs &U = A.bul;
+    BulletArgs U = A.bul;
+    if (A.go.want) { Fr v[4]; if (!armed_fetch<4>(A.go, v)) return; U.u = v[0]; U.uinv = v[1]; U.u_raw = v[2]; U.uinv_raw = v[3]; }
     // extras: plain launches carry them in chunk 0; a bullet round has {slice of <a, b> on Q} everywhere and {blind on H} in chunk 0
     const uint32_t n_ex = bullet ? (chunk_id == 0 ? 2u : 1u) : (chunk_id == 0 ? (uint32_t)A.n_extra : 0u);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -357,8 +359,8 @@ double dev_small_fraction(DevCtx &c, const Fr *z, size_t n) {
     return (double)h / (double)n;
 }
 unsigned long long dev_bullet_round(DevCtx &c, const DeviceGens &g, size_t R, size_t n_cur, bool fold, const Fr &u, const Fr &u_inv, const Fr *a_in,
-                                    const Fr *b_in, const Fr *s_in, Fr *a_out, Fr *b_out, Fr *s_out, const Fr *extra_s, const uint32_t *extra_base) {
-    BulletArgs U; U.on = 1; U.fold = fold ? 1 : 0; U.n = (uint32_t)n_cur; U.a_in = a_in; U.b_in = b_in; U.s_in = s_in;
+                                    const Fr *b_in, const Fr *s_in, Fr *a_out, Fr *b_out, Fr *s_out, const Fr *extra_s, const uint32_t *extra_base, bool armed) {
+    BulletArgs U; U.on = armed ? 2 : 1; U.fold = fold ? 1 : 0; U.n = (uint32_t)n_cur; U.a_in = a_in; U.b_in = b_in; U.s_in = s_in;
     U.a_out = a_out; U.b_out = b_out; U.s_out = s_out; U.u = u; U.uinv = u_inv; U.u_raw = fr_to_raw(u); U.uinv_raw = fr_to_raw(u_inv);
     return msm_launch(c, g, nullptr, 0, R / 2, 2, extra_s, extra_base, 2, MSM_COMPRESSED, nullptr, &U, false);   // R/2 active terms per row
 }
@@ -403,6 +405,7 @@ static unsigned long long msm_launch(DevCtx &c, const DeviceGens &g, const Fr *d
     A.partial = c.msm_partial.p;
     A.fuse = (!bulk && mode == MSM_COMPRESSED && !addend && rows <= 2 && rows * nchunks <= 512) ? 1 : 0;
     if (bul) A.bul = *bul; else { memset(&A.bul, 0, sizeof A.bul); }
+    A.go = Armed{nullptr, nullptr, 0};
     A.rows = (uint32_t)rows; A.counter = c.d_counter2.p; A.host_pts = c.d_pts_alias; A.host_flag = c.d_flag_alias; A.seq = A.fuse ? ++c.seq : 0;
     dim3 grid((unsigned)nchunks, (unsigned)rows);
     // OTTI_MSM_STAMPS=1: phase stamps of every fused small launch on stderr (development aid; synchronises the stream)
@@ -413,6 +416,7 @@ static unsigned long long msm_launch(DevCtx &c, const DeviceGens &g, const Fr *d
         if (!h_stamps) { OTTI_HIP(hipHostMalloc((void **)&h_stamps, 128, hipHostMallocDefault)); OTTI_HIP(hipHostGetDevicePointer((void **)&d_stamps, h_stamps, 0)); }
         memset(h_stamps, 0, 128); A.stamps = d_stamps;
     }
+    if (bul && bul->on == 2) { A.bul.on = 1; if (!A.stamps) A.go = c.arm(); else throw Error(OTTI_ERR_INTERNAL, "armed launches cannot be stamped"); }
     {
         KScope ks(c, bulk ? KC_MSM_ROWS : KC_MSM_SMALL);
         if (sparse) hipLaunchKernelGGL(k_msm_rows<MSM_BULK_SPARSE>, grid, kBlock, 0, c.stream, A);

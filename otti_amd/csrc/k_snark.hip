@@ -143,7 +143,7 @@ __device__ __forceinline__ void abe_accum(Fr (&acc)[3], const Pair &a, const Pai
 }
 // kFold: the tables have 4q entries and are folded by r to 2q (pairs (i, i + q)); otherwise they have 2q entries as they are
 template <bool kFold> __global__ __launch_bounds__(kBlock) void k_pc_round(PcList L, size_t q, Fr r, EqSrc E, Mailbox mb, Armed go) {
-    if (kFold && go.want) { Fr v[2]; if (!armed_fetch(go, v)) return; r = v[0]; }
+    if (kFold && go.want) { Fr v[1]; if (!armed_fetch<1>(go, v)) return; r = v[0]; }
     Fr *A = L.A[blockIdx.y], *B = L.B[blockIdx.y], *C = L.C[blockIdx.y];
     Fr acc[3] = {fr_zero(), fr_zero(), fr_zero()};
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < q; i += (size_t)gridDim.x * blockDim.x) {
@@ -184,7 +184,7 @@ unsigned long long dev_pc_fold_eval(DevCtx &c, const PcList &L, size_t len, cons
 }
 // tail hand-over: every table of the batch (folded by r when fold is set) into pinned host memory; the flag follows the last workgroup
 __global__ __launch_bounds__(64) void k_pc_export(PcList L, size_t n_out, int fold, Fr r, Mailbox mb, Armed go) {
-    if (go.want) { Fr v[2]; if (!armed_fetch(go, v)) return; r = v[0]; }
+    if (go.want) { Fr v[1]; if (!armed_fetch<1>(go, v)) return; r = v[0]; }
     const Fr *T[3] = {L.A[blockIdx.y], L.B[blockIdx.y], L.C[blockIdx.y]};
     for (int t = 0; t < 3; t++) {
         if (!T[t]) continue;

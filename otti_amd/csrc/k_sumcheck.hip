@@ -140,7 +140,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_sc_cubic3_eval(const Fr *B, const
     finish_in_kernel<3>(acc, mb);
 }
 __global__ __launch_bounds__(kBlock) void k_sc_cubic3_fold_eval(Fr *B, Fr *C, Fr *D, size_t q, Fr r, EqSrc E, Mailbox mb, Armed go) {
-    if (go.want) { Fr v[2]; if (!armed_fetch(go, v)) return; r = v[0]; }
+    if (go.want) { Fr v[1]; if (!armed_fetch<1>(go, v)) return; r = v[0]; }
     Fr acc[3] = {fr_zero(), fr_zero(), fr_zero()};
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < q; i += (size_t)gridDim.x * blockDim.x) {
         Fr b0 = B[i], b1 = B[i + q], b2 = B[i + 2 * q], b3 = B[i + 3 * q];
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(kBlock) void k_sc_quad_eval(const Fr *A, const Fr *
     finish_in_kernel<2>(acc, mb);
 }
 __global__ __launch_bounds__(kBlock) void k_sc_quad_fold_eval(Fr *A, Fr *B, size_t q, Fr r, Mailbox mb, Armed go) {
-    if (go.want) { Fr v[2]; if (!armed_fetch(go, v)) return; r = v[0]; }
+    if (go.want) { Fr v[1]; if (!armed_fetch<1>(go, v)) return; r = v[0]; }
     Fr acc[2] = {fr_zero(), fr_zero()};
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < q; i += (size_t)gridDim.x * blockDim.x) {
         Fr a0 = A[i], a1 = A[i + q], a2 = A[i + 2 * q], a3 = A[i + 3 * q];

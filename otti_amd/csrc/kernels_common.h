@@ -53,13 +53,15 @@ __device__ __forceinline__ bool arrive_and_check_last(unsigned *counter, unsigne
 // Every workgroup calls this first.  Workgroup (0,0) waits for the host's value in pinned memory and republishes it in HBM, the others
 // wait for that copy.  Returns false in every thread of the workgroup when the launch was aborted or a deadline passed: the kernel then
 // returns at once.
-__device__ __forceinline__ bool armed_fetch(const Armed &a, Fr (&v)[2]) {
-    __shared__ Fr s_v[2]; __shared__ int s_ok;
+template <int N> __device__ __forceinline__ bool armed_fetch(const Armed &a, Fr (&v)[N]) {
+    static_assert(N >= 1 && N <= 4, "a GoBox carries four values");
+    __shared__ Fr s_v[N]; __shared__ int s_ok;
     if (threadIdx.x == 0) {
         const bool leader = (blockIdx.x | blockIdx.y | blockIdx.z) == 0;
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime(), abort_bit = 1ull << 63, deadline = 300000000ull;   // 100 MHz
         int ok = -1;
-        Fr t[2] = {fr_zero(), fr_zero()};
+        Fr t[N];
+        for (int k = 0; k < N; k++) t[k] = fr_zero();
         if (leader) {
             while (ok < 0) {
                 const unsigned long long s = __hip_atomic_load(&a.host->seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -68,9 +70,14 @@ __device__ __forceinline__ bool armed_fetch(const Armed &a, Fr (&v)[2]) {
                 else __builtin_amdgcn_s_sleep(2);
             }
             if (ok) {
-                for (int k = 0; k < 2; k++) {
-                    const unsigned long long *src = reinterpret_cast<const unsigned long long *>(&a.host->v[k]);
-                    for (int i = 0; i < 4; i++) { const unsigned long long w = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); t[k].v[2 * i] = (uint32_t)w; t[k].v[2 * i + 1] = (uint32_t)(w >> 32); }
+                // the values sit in pinned (uncached) host memory: plain 16-byte loads, all issued before the first is waited for — one
+                // PCIe round trip for the lot (8-byte atomics would be waited for one by one)
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                const u32x4 *src = reinterpret_cast<const u32x4 *>(&a.host->v[0]);
+                u32x4 w[2 * N];
+                for (int i = 0; i < 2 * N; i++) w[i] = __builtin_nontemporal_load(src + i);
+                for (int k = 0; k < N; k++) {
+                    for (int i = 0; i < 4; i++) { t[k].v[i] = w[2 * k][i]; t[k].v[4 + i] = w[2 * k + 1][i]; }
                     store_words_sc1(&a.dev->v[k], t[k].v, 8);
                 }
             }
@@ -83,12 +90,13 @@ __device__ __forceinline__ bool armed_fetch(const Armed &a, Fr (&v)[2]) {
                 else if (s == (a.want | abort_bit) || __builtin_amdgcn_s_memrealtime() - t0 > deadline) ok = 0;
                 else __builtin_amdgcn_s_sleep(1);
             }
-            if (ok) for (int k = 0; k < 2; k++) load_words_sc1(t[k].v, &a.dev->v[k], 8);
+            if (ok) for (int k = 0; k < N; k++) load_words_sc1(t[k].v, &a.dev->v[k], 8);
         }
-        s_v[0] = t[0]; s_v[1] = t[1]; s_ok = ok;
+        for (int k = 0; k < N; k++) s_v[k] = t[k];
+        s_ok = ok;
     }
     __syncthreads();
-    v[0] = s_v[0]; v[1] = s_v[1];
+    for (int k = 0; k < N; k++) v[k] = s_v[k];
     return s_ok != 0;
 }
 

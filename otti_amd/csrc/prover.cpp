@@ -195,19 +195,34 @@ DotProductProofLog dplog_prove_device(DevCtx &c, const DeviceGens &DG, const Gen
     // round state ping-pongs between two buffer sets: launch k reads set k&1 and writes the folded state to set (k+1)&1
     Fr *abuf[2] = {B.LZ, B.a}, *bbuf[2] = {B.Rv, B.b2}, *sbuf[2] = {B.s, B.s2};
     dev_fill_one(c, sbuf[0], Rsz);
-    size_t n = Rsz, round = 0;
     const uint32_t qh[2] = {v.g1, v.h_n};
     Fr u = fr_zero(), ui = fr_zero();
-    while (n != 1) {
-        const int in = (int)(round & 1), out = in ^ 1;
-        unsigned long long tk = dev_bullet_round(c, DG, Rsz, n, round != 0, u, ui, abuf[in], bbuf[in], sbuf[in], abuf[out], bbuf[out], sbuf[out], B.extras + 4 * round, qh);
-        c.wait_points(tk);
+    // round k works on vectors of length Rsz >> k; rounds k >= 1 first fold by (u_{k-1}, 1/u_{k-1}).  Armed (device.h), round k + 1 is
+    // queued while round k runs and starts when the host publishes the challenge.
+    const size_t n_rounds = lgR;
+    const bool arm_ok = c.armed_ok() && !getenv("OTTI_MSM_STAMPS");
+    struct Release { DevCtx &c; ~Release() { c.go_abort(); } } release{c};
+    std::vector<unsigned long long> tks(n_rounds + 1, 0);
+    auto launch_round = [&](size_t k, bool armed) {
+        const int in = (int)(k & 1), out = in ^ 1;
+        tks[k] = dev_bullet_round(c, DG, Rsz, Rsz >> k, k != 0, u, ui, abuf[in], bbuf[in], sbuf[in], abuf[out], bbuf[out], sbuf[out], B.extras + 4 * k, qh, armed);
+    };
+    if (n_rounds) launch_round(0, false);
+    const bool arm = arm_ok && n_rounds > 1 && tks[0] != 0;      // only fused launches (results by mailbox, no stream synchronise behind which an armed kernel would wait for the host)
+    if (arm) launch_round(1, true);
+    size_t round = 0;
+    for (; round < n_rounds; round++) {
+        if (arm) c.pending_host_encode = 2;                      // the launch queued ahead has already re-armed the counter once; this round's L and R are still to be compressed
+        c.wait_points(tks[round]);
         CPoint Lp = point_at(c, 0), Rp = point_at(c, 1);
         tr.append_point("L", Lp.b); tr.append_point("R", Rp.b);
         pf.L_vec.push_back(Lp); pf.R_vec.push_back(Rp);
         u = tr.challenge_scalar("u"); ui = fr_inv(u);
+        if (round + 1 < n_rounds) {
+            if (arm) { const Fr v4[4] = {u, ui, fr_to_raw(u), fr_to_raw(ui)}; c.go(v4, 4); if (round + 2 < n_rounds) launch_round(round + 2, true); }
+            else launch_round(round + 1, false);
+        }
         blind_fin = fr_add(blind_fin, fr_add(fr_mul(fr_mul(bv1[round], u), u), fr_mul(fr_mul(bv2[round], ui), ui)));
-        n /= 2; round++;
     }
     // last fold (length 2 -> 1) in place on the current set; s gets its final coefficients
     Fr *afin = abuf[round & 1], *bvec = bbuf[round & 1], *sfin = sbuf[round & 1];
