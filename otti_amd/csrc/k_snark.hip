@@ -1,14 +1,15 @@
 // Kernels of SNARK mode's R1CSEvalProof (snark.h): dereferencing the eq tables by row / column address, the memory-checking hash
 // layer, product-circuit layers, and the rounds of the batched cubic sum-check over many (A, B, C) table triples at once.
 // All HBM-streaming work on 32-byte field elements (no MFMA applies: 256-bit modular integers); one launch handles every instance of a
-// batch (grid.y = instance), so a round of SumcheckInstanceProof::prove_cubic_batched is two launches whatever the batch size.
+// batch (grid.y = instance), so a round of SumcheckInstanceProof::prove_cubic_batched is one launch whatever the batch size.
 //
 // Kernel <-> upstream loop [RECALL; the reference's Spartan/ submodule is empty]:
 //   k_gather                sparse_mlpoly.rs AddrTimestamps::deref_mem
 //   k_hash_mem / k_hash_ops sparse_mlpoly.rs Layers::build_hash_layer (init / audit, read / write)
 //   k_prod_layer            product_tree.rs ProductCircuit::compute_layer
-//   k_abc_evals             sumcheck.rs SumcheckInstanceProof::prove_cubic_batched, the evaluation loop (comb = A * B * C at 0, 2, 3)
-//   k_fold_many             dense_mlpoly.rs DensePolynomial::bound_poly_var_top over every table of the batch
+//   k_pc_round              sumcheck.rs SumcheckInstanceProof::prove_cubic_batched: one round = bound_poly_var_top of every table of the
+//                           batch by the previous challenge + the evaluation loop (comb = A * B * C at 0, 2, 3), fused
+//   k_pc_export             the tables' last elements (and the host-played tail of every layer)
 //   k_dot_many / k_sum3     DensePolynomial::evaluate (against a shared eq table) / DotProductCircuit::evaluate
 #include "kernels_common.h"
 #include "snark_dev.h"
@@ -64,22 +65,6 @@ void dev_prod_layer(DevCtx &c, const LayerList &L, size_t q) {
     hipLaunchKernelGGL(k_prod_layer, dim3((unsigned)grid_for(q), (unsigned)L.n), kBlock, 0, c.stream, L, q);
 }
 
-// ---- a round of the batched cubic sum-check.  Instance y: sums over i < half of A*B*C at the points 0, 2, 3 of the variable being bound.
-__global__ __launch_bounds__(kBlock) void k_abc_evals(AbcList L, size_t half, Fr *partials) {
-    const Fr *A = L.A[blockIdx.y], *B = L.B[blockIdx.y], *C = L.C[blockIdx.y];
-    Fr acc[3] = {fr_zero(), fr_zero(), fr_zero()};
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x) {
-        const Fr a0 = A[i], a1 = A[i + half], b0 = B[i], b1 = B[i + half], c0 = C[i], c1 = C[i + half];
-        acc[0] = fr_add(acc[0], fr_mul(fr_mul(a0, b0), c0));
-        const Fr da = fr_sub(a1, a0), db = fr_sub(b1, b0), dc = fr_sub(c1, c0);
-        Fr a = fr_add(a1, da), b = fr_add(b1, db), cc = fr_add(c1, dc);
-        acc[1] = fr_add(acc[1], fr_mul(fr_mul(a, b), cc));
-        a = fr_add(a, da); b = fr_add(b, db); cc = fr_add(cc, dc);
-        acc[2] = fr_add(acc[2], fr_mul(fr_mul(a, b), cc));
-    }
-    block_reduce<3>(acc);
-    if (threadIdx.x == 0) for (int k = 0; k < 3; k++) partials[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 3 + k] = acc[k];
-}
 // out[y * K + k] = sum over the nblk partials of instance y (out may be pinned host memory)
 template <int K> __global__ __launch_bounds__(kBlock) void k_reduce_many(const Fr *partials, int nblk, Fr *out) {
     Fr acc[K];
@@ -90,15 +75,9 @@ template <int K> __global__ __launch_bounds__(kBlock) void k_reduce_many(const F
     if (threadIdx.x == 0) for (int k = 0; k < K; k++) out[(size_t)blockIdx.x * K + k] = acc[k];
 }
 static inline int many_grid(size_t n, int ninst) { return (int)std::max<size_t>(1, std::min<size_t>((n + kBlock - 1) / kBlock, std::max<size_t>(1, (size_t)kMaxBlocks / (size_t)ninst))); }
-// results land in c.h_results[slot .. slot + 3 n) after c.sync()
-void dev_abc_evals(DevCtx &c, const AbcList &L, size_t half, Fr *partials, int slot) {
-    const int g = many_grid(half, L.n);
-    KScope ks(c, KC_SC_CUBIC);
-    hipLaunchKernelGGL(k_abc_evals, dim3((unsigned)g, (unsigned)L.n), kBlock, 0, c.stream, L, half, partials);
-    hipLaunchKernelGGL(k_reduce_many<3>, L.n, kBlock, 0, c.stream, (const Fr *)partials, g, c.d_results_alias + slot);
-}
-// ---- the same round as ONE launch (fold by the previous challenge + sums of the next round), results mailed to the host by the last
-// workgroup (finish_in_kernel of k_sumcheck.hip, here for every instance of the batch at once).
+// ---- a round of the batched cubic sum-check as ONE launch (fold by the previous challenge + the sums of this round at the points 0, 2, 3
+// of the variable being bound), results mailed to the host by the last workgroup (finish_in_kernel of k_sumcheck.hip, here for every
+// instance of the batch at once).
 __device__ __forceinline__ void finish_many(Fr (&acc)[3], const Mailbox &mb) {
     block_reduce<3>(acc);
     const unsigned total = gridDim.x * gridDim.y, ny = gridDim.y;
@@ -216,15 +195,6 @@ unsigned long long dev_pc_export(DevCtx &c, const PcList &L, size_t len, bool fo
     KScope ks(c, KC_SC_CUBIC);
     hipLaunchKernelGGL(k_pc_export, dim3(1, (unsigned)L.n), 64, 0, c.stream, L, n_out, fold ? 1 : 0, r ? *r : fr_zero(), mb, go);
     return mb.seq;
-}
-__global__ __launch_bounds__(kBlock) void k_fold_many(PtrList L, size_t half, Fr r) {
-    Fr *Z = L.p[blockIdx.y];
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x) { const Fr a = Z[i], b = Z[i + half]; Z[i] = fr_add(a, fr_mul(r, fr_sub(b, a))); }
-}
-void dev_fold_many(DevCtx &c, const PtrList &L, size_t half, const Fr &r) {
-    if (!half || !L.n) return;
-    KScope ks(c, KC_SC_CUBIC);
-    hipLaunchKernelGGL(k_fold_many, dim3((unsigned)many_grid(half, L.n), (unsigned)L.n), kBlock, 0, c.stream, L, half, r);
 }
 // element 0 of every table of the list -> c.h_results[slot ..)
 __global__ void k_pick0(PtrList L, Fr *out) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < L.n) out[i] = L.p[i][0]; }

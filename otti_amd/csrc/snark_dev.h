@@ -25,8 +25,6 @@ void dev_hash_mem(DevCtx &c, const Fr *eval_table, const Fr *audit_ts, Fr *out_i
 void dev_hash_ops(DevCtx &c, const Fr *addr_f, const Fr *deref, const Fr *read_ts, Fr *out_read, Fr *out_write, size_t N, const Fr &r, const Fr &gamma);
 void dev_prod_layer(DevCtx &c, const LayerList &L, size_t q);
 // partials: >= 3 * kMaxBlocks elements of scratch.  Results arrive in c.h_results[slot ..] once the stream has been synchronised.
-void dev_abc_evals(DevCtx &c, const AbcList &L, size_t half, Fr *partials, int slot);
-void dev_fold_many(DevCtx &c, const PtrList &L, size_t half, const Fr &r);
 void dev_pick0(DevCtx &c, const PtrList &L, int slot);
 void dev_dot_many(DevCtx &c, const Fr *E, const PtrList &L, size_t n, Fr *partials, int slot);
 void dev_sum3(DevCtx &c, const AbcList &L, size_t n, Fr *partials, int slot);
