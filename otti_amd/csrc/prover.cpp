@@ -43,8 +43,14 @@ void ensure_gens_device(Gens &g) {
     std::lock_guard<std::mutex> lk(device_objects_mu());
     if (g.dev) return;
     // the widest window the budget allows; if HBM is short right now (other tenants of the GPU, other generator sets), a narrower one
-    for (int c = device_window_bits(g.R + 2);; c -= 2) {
-        try { g.dev = build_device_gens(g, c); return; }
+    const int want = device_window_bits(g.R + 2);
+    for (int c = want;; c -= 2) {
+        try {
+            g.dev = build_device_gens(g, c);
+            // a narrower table means more additions in every MSM of every proof: say so once (otti_gens_table_info reports the width in use)
+            if (c != want) fprintf(stderr, "[otti] notice: HBM is short: generator window table built with c = %d instead of %d (%zu generators); proofs are unchanged, MSMs slower\n", c, want, g.R + 2);
+            return;
+        }
         catch (const OutOfDeviceMemory &) { if (c - 2 < 8 || getenv("OTTI_MSM_WINDOW")) throw; }
     }
 }
