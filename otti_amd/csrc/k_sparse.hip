@@ -1,4 +1,5 @@
-// K1 / K6: the sparse matrix-vector products (multiply_vec, compute_eval_table_sparse) and the CSR uploads, whole and sharded.
+// K1 / K6: the sparse matrix-vector products (multiply_vec, compute_eval_table_sparse) and the CSR copies they read, built on the device
+// from the uploaded entry lists (whole instance, or one rank's shard).
 #include "kernels_common.h"
 
 namespace otti {
@@ -64,22 +65,102 @@ void dev_spmv3(DevCtx &c, const DeviceCsrSet &m, const Fr *x, Fr *o0, Fr *o1, Fr
     }
 }
 
-static void upload_csr_set(DeviceCsrSet &d, const SparseMat M[3], bool by_col) {
-    size_t rows = by_col ? M[0].by_col.rows : M[0].by_row.rows;
+// ------------------------------------------------------------------------------------------------ CSR copies, built on the device
+// The host keeps the matrices as entry lists in caller order (upstream's Vec<SparseMatEntry>); the two access paths the kernels want
+// (by row for multiply_vec, by column for compute_eval_table_sparse) are counting sorts made here from ONE upload of the lists:
+// count per major index (atomics), exclusive scan -> ptr, scatter through per-row cursors.  The order of the entries inside a row
+// depends on the scatter's arrival order; every consumer adds the row's products in GF(l), where the sum does not depend on it.
+__global__ __launch_bounds__(kBlock) void k_csr_count(const uint32_t *major, size_t n, uint32_t *ptr) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) atomicAdd(&ptr[major[i] + 1], 1u);
+}
+__global__ __launch_bounds__(kBlock) void k_csr_fill(const uint32_t *major, const uint32_t *minor, const Fr *val, size_t n, uint32_t *cursor, uint32_t *idx, Fr *out) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t p = atomicAdd(&cursor[major[i]], 1u);
+        idx[p] = minor[i]; out[p] = val[i];
+    }
+}
+// in-place inclusive scan of u32 counts: every workgroup scans 4096 elements and reports its total; the totals are scanned the same way
+// (recursively: two levels reach 2^24 elements, three 2^36), then added back
+constexpr int kScanItems = 16;
+__global__ __launch_bounds__(kBlock) void k_scan_blocks(uint32_t *a, size_t n, uint32_t *totals) {
+    __shared__ uint32_t s_wave[kBlock / 64];
+    const size_t base = ((size_t)blockIdx.x * kBlock + threadIdx.x) * kScanItems;
+    uint32_t v[kScanItems], run = 0;
+#pragma unroll
+    for (int i = 0; i < kScanItems; i++) { run += base + i < n ? a[base + i] : 0u; v[i] = run; }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t x = run;
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)x, off, 64); if (lane >= off) x += y; }
+    if (lane == 63) s_wave[wave] = x;
+    __syncthreads();
+    uint32_t before = 0;
+    for (int k = 0; k < wave; k++) before += s_wave[k];
+    const uint32_t excl = before + x - run;
+#pragma unroll
+    for (int i = 0; i < kScanItems; i++) if (base + i < n) a[base + i] = v[i] + excl;
+    if (threadIdx.x == kBlock - 1) totals[blockIdx.x] = before + x;
+}
+__global__ __launch_bounds__(kBlock) void k_scan_add(uint32_t *a, size_t n, const uint32_t *totals_scanned) {
+    if (blockIdx.x == 0) return;
+    const uint32_t add = totals_scanned[blockIdx.x - 1];
+    const size_t base = ((size_t)blockIdx.x * kBlock + threadIdx.x) * kScanItems;
+#pragma unroll
+    for (int i = 0; i < kScanItems; i++) if (base + i < n) a[base + i] += add;
+}
+static void scan_inplace(DevCtx &c, uint32_t *a, size_t n, std::vector<DevBuf<uint32_t>> &levels, size_t depth = 0) {
+    const size_t per = (size_t)kBlock * kScanItems, nb = (n + per - 1) / per;
+    if (levels.size() <= depth) levels.emplace_back();
+    if (levels[depth].n < nb) { OTTI_HIP(hipStreamSynchronize(c.stream)); levels[depth].alloc(nb); }
+    hipLaunchKernelGGL(k_scan_blocks, (unsigned)nb, kBlock, 0, c.stream, a, n, levels[depth].p);
+    if (nb == 1) return;
+    uint32_t *totals = levels[depth].p;                       // (a deeper level may grow `levels`: take the pointer first)
+    scan_inplace(c, totals, nb, levels, depth + 1);
+    hipLaunchKernelGGL(k_scan_add, (unsigned)nb, kBlock, 0, c.stream, a, n, (const uint32_t *)totals);
+}
+// rows whose longest list (over the three matrices) exceeds kHeavyRow
+__global__ __launch_bounds__(kBlock) void k_csr_count_heavy(const uint32_t *p0, const uint32_t *p1, const uint32_t *p2, size_t rows, unsigned *count) {
+    for (size_t r = blockIdx.x * (size_t)blockDim.x + threadIdx.x; r < rows; r += (size_t)gridDim.x * blockDim.x)
+        if (max(p0[r + 1] - p0[r], max(p1[r + 1] - p1[r], p2[r + 1] - p2[r])) > (uint32_t)kHeavyRow) atomicAdd(count, 1u);
+}
+struct DeviceCoo { DevBuf<uint32_t> row, col; DevBuf<Fr> val; size_t n = 0; };
+static void upload_coo(DevCtx &c, DeviceCoo &d, const std::vector<uint32_t> &row, const std::vector<uint32_t> &col, const std::vector<Fr> &val) {
+    d.n = val.size();
+    d.row.alloc(std::max<size_t>(1, d.n)); d.col.alloc(std::max<size_t>(1, d.n)); d.val.alloc(std::max<size_t>(1, d.n));
+    if (!d.n) return;
+    OTTI_HIP(hipMemcpyAsync(d.row.p, row.data(), d.n * 4, hipMemcpyHostToDevice, c.stream));
+    OTTI_HIP(hipMemcpyAsync(d.col.p, col.data(), d.n * 4, hipMemcpyHostToDevice, c.stream));
+    OTTI_HIP(hipMemcpyAsync(d.val.p, val.data(), d.n * sizeof(Fr), hipMemcpyHostToDevice, c.stream));
+}
+static void build_csr_set(DevCtx &c, DeviceCsrSet &d, const DeviceCoo coo[3], bool by_col, size_t rows) {
+    if (rows + 1 > ((size_t)1 << 31)) throw Error(OTTI_ERR_BAD_ARG, "instance too large for 32-bit indices");
     d.rows = rows;
-    std::vector<uint32_t> heavy, seg_row, seg_no, seg_begin;
+    DevBuf<uint32_t> cursor(rows);
+    std::vector<DevBuf<uint32_t>> scan_levels; scan_levels.reserve(4);
     for (int k = 0; k < 3; k++) {
-        const Csr &s = by_col ? M[k].by_col : M[k].by_row;
-        d.ptr[k].alloc(s.ptr.size()); d.idx[k].alloc(std::max<size_t>(1, s.idx.size())); d.val[k].alloc(std::max<size_t>(1, s.val.size()));
-        OTTI_HIP(hipMemcpy(d.ptr[k].p, s.ptr.data(), s.ptr.size() * 4, hipMemcpyHostToDevice));
-        if (!s.idx.empty()) {
-            OTTI_HIP(hipMemcpy(d.idx[k].p, s.idx.data(), s.idx.size() * 4, hipMemcpyHostToDevice));
-            OTTI_HIP(hipMemcpy(d.val[k].p, s.val.data(), s.val.size() * sizeof(Fr), hipMemcpyHostToDevice));
+        const DeviceCoo &m = coo[k];
+        const uint32_t *major = by_col ? m.col.p : m.row.p, *minor = by_col ? m.row.p : m.col.p;
+        d.ptr[k].alloc(rows + 1); d.idx[k].alloc(std::max<size_t>(1, m.n)); d.val[k].alloc(std::max<size_t>(1, m.n));
+        OTTI_HIP(hipMemsetAsync(d.ptr[k].p, 0, (rows + 1) * 4, c.stream));
+        if (m.n) hipLaunchKernelGGL(k_csr_count, grid_for(m.n), kBlock, 0, c.stream, major, m.n, d.ptr[k].p);
+        scan_inplace(c, d.ptr[k].p, rows + 1, scan_levels);   // ptr[0] = 0: the inclusive sum over [0, rows] is the exclusive one shifted
+        if (m.n) {
+            OTTI_HIP(hipMemcpyAsync(cursor.p, d.ptr[k].p, rows * 4, hipMemcpyDeviceToDevice, c.stream));
+            hipLaunchKernelGGL(k_csr_fill, grid_for(m.n), kBlock, 0, c.stream, major, minor, (const Fr *)m.val.p, m.n, cursor.p, d.idx[k].p, d.val[k].p);
         }
     }
+    // long lists: found on the device; only when there are any do the row pointers come back for the segment lists
+    DevBuf<unsigned> n_heavy_dev(1); unsigned n_heavy = 0;
+    OTTI_HIP(hipMemsetAsync(n_heavy_dev.p, 0, sizeof(unsigned), c.stream));
+    hipLaunchKernelGGL(k_csr_count_heavy, grid_for(rows), kBlock, 0, c.stream, (const uint32_t *)d.ptr[0].p, (const uint32_t *)d.ptr[1].p, (const uint32_t *)d.ptr[2].p, rows, n_heavy_dev.p);
+    OTTI_HIP(hipMemcpyAsync(&n_heavy, n_heavy_dev.p, sizeof(unsigned), hipMemcpyDeviceToHost, c.stream));
+    OTTI_HIP(hipStreamSynchronize(c.stream));                 // also: cursor / scan scratch / the entry lists may go out of scope after this
+    d.n_heavy = 0; d.n_seg = 0;
+    if (!n_heavy) return;
+    std::vector<uint32_t> ptr[3], heavy, seg_row, seg_no, seg_begin;
+    for (int k = 0; k < 3; k++) { ptr[k].resize(rows + 1); OTTI_HIP(hipMemcpy(ptr[k].data(), d.ptr[k].p, (rows + 1) * 4, hipMemcpyDeviceToHost)); }
     for (size_t r = 0; r < rows; r++) {
         uint32_t mx = 0;
-        for (int k = 0; k < 3; k++) { const Csr &s = by_col ? M[k].by_col : M[k].by_row; mx = std::max(mx, s.ptr[r + 1] - s.ptr[r]); }
+        for (int k = 0; k < 3; k++) mx = std::max(mx, ptr[k][r + 1] - ptr[k][r]);
         if (mx > (uint32_t)kHeavyRow) {
             heavy.push_back((uint32_t)r); seg_begin.push_back((uint32_t)seg_row.size());
             for (uint32_t sn = 0; sn * kHeavySeg < mx; sn++) { seg_row.push_back((uint32_t)r); seg_no.push_back(sn); }
@@ -87,37 +168,41 @@ static void upload_csr_set(DeviceCsrSet &d, const SparseMat M[3], bool by_col) {
     }
     seg_begin.push_back((uint32_t)seg_row.size());
     d.n_heavy = heavy.size(); d.n_seg = seg_row.size();
-    if (!heavy.empty()) {
-        auto up = [](DevBuf<uint32_t> &b, const std::vector<uint32_t> &v) { b.alloc(v.size()); OTTI_HIP(hipMemcpy(b.p, v.data(), v.size() * 4, hipMemcpyHostToDevice)); };
-        up(d.heavy, heavy); up(d.seg_row, seg_row); up(d.seg_no, seg_no); up(d.seg_begin, seg_begin);
-    }
+    auto up = [](DevBuf<uint32_t> &b, const std::vector<uint32_t> &v) { b.alloc(v.size()); OTTI_HIP(hipMemcpy(b.p, v.data(), v.size() * 4, hipMemcpyHostToDevice)); };
+    up(d.heavy, heavy); up(d.seg_row, seg_row); up(d.seg_no, seg_no); up(d.seg_begin, seg_begin);
 }
 std::shared_ptr<DeviceInstance> upload_instance(const Instance &I) {
-    DevCtx::get();
+    DevCtx &c = DevCtx::get();
     auto d = std::make_shared<DeviceInstance>();
-    upload_csr_set(d->by_row, I.M, false); upload_csr_set(d->by_col, I.M, true);
+    DeviceCoo coo[3];
+    for (int k = 0; k < 3; k++) upload_coo(c, coo[k], I.M[k].row, I.M[k].col, I.M[k].val);
+    build_csr_set(c, d->by_row, coo, false, I.num_cons);
+    build_csr_set(c, d->by_col, coo, true, 2 * I.num_vars);
     d->nnz = I.M[0].val.size() + I.M[1].val.size() + I.M[2].val.size();
     return d;
 }
 
 std::shared_ptr<DeviceShard> upload_instance_shard(const Instance &I, int rank, int world) {
-    DevCtx::get();
+    DevCtx &c = DevCtx::get();
     if (world < 1 || (world & (world - 1)) || rank < 0 || rank >= world || (size_t)world > I.num_cons || (size_t)world > 2 * I.num_vars)
         throw Error(OTTI_ERR_BAD_ARG, "shard: world must be a power of two not larger than the instance");
     auto d = std::make_shared<DeviceShard>();
     d->rank = rank; d->world = world;
     const uint32_t g = (uint32_t)world, k = (uint32_t)rank;
-    SparseMat rows[3], cols[3];
+    // rows r = k (mod g) renumbered r / g, columns untouched; and the entries of columns c = k (mod g) renumbered c / g, rows untouched
+    DeviceCoo rows[3], cols[3];
     for (int m = 0; m < 3; m++) {
         const SparseMat &M = I.M[m];
+        std::vector<uint32_t> rr, rc, cr, cc; std::vector<Fr> rv, cv;
         for (size_t e = 0; e < M.val.size(); e++) {
-            if (M.row[e] % g == k) { rows[m].row.push_back(M.row[e] / g); rows[m].col.push_back(M.col[e]); rows[m].val.push_back(M.val[e]); }
-            if (M.col[e] % g == k) { cols[m].row.push_back(M.row[e]); cols[m].col.push_back(M.col[e] / g); cols[m].val.push_back(M.val[e]); }
+            if (M.row[e] % g == k) { rr.push_back(M.row[e] / g); rc.push_back(M.col[e]); rv.push_back(M.val[e]); }
+            if (M.col[e] % g == k) { cr.push_back(M.row[e]); cc.push_back(M.col[e] / g); cv.push_back(M.val[e]); }
         }
-        build_csr(rows[m].by_row, rows[m].row, rows[m].col, rows[m].val, I.num_cons / g);
-        build_csr(cols[m].by_col, cols[m].col, cols[m].row, cols[m].val, 2 * I.num_vars / g);
+        upload_coo(c, rows[m], rr, rc, rv); upload_coo(c, cols[m], cr, cc, cv);
+        OTTI_HIP(hipStreamSynchronize(c.stream));             // the host lists above go out of scope
     }
-    upload_csr_set(d->by_row, rows, false); upload_csr_set(d->by_col, cols, true);
+    build_csr_set(c, d->by_row, rows, false, I.num_cons / g);
+    build_csr_set(c, d->by_col, cols, true, 2 * I.num_vars / g);
     return d;
 }
 

@@ -23,17 +23,15 @@ inline size_t ilog2(size_t n) { size_t l = 0; while (((size_t)1 << l) < n) l++; 
 inline size_t next_pow2(size_t n) { size_t p = 1; while (p < n) p <<= 1; return p; }
 
 // ---------------------------------------------------------------------------------------------- sparse matrices
-// Compressed-row storage with 32-bit indices (N, 2V <= 2^31); values are Montgomery-form Fr.
-struct Csr { std::vector<uint32_t> ptr, idx; std::vector<Fr> val; size_t rows = 0; };
+// 32-bit indices (N, 2V <= 2^31); values are Montgomery-form Fr.  The host keeps the entry list; the access paths of multiply_vec /
+// compute_eval_table_sparse (CSR by row / by column) exist in HBM only (device.h DeviceCsrSet, built by k_sparse.hip).
 struct SparseMat {
     std::vector<uint32_t> row, col; std::vector<Fr> val;    // entry list in caller order (as upstream's Vec<SparseMatEntry>)
-    Csr by_row, by_col;                                     // multiply_vec / compute_eval_table_sparse access paths
 };
 
 struct DeviceInstance;   // device.h / k_sparse.hip
 struct DeviceShard;      // device.h / k_sparse.hip: this rank's slice of the instance when one proof runs over several GPUs (shard.h)
 struct DeviceGens;       // device.h / k_msm.hip
-void build_csr(Csr &out, const std::vector<uint32_t> &major, const std::vector<uint32_t> &minor, const std::vector<Fr> &val, size_t rows);
 
 struct Instance {
     size_t num_cons = 0, num_vars = 0, num_inputs = 0;      // padded cons / vars (powers of two)

@@ -11,15 +11,6 @@
 namespace otti {
 
 // ================================================================================================ instance (lib.rs Instance::new)
-void build_csr(Csr &out, const std::vector<uint32_t> &major, const std::vector<uint32_t> &minor, const std::vector<Fr> &val, size_t rows) {
-    out.rows = rows; out.ptr.assign(rows + 1, 0);
-    for (uint32_t r : major) out.ptr[r + 1]++;
-    for (size_t i = 0; i < rows; i++) out.ptr[i + 1] += out.ptr[i];
-    out.idx.resize(major.size()); out.val.resize(major.size());
-    std::vector<uint32_t> cur(out.ptr.begin(), out.ptr.end() - 1);
-    for (size_t i = 0; i < major.size(); i++) { uint32_t p = cur[major[i]]++; out.idx[p] = minor[i]; out.val[p] = val[i]; }
-}
-
 std::unique_ptr<Instance> instance_new(size_t num_cons, size_t num_vars, size_t num_inputs, const otti_entry *A, size_t nA,
                                        const otti_entry *B, size_t nB, const otti_entry *C, size_t nC) {
     size_t nvp = next_pow2(std::max(num_vars, num_inputs + 1));
@@ -61,16 +52,7 @@ std::unique_ptr<Instance> instance_new(size_t num_cons, size_t num_vars, size_t 
         }
     }
     // (upstream also appends explicit zero entries when num_cons < 2; zeros change nothing for the satisfiability proof and are not stored)
-    {   // the six CSR copies (by row and by column, three matrices) are independent counting sorts
-        std::vector<std::thread> th;
-        for (int k = 0; k < 3; k++) {
-            SparseMat *m = &I->M[k];
-            auto by_row = [m, ncp] { build_csr(m->by_row, m->row, m->col, m->val, ncp); };
-            auto by_col = [m, nvp] { build_csr(m->by_col, m->col, m->row, m->val, 2 * nvp); };
-            if (nt > 1) { th.emplace_back(by_row); th.emplace_back(by_col); } else { by_row(); by_col(); }
-        }
-        for (auto &x : th) x.join();
-    }
+    // the access paths the kernels read (CSR by row and by column) are built on the device from these lists (k_sparse.hip upload_instance)
     return I;
 }
 
@@ -108,8 +90,8 @@ bool Instance::is_sat(const std::vector<Fr> &vars, const std::vector<Fr> &inputs
     std::vector<Fr> Mz[3];
     for (int k = 0; k < 3; k++) {
         Mz[k].assign(num_cons, fr_zero());
-        const Csr &c = M[k].by_row;
-        for (size_t r = 0; r < num_cons; r++) { Fr acc = fr_zero(); for (uint32_t p = c.ptr[r]; p < c.ptr[r + 1]; p++) acc = fr_add(acc, fr_mul(c.val[p], z[c.idx[p]])); Mz[k][r] = acc; }
+        const SparseMat &m = M[k];
+        for (size_t i = 0; i < m.val.size(); i++) Mz[k][m.row[i]] = fr_add(Mz[k][m.row[i]], fr_mul(m.val[i], z[m.col[i]]));
     }
     for (size_t r = 0; r < num_cons; r++) if (!fr_eq(fr_mul(Mz[0][r], Mz[1][r]), Mz[2][r])) return false;
     return true;
