@@ -5,8 +5,9 @@
 // Data flow of R1CSEvalProof: the dense representation of A, B, C (addresses, timestamps, values: 16 N + 2 M field elements) and the
 // two generator window tables stay in HBM; per proof the device builds eq(rx), eq(ry), dereferences them by address (6 N elements, committed
 // with the bulk MSM), hashes 12 operation vectors and 4 memory vectors into product circuits (about 24 N + 8 M elements with all layers),
-// and plays the layered sum-checks: every round is one evaluation launch over all tables of the batch plus one fold launch; the host
-// only hashes four scalars per round (this sum-check is not zero-knowledge: no commitments on the sequential path).  The three closing
+// and plays the layered sum-checks: every round is ONE launch over all tables of the batch (fold by the previous challenge + this round's
+// sums, pcbatch_prove below), the last rounds of every layer on the host; the host only hashes four scalars per round (this sum-check is
+// not zero-knowledge: no commitments on the sequential path).  The three closing
 // polynomial-evaluation proofs reuse the log-size dot-product prover of NIZK mode (bullet rounds on the original generators).
 #include "snark.h"
 #include "snark_dev.h"
