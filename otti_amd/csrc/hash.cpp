@@ -1,5 +1,6 @@
 // See hash.h.  FIPS 202 Keccak-f[1600]; STROBE-128 per merlin's strobe.rs subset; Merlin v1.0 framing.
 #include "hash.h"
+#include <algorithm>
 #include <stdexcept>
 #include <string>
 #include <stdio.h>
@@ -39,7 +40,11 @@ void Shake256::absorb(const void *data, size_t n) {
 void Shake256::squeeze(void *out, size_t n) {
     uint8_t *b = (uint8_t *)st_, *o = (uint8_t *)out;
     if (!squeezing_) { b[pos_] ^= 0x1f; b[135] ^= 0x80; keccak_f1600(st_); pos_ = 0; squeezing_ = true; }
-    for (size_t i = 0; i < n; i++) { if (pos_ == 136) { keccak_f1600(st_); pos_ = 0; } o[i] = b[pos_++]; }
+    while (n) {                                                // generator derivation squeezes 64 bytes per point: whole blocks at a time
+        if (pos_ == 136) { keccak_f1600(st_); pos_ = 0; }
+        const size_t take = std::min<size_t>(n, 136 - pos_);
+        memcpy(o, b + pos_, take); pos_ += take; o += take; n -= take;
+    }
 }
 
 namespace {
@@ -59,9 +64,36 @@ void Strobe128::run_f() {
     keccak_f1600((uint64_t *)st_);
     pos_ = 0; pos_begin_ = 0;
 }
-void Strobe128::absorb(const uint8_t *d, size_t n) { for (size_t i = 0; i < n; i++) { st_[pos_++] ^= d[i]; if (pos_ == kRate) run_f(); } }
-void Strobe128::overwrite(const uint8_t *d, size_t n) { for (size_t i = 0; i < n; i++) { st_[pos_++] = d[i]; if (pos_ == kRate) run_f(); } }
-void Strobe128::squeeze(uint8_t *d, size_t n) { for (size_t i = 0; i < n; i++) { d[i] = st_[pos_]; st_[pos_++] = 0; if (pos_ == kRate) run_f(); } }
+// the duplex operations in chunks up to the rate boundary (a 2^20 proof absorbs ~100 KB: a thousand commitments, then ~10 messages per round)
+static inline void xor_bytes(uint8_t *dst, const uint8_t *src, size_t n) {
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) { uint64_t a, b; memcpy(&a, dst + i, 8); memcpy(&b, src + i, 8); a ^= b; memcpy(dst + i, &a, 8); }
+    for (; i < n; i++) dst[i] ^= src[i];
+}
+void Strobe128::absorb(const uint8_t *d, size_t n) {
+    while (n) {
+        const size_t take = std::min<size_t>(n, (size_t)kRate - pos_);
+        xor_bytes(st_ + pos_, d, take);
+        pos_ = (uint8_t)(pos_ + take); d += take; n -= take;
+        if (pos_ == kRate) run_f();
+    }
+}
+void Strobe128::overwrite(const uint8_t *d, size_t n) {
+    while (n) {
+        const size_t take = std::min<size_t>(n, (size_t)kRate - pos_);
+        memcpy(st_ + pos_, d, take);
+        pos_ = (uint8_t)(pos_ + take); d += take; n -= take;
+        if (pos_ == kRate) run_f();
+    }
+}
+void Strobe128::squeeze(uint8_t *d, size_t n) {
+    while (n) {
+        const size_t take = std::min<size_t>(n, (size_t)kRate - pos_);
+        memcpy(d, st_ + pos_, take); memset(st_ + pos_, 0, take);
+        pos_ = (uint8_t)(pos_ + take); d += take; n -= take;
+        if (pos_ == kRate) run_f();
+    }
+}
 void Strobe128::begin_op(uint8_t flags, bool more) {
     if (more) { if (flags != cur_flags_) throw std::logic_error("strobe: continued op with different flags"); return; }
     if (flags & FT) throw std::logic_error("strobe: transport ops unsupported");
