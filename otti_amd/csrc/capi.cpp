@@ -80,6 +80,13 @@ int32_t otti_host_selftest(uint32_t iterations) {
             const Pt want = pt_add(rnd, host_scalarmul(g->P[base], s));
             pt_encode_ref(a, acc); pt_encode_ref(b, want);
             if (memcmp(a, b, 32)) throw Error(OTTI_ERR_INTERNAL, "fixed-base table result differs from the variable-base multiplication");
+            {   // five-limb extended addition against the generic one
+                PtFe x = ptfe_from(rnd); ptfe_add(x, ptfe_from(want));
+                pt_encode_fe(a, x); pt_encode_ref(b, pt_add(rnd, want));
+                if (memcmp(a, b, 32)) throw Error(OTTI_ERR_INTERNAL, "five-limb point addition differs from pt_add");
+                x = ptfe_identity(); ptfe_add(x, ptfe_from(rnd)); pt_encode_fe(a, x); pt_encode_ref(b, rnd);
+                if (memcmp(a, b, 32)) throw Error(OTTI_ERR_INTERNAL, "five-limb addition to the identity changed a point");
+            }
             pt_encode_fast(a, pt_identity()); pt_encode_ref(b, pt_identity());
             if (memcmp(a, b, 32)) throw Error(OTTI_ERR_INTERNAL, "identity encodes differently");
         }
@@ -112,7 +119,7 @@ int32_t otti_host_microbench(double out[10]) {
             const int rounds = 200;
             Transcript tr("bench", 5); RandomTape tape(w);
             SumcheckState st; sumcheck_draw_tape(st, tape, rounds, 4);
-            for (auto &p : st.pre) { Term t = {g->sc_4.h, st.blinds_poly[0]}; p.bp_h = g->commit_terms(&t, 1); p.be_h = p.bp_h; p.rb_h = p.bp_h; p.delta = p.bp_h; pt_encode(p.delta_c.b, p.delta); }
+            for (auto &p : st.pre) { Term t = {g->sc_4.h, st.blinds_poly[0]}; p.bp_h = g->commit_terms(&t, 1); p.be_h = p.bp_h; p.rb_h = p.bp_h; p.delta = p.bp_h; p.to_fe(); pt_encode(p.delta_c.b, p.delta); }
             st.claim = s; st.blind_claim = s2; pt_encode(st.comm_claim.b, rnd);
             ZKSumcheckProof pf; pf.comm_polys.resize(rounds); pf.comm_evals.resize(rounds); pf.proofs.resize(rounds);
             double tb = 0, tf = 0;

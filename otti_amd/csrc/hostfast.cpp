@@ -104,9 +104,22 @@ void ptfe_madd(PtFe &p, const NielsFe &q, bool negate) {
     p.X = fe_mul(e, f); p.Y = fe_mul(g, h); p.T = fe_mul(e, h); p.Z = fe_mul(f, g);
 }
 
-void pt_encode_fast(uint8_t out[32], const Pt &p) {
+PtFe ptfe_identity() { static const PtFe id = ptfe_from(pt_identity()); return id; }
+// add-2008-hwcd-3 with both operands extended: the same formula as pt_add (point.h)
+void ptfe_add(PtFe &p, const PtFe &q) {
+    static const Fe d2 = fe_from_fp(fp_2D());
+    const Fe a = fe_mul(fe_sub(p.Y, p.X), fe_sub(q.Y, q.X));
+    const Fe b = fe_mul(fe_add(p.Y, p.X), fe_add(q.Y, q.X));
+    const Fe c = fe_mul(fe_mul(p.T, d2), q.T);
+    const Fe zz = fe_mul(p.Z, q.Z), d = fe_add(zz, zz);
+    const Fe e = fe_sub(b, a), f = fe_sub(d, c), g = fe_add(d, c), h = fe_add(b, a);
+    p.X = fe_mul(e, f); p.Y = fe_mul(g, h); p.T = fe_mul(e, h); p.Z = fe_mul(f, g);
+}
+
+void pt_encode_fast(uint8_t out[32], const Pt &p) { pt_encode_fe(out, ptfe_from(p)); }
+void pt_encode_fe(uint8_t out[32], const PtFe &p) {
     static const Fe sqrt_m1 = fe_from_fp(fp_SQRT_M1()), invsqrt_a_minus_d = fe_from_fp(fp_INVSQRT_A_MINUS_D());
-    const Fe X = fe_from_fp(p.X), Y = fe_from_fp(p.Y), Z = fe_from_fp(p.Z), T = fe_from_fp(p.T);
+    const Fe &X = p.X, &Y = p.Y, &Z = p.Z, &T = p.T;
     const Fe u1 = fe_mul(fe_add(Z, Y), fe_sub(Z, Y)), u2 = fe_mul(X, Y);
     // SQRT_RATIO_M1(1, v), v = u1 * u2^2  (RFC 9496 4.2): r = v^3 (v^7)^((p-5)/8); fix the sign of the root by what v r^2 turns out to be
     const Fe v = fe_mul(u1, fe_sqr(u2));

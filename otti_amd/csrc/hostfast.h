@@ -20,8 +20,11 @@ PtFe ptfe_from(const Pt &p);
 Pt ptfe_to(const PtFe &p);
 NielsFe nielsfe_from(const Niels &n);
 void ptfe_madd(PtFe &p, const NielsFe &q, bool negate);      // p += q (or -= q)
+void ptfe_add(PtFe &p, const PtFe &q);                       // p += q (unified extended addition, 9M)
+PtFe ptfe_identity();
 
 // RFC 9496 4.3.2 Encode; identical output to pt_encode (point.h)
 void pt_encode_fast(uint8_t out[32], const Pt &p);
+void pt_encode_fe(uint8_t out[32], const PtFe &p);           // the same from the five-limb form
 
 }  // namespace otti

@@ -138,7 +138,7 @@ void precompute_round_points_collect(DevCtx &c, const RoundPointsJob &job, Sumch
     OTTI_HIP(hipEventSynchronize(c.ev1));
     SumcheckState *st[2] = {&s1, &s2}; size_t row = 0;
     for (int k = 0; k < 2; k++)
-        for (auto &p : st[k]->pre) { p.delta = c.h_pts[row]; p.bp_h = c.h_pts[row + 1]; p.be_h = c.h_pts[row + 2]; p.rb_h = c.h_pts[row + 3]; row += 4; }
+        for (auto &p : st[k]->pre) { p.delta = c.h_pts[row]; p.bp_h = c.h_pts[row + 1]; p.be_h = c.h_pts[row + 2]; p.rb_h = c.h_pts[row + 3]; p.to_fe(); row += 4; }
     // compress the deltas now, off the per-round path, striped over the helper threads
     std::vector<RoundPre *> all; for (int k = 0; k < 2; k++) for (auto &p : st[k]->pre) all.push_back(&p);
     SpinPool &pool = SpinPool::get(); const int nt = pool.workers() + 1;

@@ -61,6 +61,7 @@ struct Gens {
     std::vector<FixedBaseTable> small_tables;               // host tables for P[0..4], P[R], P[R+1]
     std::shared_ptr<DeviceGens> dev;                        // device window table, built lazily
     Pt commit_terms(const Term *t, size_t n) const;         // host, fixed-base tables only
+    PtFe commit_terms_fe(const Term *t, size_t n) const;    // the same, staying in the five-limb form of the sequential path (hostfast.h)
     void commit_terms_c(uint8_t out[32], const Term *t, size_t n) const { Pt p = commit_terms(t, n); pt_encode(out, p); }
     Pt commit_generic(const Fr *v, size_t n, const Fr &blind, const GensView &g) const;   // host MSM (verifier)
 };
@@ -111,6 +112,8 @@ struct RoundPre {
     Fr d[4], r_delta, r_beta;          // DotProductProof::prove draws: d_vec, r_delta, r_beta
     Pt delta; CPoint delta_c;          // commit(d_vec, r_delta) over gens_n, and its compressed form
     Pt bp_h, be_h, rb_h;               // blinds_poly[j]*h_n, blinds_evals[j]*h_1, r_beta*h_1
+    PtFe bp_fe, be_fe, rb_fe;          // the same in the host's five-limb form (RoundPre::to_fe)
+    void to_fe() { bp_fe = ptfe_from(bp_h); be_fe = ptfe_from(be_h); rb_fe = ptfe_from(rb_h); }
 };
 struct SumcheckState { Fr claim; CPoint comm_claim; Fr blind_claim; std::vector<Fr> blinds_poly, blinds_evals; std::vector<RoundPre> pre; };
 struct RoundPart1 { Fr poly[4]; size_t ne; Fr r_j; };

@@ -145,15 +145,16 @@ std::unique_ptr<Gens> gens_new(size_t num_cons, size_t num_vars, size_t num_inpu
     return g;
 }
 
-Pt Gens::commit_terms(const Term *t, size_t n) const {
-    PtFe acc = ptfe_from(pt_identity());
+PtFe Gens::commit_terms_fe(const Term *t, size_t n) const {
+    PtFe acc = ptfe_identity();
     for (size_t i = 0; i < n; i++) {
         int slot = small_slot[t[i].base];
         if (slot < 0) throw Error(OTTI_ERR_INTERNAL, "commit_terms: base without a host table");
         small_tables[slot].accumulate(acc, t[i].s);
     }
-    return ptfe_to(acc);
+    return acc;
 }
+Pt Gens::commit_terms(const Term *t, size_t n) const { return ptfe_to(commit_terms_fe(t, n)); }
 Pt Gens::commit_generic(const Fr *v, size_t n, const Fr &blind, const GensView &gv) const {
     std::vector<Fr> s(v, v + n); s.push_back(blind);
     std::vector<Pt> pts(n + 1);
@@ -248,7 +249,7 @@ void sumcheck_draw_tape(SumcheckState &st, ScalarSource &tape, size_t num_rounds
         p.r_delta = tape.random_scalar("r_delta"); p.r_beta = tape.random_scalar("r_beta");
     }
 }
-static CPoint encode_sum(const Pt &a, const Pt &b) { CPoint c; pt_encode(c.b, pt_add(a, b)); return c; }
+static CPoint encode_sum(PtFe a, const PtFe &b) { CPoint c; ptfe_add(a, b); pt_encode_fe(c.b, a); return c; }
 
 // the transcript work of one round, split at the challenge so the device can fold while the host finishes
 RoundPart1 sumcheck_round_begin(ZKSumcheckProof &pf, size_t j, const Fr *evals, size_t ne, const SumcheckState &st, const Gens &g,
@@ -256,12 +257,12 @@ RoundPart1 sumcheck_round_begin(ZKSumcheckProof &pf, size_t j, const Fr *evals, 
     RoundPart1 p; p.ne = ne;
     unipoly_from_evals(p.poly, evals, ne);
     // commit(poly, blinds_poly[j]) over gens_n: one fixed-base term per coefficient, spread over the helper threads
-    Pt part[4]; std::function<void()> tasks[4];
-    for (size_t i = 0; i < ne; i++) tasks[i] = [&, i] { Term t = {gn.G[i], p.poly[i]}; part[i] = g.commit_terms(&t, 1); };
+    PtFe part[4]; std::function<void()> tasks[4];
+    for (size_t i = 0; i < ne; i++) tasks[i] = [&, i] { Term t = {gn.G[i], p.poly[i]}; part[i] = g.commit_terms_fe(&t, 1); };
     SpinPool::get().parallel(tasks, (int)ne);
-    Pt sum = st.pre[j].bp_h;
-    for (size_t i = 0; i < ne; i++) sum = pt_add(sum, part[i]);
-    pt_encode(pf.comm_polys[j].b, sum);
+    PtFe sum = st.pre[j].bp_fe;
+    for (size_t i = 0; i < ne; i++) ptfe_add(sum, part[i]);
+    pt_encode_fe(pf.comm_polys[j].b, sum);
     tr.append_point("comm_poly", pf.comm_polys[j].b);
     p.r_j = tr.challenge_scalar("challenge_nextround");
     return p;
@@ -271,7 +272,7 @@ void sumcheck_round_finish(ZKSumcheckProof &pf, size_t j, const RoundPart1 &p1, 
     const size_t ne = p1.ne; const RoundPre &pre = st.pre[j]; (void)gn;
     Fr eval = unipoly_eval(p1.poly, ne, p1.r_j);
     Term te = {g.sc_1.G[0], eval};
-    CPoint comm_eval = encode_sum(g.commit_terms(&te, 1), pre.be_h);                       // commit(eval, blinds_evals[j]) over gens_1
+    CPoint comm_eval = encode_sum(g.commit_terms_fe(&te, 1), pre.be_fe);                       // commit(eval, blinds_evals[j]) over gens_1
     tr.append_point("comm_claim_per_round", st.comm_claim.b);
     tr.append_point("comm_eval", comm_eval.b);
     std::vector<Fr> w = tr.challenge_vector("combine_two_claims_to_one", 2);
@@ -283,11 +284,11 @@ void sumcheck_round_finish(ZKSumcheckProof &pf, size_t j, const RoundPart1 &p1, 
     Fr ad = fr_zero(); for (size_t i = 0; i < ne; i++) ad = fr_add(ad, fr_mul(a[i], pre.d[i]));
     // DotProductProof::prove(gens_1, gens_n, poly, blinds_poly[j], a, target, blind); Cx is this round's comm_poly.
     // Cy = commit(target, blind) and beta = commit(<a,d>, r_beta) are independent: three concurrent pieces.
-    DotProductProof dp; Pt cy_g, cy_h; CPoint Cy;
+    DotProductProof dp; PtFe cy_g, cy_h; CPoint Cy;
     std::function<void()> tasks[3] = {
-        [&] { Term t = {g.sc_1.G[0], target}; cy_g = g.commit_terms(&t, 1); },
-        [&] { Term t = {g.sc_1.h, blind}; cy_h = g.commit_terms(&t, 1); },
-        [&] { Term t = {g.sc_1.G[0], ad}; dp.beta = encode_sum(g.commit_terms(&t, 1), pre.rb_h); }};
+        [&] { Term t = {g.sc_1.G[0], target}; cy_g = g.commit_terms_fe(&t, 1); },
+        [&] { Term t = {g.sc_1.h, blind}; cy_h = g.commit_terms_fe(&t, 1); },
+        [&] { Term t = {g.sc_1.G[0], ad}; dp.beta = encode_sum(g.commit_terms_fe(&t, 1), pre.rb_fe); }};
     SpinPool &pool = SpinPool::get();
     int nw = pool.workers();
     if (nw >= 2) {
