@@ -24,6 +24,14 @@ void dev_gather(DevCtx &c, const Fr *table, const uint32_t *idx, Fr *out, size_t
     hipLaunchKernelGGL(k_gather, grid_for(n), kBlock, 0, c.stream, table, idx, out, n);
 }
 
+// addresses and timestamps of the dense representation: small integers -> Montgomery form
+__global__ __launch_bounds__(kBlock) void k_u32_to_fr(const uint32_t *in, Fr *out, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = fr_from_u64((uint64_t)in[i]);
+}
+void dev_u32_to_fr(DevCtx &c, const uint32_t *in, Fr *out, size_t n) {
+    if (n) hipLaunchKernelGGL(k_u32_to_fr, grid_for(n), kBlock, 0, c.stream, in, out, n);
+}
+
 // hash(addr, val, ts) - gamma = ts * r^2 + val * r + addr - gamma
 __device__ __forceinline__ Fr hash3(const Fr &addr, const Fr &val, const Fr &ts, const Fr &r, const Fr &r2, const Fr &gamma) {
     return fr_sub(fr_add(fr_add(fr_mul(ts, r2), fr_mul(val, r)), addr), gamma);

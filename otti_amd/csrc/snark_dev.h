@@ -21,6 +21,7 @@ unsigned long long dev_pc_fold_eval(DevCtx &c, const PcList &L, size_t len, cons
 unsigned long long dev_pc_export(DevCtx &c, const PcList &L, size_t len, bool fold, const Fr *r, int slot);
 
 void dev_gather(DevCtx &c, const Fr *table, const uint32_t *idx, Fr *out, size_t n);
+void dev_u32_to_fr(DevCtx &c, const uint32_t *in, Fr *out, size_t n);        // out[i] = in[i] as a field element (Montgomery form)
 void dev_hash_mem(DevCtx &c, const Fr *eval_table, const Fr *audit_ts, Fr *out_init, Fr *out_audit, size_t M, const Fr &r, const Fr &gamma);
 void dev_hash_ops(DevCtx &c, const Fr *addr_f, const Fr *deref, const Fr *read_ts, Fr *out_read, Fr *out_write, size_t N, const Fr &r, const Fr &gamma);
 void dev_prod_layer(DevCtx &c, const LayerList &L, size_t q);

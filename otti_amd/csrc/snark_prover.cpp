@@ -13,6 +13,7 @@
 #include "snark_dev.h"
 #include "pool.h"
 #include <chrono>
+#include <thread>
 
 namespace otti {
 
@@ -62,39 +63,57 @@ std::unique_ptr<CompComm> snark_encode_gpu(Instance &I, SnarkGens &g) {
     const size_t N = next_pow2(std::max<size_t>(nz, 2)), M = (size_t)1 << std::max(ilog2(I.num_cons), ilog2(2 * I.num_vars));
     if (ilog2(16 * N) != g.ops.num_vars || ilog2(2 * M) != g.mem.num_vars) throw Error(OTTI_ERR_BAD_ARG, "SNARK generators were made for a different number of non-zero entries");
     auto dec = std::make_shared<DeviceDecomm>(); dec->N = N; dec->M = M;
-    // MultiSparseMatPolynomialAsDense on the host (the timestamps are a sequential scan: read_ts = visits of that address so far), once per circuit
-    std::vector<Fr> comb_ops(16 * N, fr_zero()), comb_mem(2 * M, fr_zero());
-    std::vector<uint32_t> addr[2][3];
+    const bool trace = getenv("OTTI_TRACE") != nullptr; double t_lap = now_ms();
+    auto lap = [&](const char *what) { if (!trace) return; c.sync(); const double t = now_ms(); fprintf(stderr, "[otti] snark_encode %-34s %.3f ms\n", what, t - t_lap); t_lap = t; };
+    // MultiSparseMatPolynomialAsDense.  The host does the part that is a sequential scan over small integers (read_ts = visits of that
+    // address so far, audit_ts = visits in total, shared by A, B, C) on u32 lists; their expansion to field elements (16 N + 2 M Montgomery
+    // products) happens on the device, next to where the lists are needed anyway as gather indices.
+    std::vector<uint32_t> addr[2][3], read_ts[2][3], audit[2];
     for (int k = 0; k < 3; k++) {
         const SparseMat &m = I.M[k];
         addr[0][k].assign(N, 0); addr[1][k].assign(N, 0);
-        for (size_t i = 0; i < m.val.size(); i++) { addr[0][k][i] = m.row[i]; addr[1][k][i] = m.col[i]; comb_ops[(size_t)(12 + k) * N + i] = m.val[i]; }
+        for (size_t i = 0; i < m.val.size(); i++) { addr[0][k][i] = m.row[i]; addr[1][k][i] = m.col[i]; }
         if (I.given_cons < 2)                                 // upstream pads 0 / 1 constraints with explicit zero entries (row i, column num_vars)
             for (size_t i = m.val.size(); i < I.num_cons; i++) { addr[0][k][i] = (uint32_t)i; addr[1][k][i] = (uint32_t)I.num_vars; }
     }
-    for (int side = 0; side < 2; side++) {                    // AddrTimestamps::new: audit_ts is shared by the three matrices
-        std::vector<uint32_t> audit(M, 0);
-        for (int k = 0; k < 3; k++)
-            for (size_t i = 0; i < N; i++) {
-                const uint32_t a = addr[side][k][i];
-                comb_ops[(size_t)(6 * side + k) * N + i] = fr_from_u64(a);
-                comb_ops[(size_t)(6 * side + 3 + k) * N + i] = fr_from_u64(audit[a]++);
-            }
-        for (size_t i = 0; i < M; i++) comb_mem[(size_t)side * M + i] = fr_from_u64(audit[i]);
-    }
+    auto scan_side = [&](int side) {                          // AddrTimestamps::new: audit_ts is shared by the three matrices
+        audit[side].assign(M, 0);
+        for (int k = 0; k < 3; k++) {
+            read_ts[side][k].resize(N);
+            for (size_t i = 0; i < N; i++) read_ts[side][k][i] = audit[side][addr[side][k][i]]++;
+        }
+    };
+    { std::thread other(scan_side, 1); scan_side(0); other.join(); }
+    lap("address / timestamp scans (host)");
     dec->comb_ops.alloc(16 * N); dec->comb_mem.alloc(2 * M);
-    OTTI_HIP(hipMemcpyAsync(dec->comb_ops.p, comb_ops.data(), comb_ops.size() * sizeof(Fr), hipMemcpyHostToDevice, c.stream));
-    OTTI_HIP(hipMemcpyAsync(dec->comb_mem.p, comb_mem.data(), comb_mem.size() * sizeof(Fr), hipMemcpyHostToDevice, c.stream));
-    for (int k = 0; k < 3; k++) {
-        dec->row_addr[k].alloc(N); dec->col_addr[k].alloc(N);
-        OTTI_HIP(hipMemcpyAsync(dec->row_addr[k].p, addr[0][k].data(), N * 4, hipMemcpyHostToDevice, c.stream));
-        OTTI_HIP(hipMemcpyAsync(dec->col_addr[k].p, addr[1][k].data(), N * 4, hipMemcpyHostToDevice, c.stream));
+    {
+        DevBuf<uint32_t> tmp(std::max(N, M));
+        OTTI_HIP(hipMemsetAsync(dec->comb_ops.p + 12 * N, 0, 4 * N * sizeof(Fr), c.stream));      // values (zero-padded) and the unused sixteenth part
+        for (int k = 0; k < 3; k++) {
+            dec->row_addr[k].alloc(N); dec->col_addr[k].alloc(N);
+            OTTI_HIP(hipMemcpyAsync(dec->row_addr[k].p, addr[0][k].data(), N * 4, hipMemcpyHostToDevice, c.stream));
+            OTTI_HIP(hipMemcpyAsync(dec->col_addr[k].p, addr[1][k].data(), N * 4, hipMemcpyHostToDevice, c.stream));
+            dev_u32_to_fr(c, dec->row_addr[k].p, dec->part(0, k), N); dev_u32_to_fr(c, dec->col_addr[k].p, dec->part(2, k), N);
+            for (int side = 0; side < 2; side++) {
+                OTTI_HIP(hipMemcpyAsync(tmp.p, read_ts[side][k].data(), N * 4, hipMemcpyHostToDevice, c.stream));
+                dev_u32_to_fr(c, tmp.p, dec->part(2 * side + 1, k), N);
+                OTTI_HIP(hipStreamSynchronize(c.stream));     // tmp is reused (the copies come from pageable memory: nothing to overlap with)
+            }
+            if (!I.M[k].val.empty()) OTTI_HIP(hipMemcpyAsync(dec->part(4, k), I.M[k].val.data(), I.M[k].val.size() * sizeof(Fr), hipMemcpyHostToDevice, c.stream));
+        }
+        for (int side = 0; side < 2; side++) {
+            OTTI_HIP(hipMemcpyAsync(tmp.p, audit[side].data(), M * 4, hipMemcpyHostToDevice, c.stream));
+            dev_u32_to_fr(c, tmp.p, dec->comb_mem.p + (size_t)side * M, M);
+            OTTI_HIP(hipStreamSynchronize(c.stream));
+        }
     }
-    c.sync();
+    lap("uploads + expansion to field elements");
     auto cc = std::make_unique<CompComm>();
     cc->num_cons = I.num_cons; cc->num_vars = I.num_vars; cc->num_inputs = I.num_inputs; cc->num_ops = N; cc->num_mem_cells = M;
     cc->comm_ops = commit_poly(c, *g.eval, dec->comb_ops.p, g.ops);          // SparseMatPolynomial::multi_commit: comb_ops.commit(gens_ops, None), comb_mem.commit(gens_mem, None)
+    lap("commit comb_ops (+ window table)");
     cc->comm_mem = commit_poly(c, *g.eval, dec->comb_mem.p, g.mem);
+    lap("commit comb_mem");
     cc->dec = dec;
     return cc;
 }
