@@ -87,6 +87,19 @@ int32_t otti_host_selftest(uint32_t iterations) {
                 x = ptfe_identity(); ptfe_add(x, ptfe_from(rnd)); pt_encode_fe(a, x); pt_encode_ref(b, rnd);
                 if (memcmp(a, b, 32)) throw Error(OTTI_ERR_INTERNAL, "five-limb addition to the identity changed a point");
             }
+            {   // five-limb decompression against the generic one (valid encodings, and one that is not)
+                Pt d1, d2; pt_encode_ref(a, rnd);
+                if (!pt_decode_fast(d1, a) || !pt_decode(d2, a)) throw Error(OTTI_ERR_INTERNAL, "a valid encoding did not decode");
+                pt_encode_ref(b, d1); if (memcmp(a, b, 32)) throw Error(OTTI_ERR_INTERNAL, "pt_decode_fast does not invert the encoding");
+                if (memcmp(&d1, &d2, sizeof(Pt)) && !(fp_eq(d1.X, d2.X) && fp_eq(d1.Y, d2.Y) && fp_eq(d1.T, d2.T))) throw Error(OTTI_ERR_INTERNAL, "pt_decode_fast differs from pt_decode");
+                a[0] ^= 1;                                        // negative s: both must refuse
+                if (pt_decode_fast(d1, a) != pt_decode(d2, a)) throw Error(OTTI_ERR_INTERNAL, "pt_decode_fast and pt_decode disagree on a non-canonical encoding");
+                for (int k = 0; k < 32; k++) a[k] = (uint8_t)(w[k] ^ (it * 37 + k));   // arbitrary bytes: mostly invalid, sometimes valid
+                a[31] &= 0x7f;
+                const bool ok1 = pt_decode_fast(d1, a), ok2 = pt_decode(d2, a);
+                if (ok1 != ok2) throw Error(OTTI_ERR_INTERNAL, "pt_decode_fast and pt_decode disagree on arbitrary bytes");
+                if (ok1) { pt_encode_ref(b, d1); uint8_t b2[32]; pt_encode_ref(b2, d2); if (memcmp(b, b2, 32)) throw Error(OTTI_ERR_INTERNAL, "pt_decode_fast and pt_decode decode to different points"); }
+            }
             pt_encode_fast(a, pt_identity()); pt_encode_ref(b, pt_identity());
             if (memcmp(a, b, 32)) throw Error(OTTI_ERR_INTERNAL, "identity encodes differently");
         }

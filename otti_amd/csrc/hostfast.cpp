@@ -116,6 +116,54 @@ void ptfe_add(PtFe &p, const PtFe &q) {
     p.X = fe_mul(e, f); p.Y = fe_mul(g, h); p.T = fe_mul(e, h); p.Z = fe_mul(f, g);
 }
 
+CachedFe ptfe_cache(const PtFe &p) {
+    static const Fe d2 = fe_from_fp(fp_2D());
+    CachedFe c; c.yplusx = fe_add(p.Y, p.X); c.yminusx = fe_sub(p.Y, p.X); c.z2 = fe_add(p.Z, p.Z); c.t2d = fe_mul(p.T, d2);
+    fe_carry(c.yplusx); fe_carry(c.yminusx); fe_carry(c.z2);              // every limb back under 2^52: the additions below start from there
+    return c;
+}
+// dbl-2008-hwcd with a = -1
+void ptfe_dbl(PtFe &p) {
+    const Fe A = fe_sqr(p.X), B = fe_sqr(p.Y), zz = fe_sqr(p.Z), C = fe_add(zz, zz);
+    Fe xy = fe_add(p.X, p.Y);
+    const Fe E = fe_sub(fe_sqr(xy), fe_add(A, B));                        // (X + Y)^2 - A - B
+    Fe G = fe_sub(B, A); fe_carry(G);                                     // D + B with D = -A
+    const Fe F = fe_sub(G, C), H = fe_sub(fe_from_fp(fp_zero()), fe_add(A, B));   // D - B
+    p.X = fe_mul(E, F); p.Y = fe_mul(G, H); p.T = fe_mul(E, H); p.Z = fe_mul(F, G);
+}
+void ptfe_add_cached(PtFe &p, const CachedFe &q, bool negate) {
+    const Fe a = fe_mul(fe_sub(p.Y, p.X), negate ? q.yplusx : q.yminusx);
+    const Fe b = fe_mul(fe_add(p.Y, p.X), negate ? q.yminusx : q.yplusx);
+    const Fe c = fe_mul(p.T, q.t2d), d = fe_mul(p.Z, q.z2);
+    const Fe e = fe_sub(b, a), h = fe_add(b, a);
+    const Fe f = negate ? fe_add(d, c) : fe_sub(d, c), g = negate ? fe_sub(d, c) : fe_add(d, c);
+    p.X = fe_mul(e, f); p.Y = fe_mul(g, h); p.T = fe_mul(e, h); p.Z = fe_mul(f, g);
+}
+
+bool pt_decode_fast(Pt &o, const uint8_t b[32]) {
+    static const Fe sqrt_m1 = fe_from_fp(fp_SQRT_M1()), dconst = fe_from_fp(fp_D()), one = fe_from_fp(fp_one()), zero = fe_from_fp(fp_zero());
+    if (!fp_bytes_canonical(b) || (b[0] & 1)) return false;
+    const Fe s = fe_from_fp(fp_from_bytes(b)), ss = fe_sqr(s);
+    Fe u1 = fe_sub(one, ss), u2 = fe_add(one, ss); fe_carry(u1);
+    const Fe u2s = fe_sqr(u2);
+    Fe v = fe_sub(fe_sub(zero, fe_mul(dconst, fe_sqr(u1))), u2s); fe_carry(v);     // -d u1^2 - u2^2
+    // SQRT_RATIO_M1(1, w), w = v u2^2: r = w^3 (w^7)^((p-5)/8); the root's sign from what w r^2 turns out to be
+    const Fe w = fe_mul(v, u2s);
+    const Fe w3 = fe_mul(fe_sqr(w), w), w7 = fe_mul(fe_sqr(w3), w);
+    Fe r = fe_mul(w3, fe_pow22523(w7));
+    const Fp check = fe_to_fp(fe_mul(w, fe_sqr(r)));
+    const Fp neg_one = fp_neg(fp_one());
+    const bool correct = fp_eq(check, fp_one()), flipped = fp_eq(check, neg_one), flipped_i = fp_eq(check, fp_mul(neg_one, fp_SQRT_M1()));
+    if (flipped || flipped_i) r = fe_mul(r, sqrt_m1);
+    const Fe inv = fe_from_fp(fp_abs(fe_to_fp(r)));
+    const Fe dx = fe_mul(inv, u2), dy = fe_mul(fe_mul(inv, dx), v);
+    Fp x = fe_to_fp(fe_mul(s, dx)); x = fp_abs(fp_add(x, x));
+    const Fe xe = fe_from_fp(x), ye = fe_mul(u1, dy);
+    const Fp y = fe_to_fp(ye), t = fe_to_fp(fe_mul(xe, ye));
+    if (!(correct || flipped) || fp_is_negative(t) || fp_is_zero(y)) return false;
+    o.X = x; o.Y = y; o.Z = fp_one(); o.T = t; return true;
+}
+
 void pt_encode_fast(uint8_t out[32], const Pt &p) { pt_encode_fe(out, ptfe_from(p)); }
 void pt_encode_fe(uint8_t out[32], const PtFe &p) {
     static const Fe sqrt_m1 = fe_from_fp(fp_SQRT_M1()), invsqrt_a_minus_d = fe_from_fp(fp_INVSQRT_A_MINUS_D());

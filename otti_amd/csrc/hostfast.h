@@ -22,9 +22,17 @@ NielsFe nielsfe_from(const Niels &n);
 void ptfe_madd(PtFe &p, const NielsFe &q, bool negate);      // p += q (or -= q)
 void ptfe_add(PtFe &p, const PtFe &q);                       // p += q (unified extended addition, 9M)
 PtFe ptfe_identity();
+// the verifier's variable-base work (scalar multiplications of proof points, MSMs over decompressed commitments): doubling, and
+// addition of a point kept in "cached" form (Y+X, Y-X, 2Z, 2dT: 8M, negation is a swap)
+struct CachedFe { Fe yplusx, yminusx, z2, t2d; };
+CachedFe ptfe_cache(const PtFe &p);
+void ptfe_dbl(PtFe &p);                                      // p = 2p (4S + 4M)
+void ptfe_add_cached(PtFe &p, const CachedFe &q, bool negate);
 
 // RFC 9496 4.3.2 Encode; identical output to pt_encode (point.h)
 void pt_encode_fast(uint8_t out[32], const Pt &p);
 void pt_encode_fe(uint8_t out[32], const PtFe &p);           // the same from the five-limb form
+// RFC 9496 4.3.1 Decode; identical result to pt_decode (point.h); false = DecompressionError
+bool pt_decode_fast(Pt &out, const uint8_t b[32]);
 
 }  // namespace otti

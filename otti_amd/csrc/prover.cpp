@@ -56,6 +56,24 @@ void ensure_gens_device(Gens &g) {
 }
 void ensure_device_objects(Instance &I, Gens &g) { ensure_instance_device(I); ensure_gens_device(g); }
 
+// the verifiers' fixed-base sums (spartan.h g_fixed_base_msm_hook): one row over the resident table; never builds a table for it
+static bool fixed_base_msm_on_device(const Gens &g, const Fr *s, size_t n, Pt &out) {
+    if (!g.dev || n < 256 || n > g.R) return false;
+    try {
+        DevCtx &c = DevCtx::get();
+        DevBuf<Fr> d(n);
+        OTTI_HIP(hipMemcpyAsync(d.p, s, n * sizeof(Fr), hipMemcpyHostToDevice, c.stream));
+        c.ensure_points(1, std::max<size_t>(1, n / 64));
+        const unsigned long long tk = dev_msm_rows(c, *g.dev, d.p, n, n, 1, nullptr, nullptr, 0, MSM_RAW);
+        if (tk) c.wait_ticket(tk);                               // fused launch: the extended row sum is mailed to pinned memory
+        OTTI_HIP(hipStreamSynchronize(c.stream));
+        c.pending_host_encode = 0;                               // the sum is wanted as a point, not compressed
+        out = c.h_pts[0];
+        return true;
+    } catch (const Error &) { return false; }
+}
+static const bool g_hook_registered = [] { g_fixed_base_msm_hook = fixed_base_msm_on_device; return true; }();
+
 void instance_evaluate_gpu(Instance &I, const std::vector<Fr> &rx, const std::vector<Fr> &ry, Fr out[3]) {
     DevCtx &c = DevCtx::get();
     ensure_instance_device(I);

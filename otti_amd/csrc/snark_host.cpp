@@ -235,7 +235,7 @@ void polyeval_verify_plain(const DotProductProofLog &pf, const PcSet &s, const G
     std::vector<Fr> Lv = eq_evals_host(r.data(), lv), Rv = eq_evals_host(r.data() + lv, s.num_vars - lv);
     std::vector<Pt> Cs(s.L);
     {
-        const size_t nt = std::min<size_t>({s.L / 64 + 1, (size_t)8, (size_t)std::max(1u, std::thread::hardware_concurrency())});
+        const size_t nt = std::min<size_t>({s.L / 128 + 1, (size_t)16, (size_t)std::max(1u, std::thread::hardware_concurrency())});
         std::vector<int> bad(nt, 0); std::vector<std::thread> th;
         auto work = [&](size_t t) { try { for (size_t i = t; i < s.L; i += nt) Cs[i] = dec(comm[i]); } catch (const VerifyFail &f) { bad[t] = f.code; } };
         for (size_t t = 1; t < nt; t++) th.emplace_back(work, t);

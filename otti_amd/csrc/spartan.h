@@ -66,6 +66,9 @@ struct Gens {
     Pt commit_generic(const Fr *v, size_t n, const Fr &blind, const GensView &g) const;   // host MSM (verifier)
 };
 std::unique_ptr<Gens> gens_new(size_t num_cons, size_t num_vars, size_t num_inputs);
+// sum_{i<n} s[i] * g.P[i] from g's resident device window table; false = not available (the caller computes it on the host)
+typedef bool (*FixedBaseMsmHook)(const Gens &g, const Fr *s, size_t n, Pt &out);
+extern FixedBaseMsmHook g_fixed_base_msm_hook;
 // a DotProductProofGens inside a generator stream: gens_n.G = P[0 .. R), gens_n.h = P[h_n], gens_1 = (P[g1], h = P[h1])
 struct PcView { uint32_t h_n, g1, h1; size_t R; };
 std::vector<Pt> derive_generators(const char *label, size_t count);      // MultiCommitGens::new stream

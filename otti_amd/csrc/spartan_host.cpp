@@ -4,6 +4,7 @@
 #include "snark.h"
 #include "pool.h"
 #include <algorithm>
+#include <chrono>
 #include <numeric>
 #include <thread>
 #include <functional>
@@ -376,14 +377,14 @@ NizkProof NizkProof::parse(const uint8_t *p, size_t n) {
 
 // ================================================================================================ verifier
 // (external linkage: snark_host.cpp builds SNARK::verify from the same pieces; declared in snark.h)
-Pt dec(const CPoint &c) { Pt p; if (!pt_decode(p, c.b)) throw VerifyFail{OTTI_ERR_VERIFY_DECOMPRESS}; return p; }
+Pt dec(const CPoint &c) { Pt p; if (!pt_decode_fast(p, c.b)) throw VerifyFail{OTTI_ERR_VERIFY_DECOMPRESS}; return p; }
 void require(bool ok) { if (!ok) throw VerifyFail{OTTI_ERR_VERIFY_INTERNAL}; }
 Pt commit_scalar_pt(const Gens &g, const GensView &g1, const Fr &x, const Fr &blind) { return g.commit_generic(&x, 1, blind, g1); }
 // Group equations that do not feed the transcript (most of the verifier's work: two scalar multiplications and a small MSM per
 // sum-check round) are collected here and checked at the end, spread over the host cores.  Each entry throws VerifyFail on failure.
 // a sum over many points, split over the host cores (the verifier's two sqrt(V)-sized multi-scalar multiplications)
 Pt host_msm_wide(const Fr *sc, const Pt *pts, size_t n) {
-    const size_t nt = std::min<size_t>({n / 128, (size_t)8, (size_t)std::max(1u, std::thread::hardware_concurrency())});
+    const size_t nt = std::min<size_t>({n / 128, (size_t)16, (size_t)std::max(1u, std::thread::hardware_concurrency())});
     if (nt < 2) return host_msm(sc, pts, n);
     std::vector<Pt> part(nt); std::vector<std::thread> th;
     auto work = [&](size_t t) { size_t lo = n * t / nt, hi = n * (t + 1) / nt; part[t] = host_msm(sc + lo, pts + lo, hi - lo); };
@@ -475,6 +476,10 @@ CPoint sumcheck_verify(const ZKSumcheckProof &pf, const CPoint &comm_claim, size
     }
     return pf.comm_evals[num_rounds - 1];
 }
+// g_hat = <s, gens_n.G> is a FIXED-base sum over the first n generators of the stream: when the prover's window table of that stream is
+// already resident (prove and verify in one process, as `spzk verify` runs them), the device side registers this hook and the verifier
+// takes the sum from one small MSM launch instead of a host Pippenger over n points.  Without it (no device, no table) nothing changes.
+FixedBaseMsmHook g_fixed_base_msm_hook = nullptr;
 // BulletReductionProof::verify
 void bullet_verify(const DotProductProofLog &pf, size_t n, const Fr *a, Transcript &tr, const Pt &Gamma, const Gens &g, Pt &g_hat,
                    Pt &Gamma_hat, Fr &a_hat) {                                    // gens_n.G = the first n points of g's stream
@@ -487,7 +492,7 @@ void bullet_verify(const DotProductProofLog &pf, size_t n, const Fr *a, Transcri
     for (size_t i = 0; i < lg; i++) { ch[i] = fr_sqr(ch[i]); chi[i] = fr_sqr(chi[i]); }
     std::vector<Fr> s(n); s[0] = allinv;
     for (size_t i = 1; i < n; i++) { size_t lg_i = ilog2(i + 1) - 1; size_t k = (size_t)1 << lg_i; s[i] = fr_mul(s[i - k], ch[(lg - 1) - lg_i]); }
-    g_hat = host_msm_wide(s.data(), g.P.data(), n);
+    if (!(g_fixed_base_msm_hook && g_fixed_base_msm_hook(g, s.data(), n, g_hat))) g_hat = host_msm_wide(s.data(), g.P.data(), n);
     a_hat = fr_zero(); for (size_t i = 0; i < n; i++) a_hat = fr_add(a_hat, fr_mul(a[i], s[i]));
     std::vector<Fr> sc; std::vector<Pt> pts;
     for (size_t i = 0; i < lg; i++) { sc.push_back(ch[i]); pts.push_back(dec(pf.L_vec[i])); }
@@ -524,7 +529,10 @@ int r1cs_verify_host(const NizkProof &P, size_t N, size_t V, const std::vector<F
         CPoint claim_phase1; pt_encode(claim_phase1.b, commit_scalar_pt(g, g.sc_1, fr_zero(), fr_zero()));
         Deferred later;                                                   // P, g and the CPoints it captures live until run_deferred below
         SpinPool::Session pool_session;
+        const bool trace = getenv("OTTI_TRACE") != nullptr; auto t_lap = std::chrono::steady_clock::now();
+        auto lap = [&](const char *what) { if (!trace) return; const auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[otti] r1cs_verify %-28s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t_lap).count()); t_lap = t; };
         CPoint comm_post1 = sumcheck_verify(P.sc1, claim_phase1, nrx, 3, g, g.sc_4, tr, rx, later);
+        lap("sum-check one");
         const CPoint &cAz = P.claims_phase2[0], &cBz = P.claims_phase2[1], &cCz = P.claims_phase2[2], &cPr = P.claims_phase2[3];
         knowledge_verify(P.pok, g, tr, cCz, later);
         product_verify(P.prod, g, tr, cAz, cBz, cPr, later);
@@ -537,7 +545,9 @@ int r1cs_verify_host(const NizkProof &P, size_t N, size_t V, const std::vector<F
         Fr rA = tr.challenge_scalar("challenege_Az"), rB = tr.challenge_scalar("challenege_Bz"), rC = tr.challenge_scalar("challenege_Cz");
         CPoint comm_claim2;
         pt_encode(comm_claim2.b, pt_add(pt_add(host_scalarmul(dec(cAz), rA), host_scalarmul(dec(cBz), rB)), host_scalarmul(dec(cCz), rC)));
+        lap("sigma protocols");
         CPoint comm_post2 = sumcheck_verify(P.sc2, comm_claim2, nry, 2, g, g.sc_3, tr, ry, later);
+        lap("sum-check two");
         // PolyEvalProof::verify
         {
             tr.append_protocol_name("polynomial evaluation proof");
@@ -553,7 +563,9 @@ int r1cs_verify_host(const NizkProof &P, size_t N, size_t V, const std::vector<F
                 for (auto &x : th) x.join();
                 for (int b : bad) if (b) throw VerifyFail{b};
             }
+            lap("decompress row commitments");
             CPoint C_LZ; pt_encode(C_LZ.b, host_msm_wide(Lv.data(), Cs.data(), Lsz));
+            lap("C_LZ");
             require(P.polyeval.L_vec.size() == ilog2(Rsz));
             const PcView pv = {g.pc_n.h, g.pc_1.G[0], g.pc_1.h, Rsz};
             dotproductlog_verify(P.polyeval, Rsz, g, pv, tr, Rv.data(), C_LZ, P.comm_vars_at_ry);
@@ -570,7 +582,9 @@ int r1cs_verify_host(const NizkProof &P, size_t N, size_t V, const std::vector<F
         Fr comb = fr_add(fr_add(fr_mul(rA, inst_evals[0]), fr_mul(rB, inst_evals[1])), fr_mul(rC, inst_evals[2]));
         CPoint expected2; pt_encode(expected2.b, host_scalarmul(comm_eval_Z, comb));
         equality_verify(P.eq2, g, tr, expected2, comm_post2, later);
+        lap("log dot-product proof + rest");
         run_deferred(later);
+        lap("deferred group equations");
         return OTTI_OK;
     } catch (const VerifyFail &f) { return f.code; }
     catch (const Error &e) { return e.code; }
