@@ -542,8 +542,7 @@ struct EqPyramids {
     DevBuf<Fr> buf; size_t n_lo = 0, n_hi = 0;
     EqPyramids(DevCtx &c, const Fr *tau, size_t m) : buf(8192 + 16384) {
         n_lo = std::min<size_t>(m, 12); n_hi = m - n_lo;
-        dev_eq_pyramid(c, tau + n_hi, n_lo, buf.p);
-        if (n_hi) dev_eq_pyramid(c, tau, n_hi, buf.p + 8192);
+        dev_eq_pyramid2(c, tau + n_hi, n_lo, buf.p, tau, n_hi, n_hi ? buf.p + 8192 : nullptr);
     }
     EqSrc top() const {                                      // E over all m variables
         EqSrc e; const size_t m = n_lo + n_hi;

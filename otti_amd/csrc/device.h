@@ -157,6 +157,7 @@ unsigned long long dev_sc_cubic_fold_eval(DevCtx &c, Fr *A, Fr *B, Fr *C, Fr *D,
 // phase one with the eq table factored out (see k_sumcheck.hip): E[i] = hi ? hi[i >> lo_bits] * lo[i & (2^lo_bits - 1)] : lo[i]
 struct EqSrc { const Fr *hi, *lo; int lo_bits; };
 void dev_eq_pyramid(DevCtx &c, const Fr *r_host, size_t n, Fr *out /* 2^(n+1) - 1 elements: level k at out + 2^k - 1 */);
+void dev_eq_pyramid2(DevCtx &c, const Fr *r0_host, size_t n0, Fr *out0, const Fr *r1_host, size_t n1, Fr *out1);   // two in one launch (out1 may be null)
 unsigned long long dev_sc_cubic3_eval(DevCtx &c, const Fr *B, const Fr *C, const Fr *D, size_t len, const EqSrc &E, int slot);
 unsigned long long dev_sc_cubic3_fold_eval(DevCtx &c, Fr *B, Fr *C, Fr *D, size_t len, const Fr &r, const EqSrc &E, int slot);
 // armed variants (see Armed above): the fold challenge is the next value published with c.go()

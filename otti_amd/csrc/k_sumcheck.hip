@@ -158,7 +158,9 @@ __global__ __launch_bounds__(kBlock) void k_sc_cubic3_fold_eval(Fr *B, Fr *C, Fr
 }
 // "Pyramid" of eq tables over the LAST k of n variables, k = 0..n: level k (2^k entries) sits at out + 2^k - 1.  Level k prepends
 // variable v = r[n-k] as the new most significant index bit: new[i] = old[i] * (1 - v), new[2^(k-1) + i] = old[i] * v.
-__global__ __launch_bounds__(1024) void k_eq_pyramid(FrArgs r, int n, Fr *out) {
+// (two pyramids per launch: workgroup 1, when present, builds the second one — the pair phase one and the SNARK's layers always need)
+__global__ __launch_bounds__(1024) void k_eq_pyramid(FrArgs r0, int n0, Fr *out0, FrArgs r1, int n1, Fr *out1) {
+    const FrArgs &r = blockIdx.x ? r1 : r0; const int n = blockIdx.x ? n1 : n0; Fr *out = blockIdx.x ? out1 : out0;
     if (threadIdx.x == 0) out[0] = fr_one();
     __syncthreads();
     for (int k = 1; k <= n; k++) {
@@ -219,11 +221,13 @@ unsigned long long dev_sc_cubic_fold_eval(DevCtx &c, Fr *A, Fr *B, Fr *C, Fr *D,
     KScope ks(c, KC_SC_CUBIC); hipLaunchKernelGGL(k_sc_cubic_fold_eval, g, kBlock, 0, c.stream, A, B, C, D, q, r, mb);
     return mb.seq;
 }
-void dev_eq_pyramid(DevCtx &c, const Fr *r_host, size_t n, Fr *out) {
-    if (n > 13) throw Error(OTTI_ERR_BAD_ARG, "eq pyramid over more than 13 variables");
-    FrArgs a; for (size_t i = 0; i < 13; i++) a.v[i] = i < n ? r_host[i] : fr_zero();
+void dev_eq_pyramid(DevCtx &c, const Fr *r_host, size_t n, Fr *out) { dev_eq_pyramid2(c, r_host, n, out, nullptr, 0, nullptr); }
+void dev_eq_pyramid2(DevCtx &c, const Fr *r0_host, size_t n0, Fr *out0, const Fr *r1_host, size_t n1, Fr *out1) {
+    if (n0 > 13 || n1 > 13) throw Error(OTTI_ERR_BAD_ARG, "eq pyramid over more than 13 variables");
+    FrArgs a, b;
+    for (size_t i = 0; i < 13; i++) { a.v[i] = i < n0 ? r0_host[i] : fr_zero(); b.v[i] = (out1 && i < n1) ? r1_host[i] : fr_zero(); }
     KScope ks(c, KC_EQ);
-    hipLaunchKernelGGL(k_eq_pyramid, 1, 1024, 0, c.stream, a, (int)n, out);
+    hipLaunchKernelGGL(k_eq_pyramid, out1 ? 2 : 1, 1024, 0, c.stream, a, (int)n0, out0, b, (int)n1, out1);
 }
 unsigned long long dev_sc_cubic3_eval(DevCtx &c, const Fr *B, const Fr *C, const Fr *D, size_t len, const EqSrc &E, int slot) {
     size_t half = len / 2; int g = sc_grid(half); Mailbox mb = c.next_mailbox(slot);

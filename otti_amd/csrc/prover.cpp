@@ -382,8 +382,7 @@ void r1cs_prove_device(Instance &I, DeviceWitness &wit, Gens &g, Transcript &tr,
     // Sharded: eq(tau, i'*G + rk) = eq(tau[0..s_loc), i') * eq(tau[s_loc..), rk)  (index bits are MSB-first), the second factor a scalar.
     const size_t s_loc = nrx - lgG, n_lo = std::min<size_t>(s_loc, 12), n_hi = s_loc - n_lo;
     Fr *pyr_lo = S.pyr.p, *pyr_hi = S.pyr.p + 8192;
-    dev_eq_pyramid(c, tau.data() + n_hi, n_lo, pyr_lo);
-    if (n_hi) dev_eq_pyramid(c, tau.data(), n_hi, pyr_hi);
+    dev_eq_pyramid2(c, tau.data() + n_hi, n_lo, pyr_lo, tau.data(), n_hi, n_hi ? pyr_hi : nullptr);
     auto eq_src = [&](size_t m) {                                     // E = eq over the last m local variables
         EqSrc e;
         if (m <= n_lo) { e.hi = nullptr; e.lo = pyr_lo + (((size_t)1 << m) - 1); e.lo_bits = 0; }

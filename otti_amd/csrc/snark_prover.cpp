@@ -172,7 +172,7 @@ ProductCircuitEvalProofBatched pcbatch_prove(DevCtx &c, Circuits &C, const std::
         const size_t n_lo = std::min<size_t>(nr, 12), n_hi = nr - n_lo;
         if (n_hi > 13) throw Error(OTTI_ERR_BAD_ARG, "product circuit over more than 2^25 elements");
         Fr *pyr_lo = pyr, *pyr_hi = pyr + 8192;
-        if (ndev) { dev_eq_pyramid(c, rand.data() + n_hi, n_lo, pyr_lo); if (n_hi) dev_eq_pyramid(c, rand.data(), n_hi, pyr_hi); }
+        if (ndev) dev_eq_pyramid2(c, rand.data() + n_hi, n_lo, pyr_lo, rand.data(), n_hi, n_hi ? pyr_hi : nullptr);
         auto eq_src = [&](size_t m) {
             EqSrc e;
             if (m <= n_lo) { e.hi = nullptr; e.lo = pyr_lo + (((size_t)1 << m) - 1); e.lo_bits = 0; }
