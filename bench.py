@@ -48,7 +48,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (guide: MI355X_MICROARCH.md); ~6300 achievable
 F = 32                          # bytes per field element
 KERNEL_NAMES = {"msm_rows": "k_msm_rows<0>", "msm_small": "k_msm_small", "sc_cubic": "k_sc_cubic3_fold_eval", "sc_quad": "k_sc_quad_fold_eval",
-                "spmv": "k_spmv3_light", "msm_finish": "k_encode_points", "eq": "k_eq_expand", "poly_bound": "k_poly_bound_slab"}
+                "spmv": "k_spmv3_light / k_spmv3_quad (one lane or one quad per row, by the matrix's entries per row)", "msm_finish": "k_encode_points", "eq": "k_eq_expand", "poly_bound": "k_poly_bound_slab"}
 
 
 def algorithmic_bytes(N, V, nnz):

@@ -31,6 +31,7 @@ struct DeviceCsrSet {
     DevBuf<uint32_t> heavy;                                   // ids of rows whose longest list exceeds kHeavyRow
     DevBuf<uint32_t> seg_row, seg_no, seg_begin;              // their segments (row id, segment number), and each long row's first segment
     size_t rows = 0, n_heavy = 0, n_seg = 0;
+    double avg_row = 0.0;                                     // entries per row and matrix: picks the row-per-lane or the row-per-quad kernel
     DCsr3 view() const { DCsr3 v; for (int k = 0; k < 3; k++) { v.ptr[k] = ptr[k].p; v.idx[k] = idx[k].p; v.val[k] = val[k].p; } return v; }
 };
 struct DeviceInstance { DeviceCsrSet by_row, by_col; size_t nnz = 0; };

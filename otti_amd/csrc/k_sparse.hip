@@ -22,6 +22,31 @@ __global__ __launch_bounds__(kBlock) void k_spmv3_light(DCsr3 m, size_t rows, co
         else { o0[r] = a0; o1[r] = a1; o2[r] = a2; }
     }
 }
+// The same with FOUR lanes per row (a quad walks its row four entries at a time and adds up by quad shuffles): for matrices with several
+// entries per row the value / index loads of a wave are then 128-byte runs instead of one entry per lane at row-length strides.
+__device__ __forceinline__ Fr quad_sum(Fr a) {
+    a = fr_add(a, shfl_xor_fr(a, 1)); a = fr_add(a, shfl_xor_fr(a, 2)); return a;
+}
+__global__ __launch_bounds__(kBlock) void k_spmv3_quad(DCsr3 m, size_t rows, const Fr *x, Fr *o0, Fr *o1, Fr *o2, int combine, Fr c0, Fr c1, Fr c2) {
+    const int q = threadIdx.x & 3;
+    for (size_t r = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 2; r < ((rows + 63) & ~(size_t)63); r += ((size_t)gridDim.x * blockDim.x) >> 2) {
+        Fr a[3] = {fr_zero(), fr_zero(), fr_zero()};
+        bool heavy = false;
+        if (r < rows) {
+            heavy = max(m.ptr[0][r + 1] - m.ptr[0][r], max(m.ptr[1][r + 1] - m.ptr[1][r], m.ptr[2][r + 1] - m.ptr[2][r])) > (uint32_t)kHeavyRow;
+            if (!heavy)
+                for (int k = 0; k < 3; k++) {
+                    const uint32_t p1 = m.ptr[k][r + 1];
+                    for (uint32_t p = m.ptr[k][r] + (uint32_t)q; p < p1; p += 4) a[k] = fr_add(a[k], fr_mul(m.val[k][p], x[m.idx[k][p]]));
+                }
+        }
+        for (int k = 0; k < 3; k++) a[k] = quad_sum(a[k]);         // every lane of the wave takes part (rows are padded to whole waves above)
+        if (r < rows && !heavy && q == 0) {
+            if (combine) o0[r] = fr_add(fr_add(fr_mul(c0, a[0]), fr_mul(c1, a[1])), fr_mul(c2, a[2]));
+            else { o0[r] = a[0]; o1[r] = a[1]; o2[r] = a[2]; }
+        }
+    }
+}
 // Long lists (a linear combination over thousands of variables; the constant-1 column of a compiled circuit, which can hold O(N)
 // entries in the transposed copy) are cut into segments of kHeavySeg entries: one workgroup per segment writes the three raw partial
 // sums, then one thread per long list adds its segments up and applies the combination.
@@ -55,7 +80,11 @@ void dev_spmv3(DevCtx &c, const DeviceCsrSet &m, const Fr *x, Fr *o0, Fr *o1, Fr
     Fr z = fr_zero();
     Fr c0 = coef ? coef[0] : z, c1 = coef ? coef[1] : z, c2 = coef ? coef[2] : z;
     KScope ks(c, KC_SPMV);
-    hipLaunchKernelGGL(k_spmv3_light, grid_for(m.rows), kBlock, 0, c.stream, m.view(), m.rows, x, o0, o1, o2, (int)combine, c0, c1, c2);
+    // measured on the compiler-like 2^20 instance (4.6 entries per row and matrix): 0.54 -> 0.37 ms; on the uniform one (1 entry) the quad
+    // kernel would idle three lanes in four (0.16 -> 0.54 ms)
+    const bool quad = m.avg_row >= 3.0;
+    if (quad) hipLaunchKernelGGL(k_spmv3_quad, grid_for(4 * m.rows), kBlock, 0, c.stream, m.view(), m.rows, x, o0, o1, o2, (int)combine, c0, c1, c2);
+    else hipLaunchKernelGGL(k_spmv3_light, grid_for(m.rows), kBlock, 0, c.stream, m.view(), m.rows, x, o0, o1, o2, (int)combine, c0, c1, c2);
     if (m.n_heavy) {
         // segment partials are scratch of the CALLER's context: the matrix object itself is shared by concurrent provers
         if (c.spmv_partial.n < 3 * m.n_seg) { OTTI_HIP(hipStreamSynchronize(c.stream)); c.spmv_partial.alloc(3 * m.n_seg); }
@@ -134,6 +163,7 @@ static void upload_coo(DevCtx &c, DeviceCoo &d, const std::vector<uint32_t> &row
 static void build_csr_set(DevCtx &c, DeviceCsrSet &d, const DeviceCoo coo[3], bool by_col, size_t rows) {
     if (rows + 1 > ((size_t)1 << 31)) throw Error(OTTI_ERR_BAD_ARG, "instance too large for 32-bit indices");
     d.rows = rows;
+    d.avg_row = rows ? (double)(coo[0].n + coo[1].n + coo[2].n) / (3.0 * (double)rows) : 0.0;
     DevBuf<uint32_t> cursor(rows);
     std::vector<DevBuf<uint32_t>> scan_levels; scan_levels.reserve(4);
     for (int k = 0; k < 3; k++) {
