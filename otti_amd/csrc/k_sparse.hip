@@ -65,13 +65,16 @@ __global__ __launch_bounds__(kBlock) void k_spmv3_heavy_seg(DCsr3 m, const uint3
     block_reduce<3>(acc);
     if (threadIdx.x == 0) for (int k = 0; k < 3; k++) partial[(size_t)blockIdx.x * 3 + k] = acc[k];
 }
-__global__ __launch_bounds__(64) void k_spmv3_heavy_combine(const uint32_t *heavy, const uint32_t *seg_begin, size_t n_heavy, const Fr *partial, Fr *o0, Fr *o1, Fr *o2,
-                                                            int combine, Fr c0, Fr c1, Fr c2) {
-    size_t h = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (h >= n_heavy) return;
+// one workgroup per long list: its segments' partial sums are added up across the workgroup (the constant-1 column of a compiled circuit
+// can have hundreds of segments: one thread walking them alone took ~90 us)
+__global__ __launch_bounds__(kBlock) void k_spmv3_heavy_combine(const uint32_t *heavy, const uint32_t *seg_begin, size_t n_heavy, const Fr *partial, Fr *o0, Fr *o1, Fr *o2,
+                                                                int combine, Fr c0, Fr c1, Fr c2) {
+    const size_t h = blockIdx.x;
     Fr acc[3] = {fr_zero(), fr_zero(), fr_zero()};
-    for (uint32_t s = seg_begin[h]; s < seg_begin[h + 1]; s++)
+    for (uint32_t s = seg_begin[h] + threadIdx.x; s < seg_begin[h + 1]; s += blockDim.x)
         for (int k = 0; k < 3; k++) acc[k] = fr_add(acc[k], partial[(size_t)s * 3 + k]);
+    block_reduce<3>(acc);
+    if (threadIdx.x != 0) return;
     const size_t r = heavy[h];
     if (combine) o0[r] = fr_add(fr_add(fr_mul(c0, acc[0]), fr_mul(c1, acc[1])), fr_mul(c2, acc[2]));
     else { o0[r] = acc[0]; o1[r] = acc[1]; o2[r] = acc[2]; }
@@ -89,7 +92,7 @@ void dev_spmv3(DevCtx &c, const DeviceCsrSet &m, const Fr *x, Fr *o0, Fr *o1, Fr
         // segment partials are scratch of the CALLER's context: the matrix object itself is shared by concurrent provers
         if (c.spmv_partial.n < 3 * m.n_seg) { OTTI_HIP(hipStreamSynchronize(c.stream)); c.spmv_partial.alloc(3 * m.n_seg); }
         hipLaunchKernelGGL(k_spmv3_heavy_seg, (unsigned)m.n_seg, kBlock, 0, c.stream, m.view(), (const uint32_t *)m.seg_row.p, (const uint32_t *)m.seg_no.p, x, c.spmv_partial.p);
-        hipLaunchKernelGGL(k_spmv3_heavy_combine, (unsigned)((m.n_heavy + 63) / 64), 64, 0, c.stream, (const uint32_t *)m.heavy.p, (const uint32_t *)m.seg_begin.p, m.n_heavy,
+        hipLaunchKernelGGL(k_spmv3_heavy_combine, (unsigned)m.n_heavy, kBlock, 0, c.stream, (const uint32_t *)m.heavy.p, (const uint32_t *)m.seg_begin.p, m.n_heavy,
                            (const Fr *)c.spmv_partial.p, o0, o1, o2, (int)combine, c0, c1, c2);
     }
 }
