@@ -100,6 +100,16 @@ int32_t otti_host_selftest(uint32_t iterations) {
                 if (ok1 != ok2) throw Error(OTTI_ERR_INTERNAL, "pt_decode_fast and pt_decode disagree on arbitrary bytes");
                 if (ok1) { pt_encode_ref(b, d1); uint8_t b2[32]; pt_encode_ref(b2, d2); if (memcmp(b, b2, 32)) throw Error(OTTI_ERR_INTERNAL, "pt_decode_fast and pt_decode decode to different points"); }
             }
+            {   // multiplication by a small signed integer (the SpMV kernels' path for compiled circuits) against the Montgomery product
+                const int32_t cs[6] = {0, 1, -1, 0x7ffffffe, -0x7ffffffe, (int32_t)(w[5] | (w[6] << 8) | (w[7] << 16) | ((w[8] & 0x3f) << 24)) * ((w[9] & 1) ? -1 : 1)};
+                for (int32_t cc : cs) {
+                    const Fr cm = cc < 0 ? fr_neg(fr_from_u64((uint64_t)(-(int64_t)cc))) : fr_from_u64((uint64_t)cc);
+                    if (!fr_eq(fr_mul_small(s, cc), fr_mul(s, cm))) throw Error(OTTI_ERR_INTERNAL, "fr_mul_small differs from fr_mul");
+                    if (fr_small_code(cm) != cc) throw Error(OTTI_ERR_INTERNAL, "fr_small_code does not recover a small integer");
+                }
+                Fr big = fr_from_u64(0x80000000ull); if (fr_small_code(big) != kNotSmall || fr_small_code(fr_neg(big)) != kNotSmall) throw Error(OTTI_ERR_INTERNAL, "fr_small_code accepts 2^31");
+                if (it > 2 && fr_small_code(s) != kNotSmall) throw Error(OTTI_ERR_INTERNAL, "fr_small_code accepts a random field element");
+            }
             pt_encode_fast(a, pt_identity()); pt_encode_ref(b, pt_identity());
             if (memcmp(a, b, 32)) throw Error(OTTI_ERR_INTERNAL, "identity encodes differently");
         }

@@ -25,14 +25,16 @@ template <class T> struct DevBuf {
 };
 
 // three CSR matrices side by side (A, B, C), by value into kernels
-struct DCsr3 { const uint32_t *ptr[3]; const uint32_t *idx[3]; const Fr *val[3]; };
+struct DCsr3 { const uint32_t *ptr[3]; const uint32_t *idx[3]; const Fr *val[3]; const int32_t *small[3]; };
 struct DeviceCsrSet {
     DevBuf<uint32_t> ptr[3], idx[3]; DevBuf<Fr> val[3];
+    DevBuf<int32_t> small[3];                                 // per entry: the coefficient as a small signed integer, or kNotSmall (then val[] is read)
+    bool use_small = false;                                   // most coefficients are small integers (a compiled circuit): the kernels read 4 bytes per entry instead of 32
     DevBuf<uint32_t> heavy;                                   // ids of rows whose longest list exceeds kHeavyRow
     DevBuf<uint32_t> seg_row, seg_no, seg_begin;              // their segments (row id, segment number), and each long row's first segment
     size_t rows = 0, n_heavy = 0, n_seg = 0;
     double avg_row = 0.0;                                     // entries per row and matrix: picks the row-per-lane or the row-per-quad kernel
-    DCsr3 view() const { DCsr3 v; for (int k = 0; k < 3; k++) { v.ptr[k] = ptr[k].p; v.idx[k] = idx[k].p; v.val[k] = val[k].p; } return v; }
+    DCsr3 view() const { DCsr3 v; for (int k = 0; k < 3; k++) { v.ptr[k] = ptr[k].p; v.idx[k] = idx[k].p; v.val[k] = val[k].p; v.small[k] = small[k].p; } return v; }
 };
 struct DeviceInstance { DeviceCsrSet by_row, by_col; size_t nnz = 0; };
 // Rank k of g holds the constraint rows r = k (mod g) (renumbered r / g, columns untouched: multiply_vec output lands where the

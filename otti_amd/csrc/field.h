@@ -209,9 +209,37 @@ HD Fr fr_mul(const Fr &a, const Fr &b) {
 }
 HD Fr fr_sqr(const Fr &a) { return fr_mul(a, a); }
 
+// x * c mod l for a small signed integer c (|c| < 2^31); x in either form (the form is kept: (xR) c = (xc) R).  The coefficients of a
+// compiled circuit are mostly such integers: ~15 multiply-accumulates instead of a 128-product Montgomery multiplication.
+//   t = x |c| < 2^283;  q = t >> 252 is floor(t / l) or one more (l = 2^252 + delta, delta < 2^125);  t - q l = (t mod 2^252) - q delta
+HD Fr fr_mul_small(const Fr &x, int32_t c) {
+    const uint32_t mag = c < 0 ? (uint32_t)(-(int64_t)c) : (uint32_t)c;
+    uint32_t t[9]; uint64_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { acc += (uint64_t)x.v[i] * mag; t[i] = (uint32_t)acc; acc >>= 32; }
+    t[8] = (uint32_t)acc;
+    const uint32_t q = (t[8] << 4) | (t[7] >> 28);
+    Fr low; for (int i = 0; i < 7; i++) low.v[i] = t[i];
+    low.v[7] = t[7] & 0x0fffffffu;
+    Fr qd = fr_zero(); acc = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { acc += (uint64_t)fr_L(i) * q; qd.v[i] = (uint32_t)acc; acc >>= 32; }
+    qd.v[4] = (uint32_t)acc;
+    const Fr r = fr_sub(low, qd);                              // both below l: the difference mod l
+    return c < 0 ? fr_neg(r) : r;
+}
 HD Fr fr_from_u64(uint64_t x) { Fr t = fr_zero(); t.v[0] = (uint32_t)x; t.v[1] = (uint32_t)(x >> 32); return fr_mul(t, fr_R2()); }
 // canonical integer (out of Montgomery form)
 HD Fr fr_to_raw(const Fr &a) { Fr one = fr_zero(); one.v[0] = 1; return fr_mul(a, one); }
+constexpr int32_t kNotSmall = INT32_MIN;                         // fr_small_code of a value that is no such integer
+// the small signed integer a Montgomery-form value stands for, or kNotSmall
+HD int32_t fr_small_code(const Fr &mont) {
+    const Fr raw = fr_to_raw(mont);
+    if ((raw.v[1] | raw.v[2] | raw.v[3] | raw.v[4] | raw.v[5] | raw.v[6] | raw.v[7]) == 0 && raw.v[0] < 0x7fffffffu) return (int32_t)raw.v[0];
+    const Fr neg = fr_to_raw(fr_neg(mont));
+    if ((neg.v[1] | neg.v[2] | neg.v[3] | neg.v[4] | neg.v[5] | neg.v[6] | neg.v[7]) == 0 && neg.v[0] < 0x7fffffffu) return -(int32_t)neg.v[0];
+    return kNotSmall;
+}
 HD void fr_to_bytes(uint8_t b[32], const Fr &a) {
     Fr r = fr_to_raw(a);
     for (int i = 0; i < 8; i++) { b[4 * i] = (uint8_t)r.v[i]; b[4 * i + 1] = (uint8_t)(r.v[i] >> 8); b[4 * i + 2] = (uint8_t)(r.v[i] >> 16); b[4 * i + 3] = (uint8_t)(r.v[i] >> 24); }

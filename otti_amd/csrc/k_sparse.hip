@@ -5,19 +5,25 @@
 namespace otti {
 
 // ------------------------------------------------------------------------------------------------ K1 / K6 sparse products
-__device__ __forceinline__ Fr row_dot(const uint32_t *ptr, const uint32_t *idx, const Fr *val, const Fr *x, size_t r) {
+// one entry's product.  kSmall: the coefficient is read as a 4-byte code first; only codes that are not small integers touch the 32-byte value
+template <bool kSmall> __device__ __forceinline__ Fr entry_term(const DCsr3 &m, int k, uint32_t p, const Fr *x) {
+    const Fr xv = x[m.idx[k][p]];
+    if (kSmall) { const int32_t c = m.small[k][p]; if (c != kNotSmall) return fr_mul_small(xv, c); }
+    return fr_mul(m.val[k][p], xv);
+}
+template <bool kSmall> __device__ __forceinline__ Fr row_dot(const DCsr3 &m, int k, const Fr *x, size_t r) {
     Fr acc = fr_zero();
-    uint32_t p0 = ptr[r], p1 = ptr[r + 1];
-    for (uint32_t p = p0; p < p1; p++) acc = fr_add(acc, fr_mul(val[p], x[idx[p]]));
+    const uint32_t p0 = m.ptr[k][r], p1 = m.ptr[k][r + 1];
+    for (uint32_t p = p0; p < p1; p++) acc = fr_add(acc, entry_term<kSmall>(m, k, p, x));
     return acc;
 }
-__global__ __launch_bounds__(kBlock) void k_spmv3_light(DCsr3 m, size_t rows, const Fr *x, Fr *o0, Fr *o1, Fr *o2, int combine, Fr c0, Fr c1, Fr c2) {
+template <bool kSmall> __global__ __launch_bounds__(kBlock) void k_spmv3_light(DCsr3 m, size_t rows, const Fr *x, Fr *o0, Fr *o1, Fr *o2, int combine, Fr c0, Fr c1, Fr c2) {
     for (size_t r = blockIdx.x * (size_t)blockDim.x + threadIdx.x; r < rows; r += (size_t)gridDim.x * blockDim.x) {
         uint32_t l0 = m.ptr[0][r + 1] - m.ptr[0][r], l1 = m.ptr[1][r + 1] - m.ptr[1][r], l2 = m.ptr[2][r + 1] - m.ptr[2][r];
         if (max(l0, max(l1, l2)) > (uint32_t)kHeavyRow) continue;
-        Fr a0 = row_dot(m.ptr[0], m.idx[0], m.val[0], x, r);
-        Fr a1 = row_dot(m.ptr[1], m.idx[1], m.val[1], x, r);
-        Fr a2 = row_dot(m.ptr[2], m.idx[2], m.val[2], x, r);
+        Fr a0 = row_dot<kSmall>(m, 0, x, r);
+        Fr a1 = row_dot<kSmall>(m, 1, x, r);
+        Fr a2 = row_dot<kSmall>(m, 2, x, r);
         if (combine) o0[r] = fr_add(fr_add(fr_mul(c0, a0), fr_mul(c1, a1)), fr_mul(c2, a2));
         else { o0[r] = a0; o1[r] = a1; o2[r] = a2; }
     }
@@ -27,7 +33,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv3_light(DCsr3 m, size_t rows, co
 __device__ __forceinline__ Fr quad_sum(Fr a) {
     a = fr_add(a, shfl_xor_fr(a, 1)); a = fr_add(a, shfl_xor_fr(a, 2)); return a;
 }
-__global__ __launch_bounds__(kBlock) void k_spmv3_quad(DCsr3 m, size_t rows, const Fr *x, Fr *o0, Fr *o1, Fr *o2, int combine, Fr c0, Fr c1, Fr c2) {
+template <bool kSmall> __global__ __launch_bounds__(kBlock) void k_spmv3_quad(DCsr3 m, size_t rows, const Fr *x, Fr *o0, Fr *o1, Fr *o2, int combine, Fr c0, Fr c1, Fr c2) {
     const int q = threadIdx.x & 3;
     for (size_t r = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 2; r < ((rows + 63) & ~(size_t)63); r += ((size_t)gridDim.x * blockDim.x) >> 2) {
         Fr a[3] = {fr_zero(), fr_zero(), fr_zero()};
@@ -37,7 +43,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv3_quad(DCsr3 m, size_t rows, con
             if (!heavy)
                 for (int k = 0; k < 3; k++) {
                     const uint32_t p1 = m.ptr[k][r + 1];
-                    for (uint32_t p = m.ptr[k][r] + (uint32_t)q; p < p1; p += 4) a[k] = fr_add(a[k], fr_mul(m.val[k][p], x[m.idx[k][p]]));
+                    for (uint32_t p = m.ptr[k][r] + (uint32_t)q; p < p1; p += 4) a[k] = fr_add(a[k], entry_term<kSmall>(m, k, p, x));
                 }
         }
         for (int k = 0; k < 3; k++) a[k] = quad_sum(a[k]);         // every lane of the wave takes part (rows are padded to whole waves above)
@@ -51,7 +57,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv3_quad(DCsr3 m, size_t rows, con
 // entries in the transposed copy) are cut into segments of kHeavySeg entries: one workgroup per segment writes the three raw partial
 // sums, then one thread per long list adds its segments up and applies the combination.
 constexpr uint32_t kHeavySeg = 2048;
-__global__ __launch_bounds__(kBlock) void k_spmv3_heavy_seg(DCsr3 m, const uint32_t *seg_row, const uint32_t *seg_no, const Fr *x, Fr *partial) {
+template <bool kSmall> __global__ __launch_bounds__(kBlock) void k_spmv3_heavy_seg(DCsr3 m, const uint32_t *seg_row, const uint32_t *seg_no, const Fr *x, Fr *partial) {
     const size_t r = seg_row[blockIdx.x]; const uint32_t sn = seg_no[blockIdx.x];
     Fr acc[3];
     for (int k = 0; k < 3; k++) {
@@ -60,7 +66,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv3_heavy_seg(DCsr3 m, const uint3
         const uint64_t lo = (uint64_t)p0 + (uint64_t)sn * kHeavySeg;
         if (lo >= p1) continue;
         const uint32_t hi = (uint32_t)min((uint64_t)p1, lo + kHeavySeg);
-        for (uint32_t p = (uint32_t)lo + threadIdx.x; p < hi; p += blockDim.x) acc[k] = fr_add(acc[k], fr_mul(m.val[k][p], x[m.idx[k][p]]));
+        for (uint32_t p = (uint32_t)lo + threadIdx.x; p < hi; p += blockDim.x) acc[k] = fr_add(acc[k], entry_term<kSmall>(m, k, p, x));
     }
     block_reduce<3>(acc);
     if (threadIdx.x == 0) for (int k = 0; k < 3; k++) partial[(size_t)blockIdx.x * 3 + k] = acc[k];
@@ -86,12 +92,16 @@ void dev_spmv3(DevCtx &c, const DeviceCsrSet &m, const Fr *x, Fr *o0, Fr *o1, Fr
     // measured on the compiler-like 2^20 instance (4.6 entries per row and matrix): 0.54 -> 0.37 ms; on the uniform one (1 entry) the quad
     // kernel would idle three lanes in four (0.16 -> 0.54 ms)
     const bool quad = m.avg_row >= 3.0;
-    if (quad) hipLaunchKernelGGL(k_spmv3_quad, grid_for(4 * m.rows), kBlock, 0, c.stream, m.view(), m.rows, x, o0, o1, o2, (int)combine, c0, c1, c2);
-    else hipLaunchKernelGGL(k_spmv3_light, grid_for(m.rows), kBlock, 0, c.stream, m.view(), m.rows, x, o0, o1, o2, (int)combine, c0, c1, c2);
+    const bool sm = m.use_small;
+    if (quad && sm) hipLaunchKernelGGL(k_spmv3_quad<true>, grid_for(4 * m.rows), kBlock, 0, c.stream, m.view(), m.rows, x, o0, o1, o2, (int)combine, c0, c1, c2);
+    else if (quad) hipLaunchKernelGGL(k_spmv3_quad<false>, grid_for(4 * m.rows), kBlock, 0, c.stream, m.view(), m.rows, x, o0, o1, o2, (int)combine, c0, c1, c2);
+    else if (sm) hipLaunchKernelGGL(k_spmv3_light<true>, grid_for(m.rows), kBlock, 0, c.stream, m.view(), m.rows, x, o0, o1, o2, (int)combine, c0, c1, c2);
+    else hipLaunchKernelGGL(k_spmv3_light<false>, grid_for(m.rows), kBlock, 0, c.stream, m.view(), m.rows, x, o0, o1, o2, (int)combine, c0, c1, c2);
     if (m.n_heavy) {
         // segment partials are scratch of the CALLER's context: the matrix object itself is shared by concurrent provers
         if (c.spmv_partial.n < 3 * m.n_seg) { OTTI_HIP(hipStreamSynchronize(c.stream)); c.spmv_partial.alloc(3 * m.n_seg); }
-        hipLaunchKernelGGL(k_spmv3_heavy_seg, (unsigned)m.n_seg, kBlock, 0, c.stream, m.view(), (const uint32_t *)m.seg_row.p, (const uint32_t *)m.seg_no.p, x, c.spmv_partial.p);
+        if (sm) hipLaunchKernelGGL(k_spmv3_heavy_seg<true>, (unsigned)m.n_seg, kBlock, 0, c.stream, m.view(), (const uint32_t *)m.seg_row.p, (const uint32_t *)m.seg_no.p, x, c.spmv_partial.p);
+        else hipLaunchKernelGGL(k_spmv3_heavy_seg<false>, (unsigned)m.n_seg, kBlock, 0, c.stream, m.view(), (const uint32_t *)m.seg_row.p, (const uint32_t *)m.seg_no.p, x, c.spmv_partial.p);
         hipLaunchKernelGGL(k_spmv3_heavy_combine, (unsigned)m.n_heavy, kBlock, 0, c.stream, (const uint32_t *)m.heavy.p, (const uint32_t *)m.seg_begin.p, m.n_heavy,
                            (const Fr *)c.spmv_partial.p, o0, o1, o2, (int)combine, c0, c1, c2);
     }
@@ -105,11 +115,20 @@ void dev_spmv3(DevCtx &c, const DeviceCsrSet &m, const Fr *x, Fr *o0, Fr *o1, Fr
 __global__ __launch_bounds__(kBlock) void k_csr_count(const uint32_t *major, size_t n, uint32_t *ptr) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) atomicAdd(&ptr[major[i] + 1], 1u);
 }
-__global__ __launch_bounds__(kBlock) void k_csr_fill(const uint32_t *major, const uint32_t *minor, const Fr *val, size_t n, uint32_t *cursor, uint32_t *idx, Fr *out) {
+__global__ __launch_bounds__(kBlock) void k_csr_fill(const uint32_t *major, const uint32_t *minor, const Fr *val, const int32_t *code, size_t n, uint32_t *cursor,
+                                                     uint32_t *idx, Fr *out, int32_t *out_code) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const uint32_t p = atomicAdd(&cursor[major[i]], 1u);
         idx[p] = minor[i]; out[p] = val[i];
+        if (out_code) out_code[p] = code[i];
     }
+}
+// the small-integer codes of an entry list (fr_small_code) and how many of them there are
+__global__ __launch_bounds__(kBlock) void k_coef_codes(const Fr *val, size_t n, int32_t *code, unsigned long long *n_small) {
+    unsigned mine = 0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) { const int32_t c = fr_small_code(val[i]); code[i] = c; mine += c != kNotSmall; }
+    for (int off = 32; off >= 1; off >>= 1) mine += __shfl_xor((int)mine, off, 64);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(n_small, (unsigned long long)mine);
 }
 // in-place inclusive scan of u32 counts: every workgroup scans 4096 elements and reports its total; the totals are scanned the same way
 // (recursively: two levels reach 2^24 elements, three 2^36), then added back
@@ -154,7 +173,7 @@ __global__ __launch_bounds__(kBlock) void k_csr_count_heavy(const uint32_t *p0, 
     for (size_t r = blockIdx.x * (size_t)blockDim.x + threadIdx.x; r < rows; r += (size_t)gridDim.x * blockDim.x)
         if (max(p0[r + 1] - p0[r], max(p1[r + 1] - p1[r], p2[r + 1] - p2[r])) > (uint32_t)kHeavyRow) atomicAdd(count, 1u);
 }
-struct DeviceCoo { DevBuf<uint32_t> row, col; DevBuf<Fr> val; size_t n = 0; };
+struct DeviceCoo { DevBuf<uint32_t> row, col; DevBuf<Fr> val; DevBuf<int32_t> code; size_t n = 0; };
 static void upload_coo(DevCtx &c, DeviceCoo &d, const std::vector<uint32_t> &row, const std::vector<uint32_t> &col, const std::vector<Fr> &val) {
     d.n = val.size();
     d.row.alloc(std::max<size_t>(1, d.n)); d.col.alloc(std::max<size_t>(1, d.n)); d.val.alloc(std::max<size_t>(1, d.n));
@@ -163,9 +182,22 @@ static void upload_coo(DevCtx &c, DeviceCoo &d, const std::vector<uint32_t> &row
     OTTI_HIP(hipMemcpyAsync(d.col.p, col.data(), d.n * 4, hipMemcpyHostToDevice, c.stream));
     OTTI_HIP(hipMemcpyAsync(d.val.p, val.data(), d.n * sizeof(Fr), hipMemcpyHostToDevice, c.stream));
 }
-static void build_csr_set(DevCtx &c, DeviceCsrSet &d, const DeviceCoo coo[3], bool by_col, size_t rows) {
+// decide once per instance whether the kernels read coefficient codes: worth it when most entries are small integers
+static bool classify_coefficients(DevCtx &c, DeviceCoo coo[3]) {
+    DevBuf<unsigned long long> count(1); unsigned long long n_small = 0; size_t total = 0;
+    OTTI_HIP(hipMemsetAsync(count.p, 0, sizeof(unsigned long long), c.stream));
+    for (int k = 0; k < 3; k++) {
+        total += coo[k].n;
+        coo[k].code.alloc(std::max<size_t>(1, coo[k].n));
+        if (coo[k].n) hipLaunchKernelGGL(k_coef_codes, grid_for(coo[k].n), kBlock, 0, c.stream, (const Fr *)coo[k].val.p, coo[k].n, coo[k].code.p, count.p);
+    }
+    OTTI_HIP(hipMemcpyAsync(&n_small, count.p, sizeof n_small, hipMemcpyDeviceToHost, c.stream));
+    OTTI_HIP(hipStreamSynchronize(c.stream));
+    return total >= 1024 && 2 * n_small >= total;
+}
+static void build_csr_set(DevCtx &c, DeviceCsrSet &d, const DeviceCoo coo[3], bool by_col, size_t rows, bool use_small) {
     if (rows + 1 > ((size_t)1 << 31)) throw Error(OTTI_ERR_BAD_ARG, "instance too large for 32-bit indices");
-    d.rows = rows;
+    d.rows = rows; d.use_small = use_small;
     d.avg_row = rows ? (double)(coo[0].n + coo[1].n + coo[2].n) / (3.0 * (double)rows) : 0.0;
     DevBuf<uint32_t> cursor(rows);
     std::vector<DevBuf<uint32_t>> scan_levels; scan_levels.reserve(4);
@@ -173,12 +205,14 @@ static void build_csr_set(DevCtx &c, DeviceCsrSet &d, const DeviceCoo coo[3], bo
         const DeviceCoo &m = coo[k];
         const uint32_t *major = by_col ? m.col.p : m.row.p, *minor = by_col ? m.row.p : m.col.p;
         d.ptr[k].alloc(rows + 1); d.idx[k].alloc(std::max<size_t>(1, m.n)); d.val[k].alloc(std::max<size_t>(1, m.n));
+        if (use_small) d.small[k].alloc(std::max<size_t>(1, m.n));
         OTTI_HIP(hipMemsetAsync(d.ptr[k].p, 0, (rows + 1) * 4, c.stream));
         if (m.n) hipLaunchKernelGGL(k_csr_count, grid_for(m.n), kBlock, 0, c.stream, major, m.n, d.ptr[k].p);
         scan_inplace(c, d.ptr[k].p, rows + 1, scan_levels);   // ptr[0] = 0: the inclusive sum over [0, rows] is the exclusive one shifted
         if (m.n) {
             OTTI_HIP(hipMemcpyAsync(cursor.p, d.ptr[k].p, rows * 4, hipMemcpyDeviceToDevice, c.stream));
-            hipLaunchKernelGGL(k_csr_fill, grid_for(m.n), kBlock, 0, c.stream, major, minor, (const Fr *)m.val.p, m.n, cursor.p, d.idx[k].p, d.val[k].p);
+            hipLaunchKernelGGL(k_csr_fill, grid_for(m.n), kBlock, 0, c.stream, major, minor, (const Fr *)m.val.p, (const int32_t *)m.code.p, m.n, cursor.p, d.idx[k].p, d.val[k].p,
+                               use_small ? d.small[k].p : (int32_t *)nullptr);
         }
     }
     // long lists: found on the device; only when there are any do the row pointers come back for the segment lists
@@ -209,8 +243,9 @@ std::shared_ptr<DeviceInstance> upload_instance(const Instance &I) {
     auto d = std::make_shared<DeviceInstance>();
     DeviceCoo coo[3];
     for (int k = 0; k < 3; k++) upload_coo(c, coo[k], I.M[k].row, I.M[k].col, I.M[k].val);
-    build_csr_set(c, d->by_row, coo, false, I.num_cons);
-    build_csr_set(c, d->by_col, coo, true, 2 * I.num_vars);
+    const bool use_small = classify_coefficients(c, coo);
+    build_csr_set(c, d->by_row, coo, false, I.num_cons, use_small);
+    build_csr_set(c, d->by_col, coo, true, 2 * I.num_vars, use_small);
     d->nnz = I.M[0].val.size() + I.M[1].val.size() + I.M[2].val.size();
     return d;
 }
@@ -234,8 +269,9 @@ std::shared_ptr<DeviceShard> upload_instance_shard(const Instance &I, int rank, 
         upload_coo(c, rows[m], rr, rc, rv); upload_coo(c, cols[m], cr, cc, cv);
         OTTI_HIP(hipStreamSynchronize(c.stream));             // the host lists above go out of scope
     }
-    build_csr_set(c, d->by_row, rows, false, I.num_cons / g);
-    build_csr_set(c, d->by_col, cols, true, 2 * I.num_vars / g);
+    const bool small_rows = classify_coefficients(c, rows), small_cols = classify_coefficients(c, cols);
+    build_csr_set(c, d->by_row, rows, false, I.num_cons / g, small_rows);
+    build_csr_set(c, d->by_col, cols, true, 2 * I.num_vars / g, small_cols);
     return d;
 }
 
