@@ -12,7 +12,7 @@ namespace otti {
 constexpr int kMsmMaxChunk = 1024;             // terms per workgroup (LDS: 36 B each)
 constexpr int kMsmBulkChunk = 512;             // bulk launches: terms per workgroup, and
 constexpr int kMsmListCap = (kMsmBulkChunk + 8) * 16;   // their (term, window) work-list entries (2 B each): (chunk + extras) * W must fit
-static_assert(kMsmMaxChunk + 8 <= 2048, "work-list entries pack the term index in 11 bits");
+static_assert(kMsmBulkChunk + 8 <= 2048, "work-list entries pack the term index (within a sub-chunk) in 11 bits");
 // Bullet-reduction round fused into the MSM launch: the scalars of rows L (0) and R (1) are not read from memory but derived in phase 1
 // from the round state (a, b: the two folded vectors; s: coefficients of the original generators), after applying the previous
 // round's challenge.  State is ping-ponged (read *_in, write *_out) so that no workgroup of the launch reads what another one writes.
@@ -73,11 +73,12 @@ template <int kKind> __global__ __launch_bounds__(kBlock) void k_msm_rows(MsmArg
     const size_t j0 = (size_t)chunk_id * A.chunk;
     const uint32_t n_here = (uint32_t)min((size_t)A.chunk, A.n_dense - j0);
     const uint32_t n_ex = chunk_id == 0 ? (uint32_t)A.n_extra : 0u;
-    // ---- phase 1: recoded scalars into LDS
-    for (uint32_t t = threadIdx.x; t < n_here + n_ex; t += blockDim.x) {
-        const Fr sc = t >= n_here ? A.extra_s[row * A.n_extra + (t - n_here)] : A.dense[row * A.stride + j0 + t];
-        recode_scalar(s_raw + t * 9, sc, A.K);
-    }
+    // ---- phase 1: recoded scalars into LDS (the sparse kind stages them sub-chunk by sub-chunk below)
+    if constexpr (kKind == MSM_BULK)
+        for (uint32_t t = threadIdx.x; t < n_here + n_ex; t += blockDim.x) {
+            const Fr sc = t >= n_here ? A.extra_s[row * A.n_extra + (t - n_here)] : A.dense[row * A.stride + j0 + t];
+            recode_scalar(s_raw + t * 9, sc, A.K);
+        }
     if (threadIdx.x < 8) s_base[threadIdx.x] = A.extra_base[threadIdx.x];
     __syncthreads();
     // ---- phase 2: one mixed addition per (term, window) pair, in 26/25-bit limbs (fp10.h)
@@ -89,39 +90,51 @@ template <int kKind> __global__ __launch_bounds__(kBlock) void k_msm_rows(MsmArg
         // with c = 16 a 64-bit scalar has 4-5 non-zero digits out of 16, and with the fixed (term, window) mapping below the lanes
         // of its empty windows would idle while the others work.  (For uniform scalars the list would simply be all pairs, at the
         // price of half-size chunks; the host picks this variant from the witness's share of small values.)
+        // A workgroup takes a whole chunk (a row, as a rule) in sub-chunks of kMsmBulkChunk terms and keeps its accumulators across them:
+        // ONE reduction tree per chunk — with ~5 additions per scalar the tree of a 512-term chunk cost as much as its additions.
         __shared__ uint16_t s_list[kMsmListCap];
         __shared__ uint32_t s_count;
-        if (threadIdx.x == 0) s_count = 0;
-        __syncthreads();
-        const uint32_t n_tot = n_here + n_ex, iters = (n_tot + A.lanes - 1) / A.lanes;
+        const uint32_t n_all = n_here + n_ex;
         const int pos = w * A.c, limb = pos >> 5, off = pos & 31;
         const uint32_t mask = (1u << A.c) - 1u; const int half = 1 << (A.c - 1);
         const unsigned lane = threadIdx.x & 63;
-        for (uint32_t it = 0; it < iters; it++) {
-            const uint32_t t = (uint32_t)tl + it * (uint32_t)A.lanes;
-            bool nz = false;
-            if (tl < A.lanes && t < n_tot) {
-                uint64_t x = s_raw[t * 9 + limb];
-                if (limb < 8) x |= (uint64_t)s_raw[t * 9 + limb + 1] << 32;
-                nz = ((uint32_t)(x >> off) & mask) != (uint32_t)half;
-            }
-            const unsigned long long bal = __ballot(nz);
-            uint32_t base_pos = 0;
-            if (lane == 0 && bal) base_pos = atomicAdd(&s_count, (uint32_t)__popcll(bal));
-            base_pos = __shfl(base_pos, 0);
-            if (nz) s_list[base_pos + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)((t << 5) | (uint32_t)w);
-        }
-        __syncthreads();
-        const uint32_t count = s_count;
         const size_t WE = (size_t)A.W * A.E;
-        for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) {
-            const uint32_t e16 = s_list[i], t = e16 >> 5, ww = e16 & 31u;
-            const int d = recoded_digit(s_raw + t * 9, (int)ww, A.c);
-            const size_t base = t < n_here ? j0 + t : (size_t)s_base[t - n_here];
-            const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
-            N10 e = n10_unpack(A.table[base * WE + (size_t)ww * A.E + (mag - 1)]);
-            if (d < 0) e = n10_negate(e);
-            acc = p10_madd(acc, e);
+        const uint32_t sub_cap = min((uint32_t)kMsmBulkChunk, (uint32_t)(kMsmListCap / A.W));      // terms whose pairs fit the work list
+        for (uint32_t sub0 = 0; sub0 < n_all; sub0 += sub_cap) {
+            const uint32_t n_tot = min(sub_cap, n_all - sub0), iters = (n_tot + A.lanes - 1) / A.lanes;
+            __syncthreads();                                     // the previous sub-chunk's scalars and list have been consumed
+            for (uint32_t t = threadIdx.x; t < n_tot; t += blockDim.x) {
+                const uint32_t T = sub0 + t;
+                const Fr sc = T >= n_here ? A.extra_s[row * A.n_extra + (T - n_here)] : A.dense[row * A.stride + j0 + T];
+                recode_scalar(s_raw + t * 9, sc, A.K);
+            }
+            if (threadIdx.x == 0) s_count = 0;
+            __syncthreads();
+            for (uint32_t it = 0; it < iters; it++) {
+                const uint32_t t = (uint32_t)tl + it * (uint32_t)A.lanes;
+                bool nz = false;
+                if (tl < A.lanes && t < n_tot) {
+                    uint64_t x = s_raw[t * 9 + limb];
+                    if (limb < 8) x |= (uint64_t)s_raw[t * 9 + limb + 1] << 32;
+                    nz = ((uint32_t)(x >> off) & mask) != (uint32_t)half;
+                }
+                const unsigned long long bal = __ballot(nz);
+                uint32_t base_pos = 0;
+                if (lane == 0 && bal) base_pos = atomicAdd(&s_count, (uint32_t)__popcll(bal));
+                base_pos = __shfl(base_pos, 0);
+                if (nz) s_list[base_pos + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)((t << 5) | (uint32_t)w);
+            }
+            __syncthreads();
+            const uint32_t count = s_count;
+            for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) {
+                const uint32_t e16 = s_list[i], t = e16 >> 5, ww = e16 & 31u, T = sub0 + t;
+                const int d = recoded_digit(s_raw + t * 9, (int)ww, A.c);
+                const size_t base = T < n_here ? j0 + T : (size_t)s_base[T - n_here];
+                const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
+                N10 e = n10_unpack(A.table[base * WE + (size_t)ww * A.E + (mag - 1)]);
+                if (d < 0) e = n10_negate(e);
+                acc = p10_madd(acc, e);
+            }
         }
     } else if (tl < A.lanes) {
         const size_t WE = (size_t)A.W * A.E;
@@ -381,7 +394,7 @@ static unsigned long long msm_launch(DevCtx &c, const DeviceGens &g, const Fr *d
         // the sparse variant keeps a (term, window) work list in LDS: (chunk + extras) * W <= kMsmListCap;  W <= 32 there (5-bit window field)
         nchunks = std::max<size_t>(1, (1024 + rows - 1) / rows);
         nchunks = std::min(nchunks, std::max<size_t>(1, n_dense / (size_t)A.lanes));
-        const size_t max_chunk = sparse ? std::min<size_t>(kMsmBulkChunk, (size_t)kMsmListCap / (size_t)g.W - n_extra) : (size_t)kMsmMaxChunk;
+        const size_t max_chunk = sparse ? (size_t)8 * kMsmBulkChunk : (size_t)kMsmMaxChunk;      // the sparse kernel walks its chunk in sub-chunks
         nchunks = std::max(nchunks, (n_dense + max_chunk - 1) / max_chunk);
     } else {
         // latency-bound launches: about two (term, window) pairs per quad (one or two rows) or four (many rows), at most 2048 workgroups
