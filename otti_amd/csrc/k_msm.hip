@@ -4,12 +4,14 @@
 namespace otti {
 
 // ------------------------------------------------------------------------------------------------ K8 fixed-base MSM
-// One workgroup sums a chunk of one row's terms.  Phase 1 stages the chunk's scalars in LDS as s' = raw(s) + K with
+// One workgroup sums a chunk of one row's terms (a whole row of up to 4096 terms in the bulk launches, walked in sub-chunks of
+// kMsmMaxChunk / kMsmBulkChunk terms that fit the LDS; the accumulators live across the sub-chunks).  Phase 1 stages a sub-chunk's
+// scalars in LDS as s' = raw(s) + K with
 // K = sum_w 2^(c-1+cw): the signed radix-2^c digit of window w is then (window w of s') - 2^(c-1), with no carry chain between
 // windows, so any thread can take any (term, window) pair.  Phase 2: thread (term lane tl, window w) walks the terms tl, tl+lanes, ..
 // and adds the table entry |d| * 2^(cw) * P[base] (affine Niels, 96-byte gather from HBM/L2; negated in registers when d < 0) into
 // its own accumulator with one 7-multiply mixed addition per pair.  Phase 3: LDS tree over the 256 accumulators.
-constexpr int kMsmMaxChunk = 1024;             // terms per workgroup (LDS: 36 B each)
+constexpr int kMsmMaxChunk = 1024;             // terms staged at a time (LDS: 36 B each)
 constexpr int kMsmBulkChunk = 512;             // bulk launches: terms per workgroup, and
 constexpr int kMsmListCap = (kMsmBulkChunk + 8) * 16;   // their (term, window) work-list entries (2 B each): (chunk + extras) * W must fit
 static_assert(kMsmBulkChunk + 8 <= 2048, "work-list entries pack the term index (within a sub-chunk) in 11 bits");
@@ -73,12 +75,8 @@ template <int kKind> __global__ __launch_bounds__(kBlock) void k_msm_rows(MsmArg
     const size_t j0 = (size_t)chunk_id * A.chunk;
     const uint32_t n_here = (uint32_t)min((size_t)A.chunk, A.n_dense - j0);
     const uint32_t n_ex = chunk_id == 0 ? (uint32_t)A.n_extra : 0u;
-    // ---- phase 1: recoded scalars into LDS (the sparse kind stages them sub-chunk by sub-chunk below)
-    if constexpr (kKind == MSM_BULK)
-        for (uint32_t t = threadIdx.x; t < n_here + n_ex; t += blockDim.x) {
-            const Fr sc = t >= n_here ? A.extra_s[row * A.n_extra + (t - n_here)] : A.dense[row * A.stride + j0 + t];
-            recode_scalar(s_raw + t * 9, sc, A.K);
-        }
+    // ---- phase 1 (recoded scalars into LDS) happens sub-chunk by sub-chunk below: a workgroup takes a whole chunk — a row, as a rule —
+    // in pieces that fit the LDS and keeps its accumulators across them, so there is ONE reduction tree and one partial per chunk
     if (threadIdx.x < 8) s_base[threadIdx.x] = A.extra_base[threadIdx.x];
     __syncthreads();
     // ---- phase 2: one mixed addition per (term, window) pair, in 26/25-bit limbs (fp10.h)
@@ -136,16 +134,29 @@ template <int kKind> __global__ __launch_bounds__(kBlock) void k_msm_rows(MsmArg
                 acc = p10_madd(acc, e);
             }
         }
-    } else if (tl < A.lanes) {
+    } else {
         const size_t WE = (size_t)A.W * A.E;
-        for (uint32_t t = tl; t < n_here + n_ex; t += A.lanes) {
-            const int d = recoded_digit(s_raw + t * 9, w, A.c);
-            if (d == 0) continue;
-            size_t base = t < n_here ? j0 + t : (size_t)s_base[t - n_here];
-            uint32_t mag = (uint32_t)(d < 0 ? -d : d);
-            N10 e = n10_unpack(A.table[base * WE + (size_t)w * A.E + (mag - 1)]);
-            if (d < 0) e = n10_negate(e);
-            acc = p10_madd(acc, e);
+        const uint32_t n_all = n_here + n_ex;
+        for (uint32_t sub0 = 0; sub0 < n_all; sub0 += kMsmMaxChunk) {
+            const uint32_t n_tot = min((uint32_t)kMsmMaxChunk, n_all - sub0);
+            if (sub0) __syncthreads();                           // the previous sub-chunk's scalars have been consumed
+            for (uint32_t t = threadIdx.x; t < n_tot; t += blockDim.x) {
+                const uint32_t T = sub0 + t;
+                const Fr sc = T >= n_here ? A.extra_s[row * A.n_extra + (T - n_here)] : A.dense[row * A.stride + j0 + T];
+                recode_scalar(s_raw + t * 9, sc, A.K);
+            }
+            __syncthreads();
+            if (tl < A.lanes)
+                for (uint32_t t = tl; t < n_tot; t += A.lanes) {
+                    const int d = recoded_digit(s_raw + t * 9, w, A.c);
+                    if (d == 0) continue;
+                    const uint32_t T = sub0 + t;
+                    size_t base = T < n_here ? j0 + T : (size_t)s_base[T - n_here];
+                    uint32_t mag = (uint32_t)(d < 0 ? -d : d);
+                    N10 e = n10_unpack(A.table[base * WE + (size_t)w * A.E + (mag - 1)]);
+                    if (d < 0) e = n10_negate(e);
+                    acc = p10_madd(acc, e);
+                }
         }
     }
     // ---- phase 3: LDS tree (reuses the scalar region: everyone must be done reading it)
@@ -394,7 +405,7 @@ static unsigned long long msm_launch(DevCtx &c, const DeviceGens &g, const Fr *d
         // the sparse variant keeps a (term, window) work list in LDS: (chunk + extras) * W <= kMsmListCap;  W <= 32 there (5-bit window field)
         nchunks = std::max<size_t>(1, (1024 + rows - 1) / rows);
         nchunks = std::min(nchunks, std::max<size_t>(1, n_dense / (size_t)A.lanes));
-        const size_t max_chunk = sparse ? (size_t)8 * kMsmBulkChunk : (size_t)kMsmMaxChunk;      // the sparse kernel walks its chunk in sub-chunks
+        const size_t max_chunk = 4096;                        // both bulk kernels walk their chunk in sub-chunks that fit the LDS
         nchunks = std::max(nchunks, (n_dense + max_chunk - 1) / max_chunk);
     } else {
         // latency-bound launches: about two (term, window) pairs per quad (one or two rows) or four (many rows), at most 2048 workgroups
