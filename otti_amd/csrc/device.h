@@ -87,6 +87,7 @@ struct DevCtx {
     static DevCtx &get();                                     // the calling thread's context; throws Error(OTTI_ERR_NO_DEVICE) when no device is usable
     DevCtx() {} DevCtx(const DevCtx &) = delete; DevCtx &operator=(const DevCtx &) = delete;
     struct Scratch *scratch = nullptr;                        // the prover's HBM workspace (prover.cpp); travels with the context
+    struct SnarkScratch *snark_scratch = nullptr;             // SNARK mode's per-proof buffers (snark_prover.cpp), kept across proofs like the above
     void sync();
     void wait_points(unsigned long long ticket);              // results of a dev_msm_rows launch: flag wait when fused, else stream sync
     void encode_pending();

@@ -29,6 +29,15 @@ struct DeviceDecomm {
     Fr *part(int p, int k) const { return comb_ops.p + (size_t)(3 * p + k) * N; }
 };
 
+// Per-proof buffers (2.5 GB at 2^20: dereferenced values, sixteen product circuits with all their layers, dot-product tables, ...) are
+// kept with the calling thread's device context and only ever grow: allocating and freeing them per proof cost ~4 ms of a 34 ms proof.
+struct SnarkScratch {
+    std::vector<DevBuf<Fr>> b;
+    Fr *get(size_t slot, size_t n) { if (b.size() <= slot) b.resize(slot + 1); if (b[slot].n < n) b[slot].alloc(n); return b[slot].p; }
+};
+enum { SS_MEM_RX = 0, SS_MEM_RY, SS_EQS, SS_DEREFS, SS_PARTIALS, SS_DOTP, SS_PYR, SS_EO, SS_EM, SS_PE0 /* 11 slots */, SS_OPS = SS_PE0 + 11 /* 12 */, SS_MEMC = SS_OPS + 12 /* 4 */ };
+static SnarkScratch &snark_workspace(DevCtx &c) { if (!c.snark_scratch) c.snark_scratch = new SnarkScratch(); return *c.snark_scratch; }
+
 namespace {
 std::vector<CPoint> commit_poly(DevCtx &c, Gens &gens, const Fr *Z, const PcSet &s) {
     ensure_gens_device(gens);
@@ -123,15 +132,15 @@ namespace {
 // a batch of product circuits of one size: layer k of circuit i is (left, right) = store + off[k] + {0, n >> (k + 1)}
 struct Circuits {
     size_t n = 0, nl = 0; int count = 0;
-    std::vector<DevBuf<Fr>> store; std::vector<size_t> off;
-    void init(int cnt, size_t n_) {
+    std::vector<Fr *> store; std::vector<size_t> off;
+    void init(int cnt, size_t n_, SnarkScratch &W, size_t first_slot) {
         n = n_; count = cnt; nl = std::max<size_t>(1, ilog2(n)); store.resize(cnt); off.assign(nl, 0);
         size_t o = 0; for (size_t k = 0; k < nl; k++) { off[k] = o; o += n >> k; }
-        for (auto &s : store) s.alloc(o);
+        for (int i = 0; i < cnt; i++) store[i] = W.get(first_slot + i, o);
     }
-    Fr *left(int i, size_t k) { return store[i].p + off[k]; }
-    Fr *right(int i, size_t k) { return store[i].p + off[k] + (n >> (k + 1)); }
-    Fr *input(int i) { return store[i].p; }                   // layer 0: the hashed vector itself, left half then right half
+    Fr *left(int i, size_t k) { return store[i] + off[k]; }
+    Fr *right(int i, size_t k) { return store[i] + off[k] + (n >> (k + 1)); }
+    Fr *input(int i) { return store[i]; }                     // layer 0: the hashed vector itself, left half then right half
     void build(DevCtx &c) {                                   // ProductCircuit::new: compute_layer, all circuits of the batch per launch
         for (size_t k = 1; k < nl; k++) {
             LayerList L; L.n = count;
@@ -284,16 +293,17 @@ DotProductProofLog polyeval_prove_plain(DevCtx &c, Gens &gens, const PcSet &s, c
     if (r.size() != s.num_vars) throw Error(OTTI_ERR_INTERNAL, "evaluation point of the wrong length");
     tr.append_protocol_name("polynomial evaluation proof");
     const size_t lv = s.num_vars / 2, lgR = ilog2(s.R);
-    DevBuf<Fr> Lv(s.L), Rv(s.R), LZ(s.R), a(s.R), sbuf(s.R), b2(s.R), s2(s.R), rows(2 * s.R), extras(4 * (lgR + 1)), eqs(5 * 4096), bound(64 * s.R);
-    dev_eq_evals(c, r.data(), lv, Lv.p, eqs.p);
-    dev_eq_evals(c, r.data() + lv, s.num_vars - lv, Rv.p, eqs.p);
-    dev_poly_bound(c, Z, s.L, s.R, Lv.p, LZ.p, bound.p);
+    SnarkScratch &W = snark_workspace(c);
+    Fr *Lv = W.get(SS_PE0 + 0, s.L), *Rv = W.get(SS_PE0 + 1, s.R), *LZ = W.get(SS_PE0 + 2, s.R), *a = W.get(SS_PE0 + 3, s.R), *sbuf = W.get(SS_PE0 + 4, s.R),
+       *b2 = W.get(SS_PE0 + 5, s.R), *s2 = W.get(SS_PE0 + 6, s.R), *rows = W.get(SS_PE0 + 7, 2 * s.R), *extras = W.get(SS_PE0 + 8, 4 * (lgR + 1)),
+       *eqs = W.get(SS_PE0 + 9, 5 * 4096), *bound = W.get(SS_PE0 + 10, 64 * s.R);
+    dev_eq_evals(c, r.data(), lv, Lv, eqs);
+    dev_eq_evals(c, r.data() + lv, s.num_vars - lv, Rv, eqs);
+    dev_poly_bound(c, Z, s.L, s.R, Lv, LZ, bound);
     const PcView pv = {s.h_n, s.g1, s.h1, s.R};
-    const PeBufs pb = {LZ.p, Rv.p, a.p, sbuf.p, b2.p, s2.p, rows.p, extras.p};
+    const PeBufs pb = {LZ, Rv, a, sbuf, b2, s2, rows, extras};
     CPoint Cy;
-    DotProductProofLog pf = dplog_prove_device(c, *gens.dev, gens, pv, pb, fr_zero(), &Zr, fr_zero(), Cy, tr, tape);
-    c.sync();                                                  // the buffers above go out of scope
-    return pf;
+    return dplog_prove_device(c, *gens.dev, gens, pv, pb, fr_zero(), &Zr, fr_zero(), Cy, tr, tape);
 }
 }  // namespace
 
@@ -331,7 +341,10 @@ std::vector<uint8_t> snark_prove_gpu(Instance &I, CompComm &comm, const uint8_t 
     if (((size_t)1 << nm) != M) throw Error(OTTI_ERR_INTERNAL, "memory size does not match the evaluation point");
     std::vector<Fr> rxe(nm - rx.size(), fr_zero()), rye(nm - ry.size(), fr_zero());     // equalize: zeros in FRONT of the shorter point
     rxe.insert(rxe.end(), rx.begin(), rx.end()); rye.insert(rye.end(), ry.begin(), ry.end());
-    DevBuf<Fr> mem_rx(M), mem_ry(M), eqs(5 * 4096), derefs((size_t)8 * N), partials((size_t)3 * 2048 + 64);                  // 3 sums x at most 2048 workgroups per launch (k_snark.hip many_grid)
+    SnarkScratch &W = snark_workspace(c);
+    struct Ptr { Fr *p; };                                    // (the buffers below used to be DevBufs of this proof; the code keeps reading x.p)
+    const Ptr mem_rx{W.get(SS_MEM_RX, M)}, mem_ry{W.get(SS_MEM_RY, M)}, eqs{W.get(SS_EQS, 5 * 4096)}, derefs{W.get(SS_DEREFS, (size_t)8 * N)},
+              partials{W.get(SS_PARTIALS, (size_t)3 * 2048 + 64)};             // 3 sums x at most 2048 workgroups per launch (k_snark.hip many_grid)
     dev_eq_evals(c, rxe.data(), nm, mem_rx.p, eqs.p);
     dev_eq_evals(c, rye.data(), nm, mem_ry.p, eqs.p);
     // dense.deref: row_ops_val[k][i] = mem_rx[row_addr[k][i]], col likewise; comb = merge(rows, cols), zero-padded to 8 N
@@ -352,7 +365,7 @@ std::vector<uint8_t> snark_prove_gpu(Instance &I, CompComm &comm, const uint8_t 
     const std::vector<Fr> r_mem_check = tr.challenge_vector("challenge_r_hash", 2);
     // PolyEvalNetwork::new: hash layers -> product circuits.  ops: row reads A,B,C; row writes; col reads; col writes.  mem: row init, row audit, col init, col audit.
     Circuits ops, mem;
-    ops.init(12, N); mem.init(4, M);
+    ops.init(12, N, W, SS_OPS); mem.init(4, M, W, SS_MEMC);
     lap("circuit allocations");
     for (int k = 0; k < 3; k++) {
         dev_hash_ops(c, d.part(0, k), drow(k), d.part(1, k), ops.input(k), ops.input(3 + k), N, r_mem_check[0], r_mem_check[1]);
@@ -364,7 +377,7 @@ std::vector<uint8_t> snark_prove_gpu(Instance &I, CompComm &comm, const uint8_t 
     ops.build(c); mem.build(c);
     lap("product layers");
     // the dot-product circuits: halves of (row_ops_val, col_ops_val, val) per matrix — copies, because the sum-check folds them in place
-    DevBuf<Fr> dotp((size_t)9 * N);
+    const Ptr dotp{W.get(SS_DOTP, (size_t)9 * N)};
     DotpTables D; D.len = H; D.n = 6;
     for (int k = 0; k < 3; k++) {
         Fr *base = dotp.p + (size_t)3 * k * N;
@@ -406,7 +419,7 @@ std::vector<uint8_t> snark_prove_gpu(Instance &I, CompComm &comm, const uint8_t 
     std::vector<Fr> rand_ops, rand_mem;
     lap("dotp copies, circuit outputs");
     {
-        DevBuf<Fr> pyr(2 * 8192);
+        const Ptr pyr{W.get(SS_PYR, 2 * 8192)};
         E.proof_ops = pcbatch_prove(c, ops, ops_evals, &D, dotp_evals, tr, pyr.p, rand_ops);
         lap("batched proof: ops");
         E.proof_mem = pcbatch_prove(c, mem, mem_evals, nullptr, {}, tr, pyr.p, rand_mem);
@@ -418,7 +431,7 @@ std::vector<uint8_t> snark_prove_gpu(Instance &I, CompComm &comm, const uint8_t 
     t0 = now_ms();
     tr.append_protocol_name("Sparse polynomial hash layer proof");
     {   // evaluations at rand_ops of the six dereferenced vectors and the fifteen committed ones, at rand_mem of the two audit vectors
-        DevBuf<Fr> Eo(N), Em(M);
+        const Ptr Eo{W.get(SS_EO, N)}, Em{W.get(SS_EM, M)};
         dev_eq_evals(c, rand_ops.data(), rand_ops.size(), Eo.p, eqs.p);
         dev_eq_evals(c, rand_mem.data(), rand_mem.size(), Em.p, eqs.p);
         PtrList Lo; Lo.n = 0;
