@@ -74,20 +74,6 @@ static bool fixed_base_msm_on_device(const Gens &g, const Fr *s, size_t n, Pt &o
 }
 static const bool g_hook_registered = [] { g_fixed_base_msm_hook = fixed_base_msm_on_device; return true; }();
 
-void instance_evaluate_gpu(Instance &I, const std::vector<Fr> &rx, const std::vector<Fr> &ry, Fr out[3]) {
-    DevCtx &c = DevCtx::get();
-    ensure_instance_device(I);
-    const size_t N = I.num_cons, V2 = 2 * I.num_vars;
-    if (((size_t)1 << rx.size()) != N || ((size_t)1 << ry.size()) != V2) throw Error(OTTI_ERR_VERIFY_INTERNAL, "challenge vector lengths do not match the instance");
-    DevBuf<Fr> ex(N), ey(V2), Mz[3] = {DevBuf<Fr>(N), DevBuf<Fr>(N), DevBuf<Fr>(N)}, scratch(5 * 4096);
-    dev_eq_evals(c, rx.data(), rx.size(), ex.p, scratch.p);
-    dev_eq_evals(c, ry.data(), ry.size(), ey.p, scratch.p);
-    dev_spmv3(c, I.dev->by_row, ey.p, Mz[0].p, Mz[1].p, Mz[2].p, false, nullptr);
-    for (int k = 0; k < 3; k++) dev_dot(c, ex.p, Mz[k].p, N, 16 + k);
-    c.sync();
-    for (int k = 0; k < 3; k++) out[k] = c.h_results[16 + k];
-}
-
 DeviceWitness::DeviceWitness(const Instance &I, const std::vector<Fr> &vars_padded, const std::vector<Fr> &inputs_) : inputs(inputs_) {
     DevCtx &c = DevCtx::get();
     if (vars_padded.size() != I.num_vars) throw Error(OTTI_ERR_INVALID_NUM_VARS, "witness length != padded num_vars");
@@ -169,13 +155,13 @@ struct ProofScratch {
     size_t N = 0, V = 0;
     DevBuf<Fr> T[4];          // eq(tau), Az, Bz, Cz  (N each)
     DevBuf<Fr> zw, ABC;       // phase-two working tables (2V each)
-    DevBuf<Fr> eqs;           // eq-table scratch (3 * 4096)
+    DevBuf<Fr> eqs;           // eq-table scratch (5 * 4096)
     DevBuf<Fr> pyr;           // the two eq pyramids of phase one: lo at [0, 8191), hi at [8192, 8192 + 16383)
     DevBuf<Fr> blinds, Lv, Rv, LZ, a, s, b2, s2, rows, extras, bound_scratch, pre;
     void reserve(size_t n, size_t v, size_t Lsz, size_t Rsz, size_t lgR) {
         if (n == N && v == V) return;
         for (auto &t : T) t.alloc(n);
-        zw.alloc(2 * v); ABC.alloc(2 * v); eqs.alloc(3 * 4096); pyr.alloc(8192 + 16384);
+        zw.alloc(2 * v); ABC.alloc(2 * v); eqs.alloc(5 * 4096); pyr.alloc(8192 + 16384);
         blinds.alloc(Lsz); Lv.alloc(Lsz); Rv.alloc(Rsz); LZ.alloc(Rsz); a.alloc(Rsz); s.alloc(Rsz); b2.alloc(Rsz); s2.alloc(Rsz); rows.alloc(2 * Rsz);
         extras.alloc(4 * (lgR + 1)); bound_scratch.alloc(64 * Rsz);
         N = n; V = v;
@@ -185,8 +171,28 @@ struct ProofScratch {
 struct Scratch : ProofScratch {};                                // the type DevCtx::scratch points to (device.h)
 namespace {
 ProofScratch &workspace(DevCtx &c) { if (!c.scratch) c.scratch = new Scratch(); return *c.scratch; }   // one per context, kept across proofs
+
 inline CPoint point_at(const DevCtx &c, size_t i) { CPoint p; memcpy(p.b, c.h_points + 32 * i, 32); return p; }
 }  // namespace
+
+// R1CSInstance::evaluate on the device, in the calling thread's proof workspace (nothing of a proof is live when a verifier or the SNARK
+// prover's closing step calls this; allocating 160 MB for it per call cost more than the evaluation)
+void instance_evaluate_gpu(Instance &I, const std::vector<Fr> &rx, const std::vector<Fr> &ry, Fr out[3]) {
+    DevCtx &c = DevCtx::get();
+    ensure_instance_device(I);
+    const size_t N = I.num_cons, V = I.num_vars, V2 = 2 * V;
+    if (((size_t)1 << rx.size()) != N || ((size_t)1 << ry.size()) != V2) throw Error(OTTI_ERR_VERIFY_INTERNAL, "challenge vector lengths do not match the instance");
+    ProofScratch &S = workspace(c);
+    { const size_t ell = ilog2(V), Lsz = (size_t)1 << (ell / 2), Rsz = (size_t)1 << (ell - ell / 2); S.reserve(N, V, Lsz, Rsz, ilog2(Rsz)); }
+    Fr *ex = S.T[0].p, *ey = S.zw.p, *Mz[3] = {S.T[1].p, S.T[2].p, S.T[3].p};
+    dev_eq_evals(c, rx.data(), rx.size(), ex, S.eqs.p);
+    dev_eq_evals(c, ry.data(), ry.size(), ey, S.eqs.p);
+    dev_spmv3(c, I.dev->by_row, ey, Mz[0], Mz[1], Mz[2], false, nullptr);
+    for (int k = 0; k < 3; k++) dev_dot(c, ex, Mz[k], N, 16 + k);
+    c.sync();
+    for (int k = 0; k < 3; k++) out[k] = c.h_results[16 + k];
+}
+
 
 // nizk/mod.rs DotProductProofLog::prove on device vectors: x = LZ (the bound polynomial row, R elements) against a = Rv, over the
 // generators gens_n = P[0..R) / gens_1 of the stream `g` was derived from (PcView: stream indices).  Cx, the bullet-reduction rounds
