@@ -85,6 +85,10 @@ DevCtx &DevCtx::get() {
     c->d_go.alloc(1);
     OTTI_HIP(hipMemset(c->d_go.p, 0, sizeof(GoBox)));
     OTTI_HIP(hipEventCreate(&c->ev0)); OTTI_HIP(hipEventCreate(&c->ev1));
+    // first launch from this library: makes the runtime load and register its code object NOW (tens of ms for a module of this size) —
+    // a one-shot process creates its context on a thread of its own while the input is being parsed
+    dev_fill_one(*c, c->results.p, 1);
+    OTTI_HIP(hipStreamSynchronize(c->stream));
     lease.c = c.release();
     return *lease.c;
 }
