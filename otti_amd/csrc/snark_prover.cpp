@@ -39,9 +39,10 @@ enum { SS_MEM_RX = 0, SS_MEM_RY, SS_EQS, SS_DEREFS, SS_PARTIALS, SS_DOTP, SS_PYR
 static SnarkScratch &snark_workspace(DevCtx &c) { if (!c.snark_scratch) c.snark_scratch = new SnarkScratch(); return *c.snark_scratch; }
 
 namespace {
-std::vector<CPoint> commit_poly(DevCtx &c, Gens &gens, const Fr *Z, const PcSet &s) {
+// sparse_hint: 1 / 0 = the scalars are / are not mostly small numbers (picks the bulk MSM variant); -1 = look (a pass over Z and a synchronise)
+std::vector<CPoint> commit_poly(DevCtx &c, Gens &gens, const Fr *Z, const PcSet &s, int sparse_hint = -1) {
     ensure_gens_device(gens);
-    const bool sparse = dev_small_fraction(c, Z, s.L * s.R) > 0.25;
+    const bool sparse = sparse_hint >= 0 ? sparse_hint != 0 : dev_small_fraction(c, Z, s.L * s.R) > 0.25;
     dev_msm_rows(c, *gens.dev, Z, s.R, s.R, s.L, nullptr, nullptr, 0, MSM_COMPRESSED, nullptr, sparse);
     c.sync();
     std::vector<CPoint> out(s.L);
@@ -354,7 +355,7 @@ std::vector<uint8_t> snark_prove_gpu(Instance &I, CompComm &comm, const uint8_t 
     lap("allocations, eq tables");
     for (int k = 0; k < 3; k++) { dev_gather(c, mem_rx.p, d.row_addr[k].p, drow(k), N); dev_gather(c, mem_ry.p, d.col_addr[k].p, dcol(k), N); }
     lap("deref gathers");
-    E.comm_derefs = commit_poly(c, *g.eval, derefs.p, g.derefs);
+    E.comm_derefs = commit_poly(c, *g.eval, derefs.p, g.derefs, 0);      // values of eq tables: uniform field elements
     tr.append_message("derefs_commitment", "begin_derefs_commitment", 23);
     append_poly_commitment(tr, "comm_poly_row_col_ops_val", E.comm_derefs);
     tr.append_message("derefs_commitment", "end_derefs_commitment", 21);
