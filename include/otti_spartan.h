@@ -127,6 +127,9 @@ void    otti_comp_comm_free(otti_comp_comm *comm);
 int32_t otti_snark_prove(otti_instance *inst, otti_comp_comm *comm, const uint8_t *vars32, size_t nvars, const uint8_t *inputs32, size_t ninputs,
                          otti_snark_gens *gens, const uint8_t *tlabel, size_t tlabel_len, const uint8_t *seed32, uint32_t flags,
                          uint8_t **proof, size_t *proof_len, double *stage_ms);
+/* the same with the assignment already resident in HBM (otti_witness_upload): what a long-lived prover calls per proof */
+int32_t otti_snark_prove_resident(otti_instance *inst, otti_comp_comm *comm, otti_witness *wit, otti_snark_gens *gens, const uint8_t *tlabel,
+                                  size_t tlabel_len, const uint8_t *seed32, uint8_t **proof, size_t *proof_len, double *stage_ms);
 int32_t otti_snark_verify(const otti_comp_comm *comm, const uint8_t *inputs32, size_t ninputs, const otti_snark_gens *gens,
                           const uint8_t *tlabel, size_t tlabel_len, const uint8_t *proof, size_t proof_len);
 void    otti_buf_free(void *p);

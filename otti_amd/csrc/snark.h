@@ -71,5 +71,8 @@ struct SnarkTimings { double ms[10]; };                      // the six R1CSProo
 std::unique_ptr<CompComm> snark_encode_gpu(Instance &inst, SnarkGens &g);
 std::vector<uint8_t> snark_prove_gpu(Instance &inst, CompComm &comm, const uint8_t *vars32, size_t nvars, const std::vector<Fr> &inputs, SnarkGens &g,
                                      const void *tlabel, size_t tlabel_len, const uint8_t *seed32, SnarkTimings *tm);
+struct DeviceWitness;                                        // device.h: the assignment resident in HBM (otti_witness_upload)
+std::vector<uint8_t> snark_prove_resident(Instance &inst, CompComm &comm, DeviceWitness &wit, SnarkGens &g, const void *tlabel, size_t tlabel_len,
+                                          const uint8_t *seed32, SnarkTimings *tm);
 
 }  // namespace otti

@@ -311,6 +311,12 @@ DotProductProofLog polyeval_prove_plain(DevCtx &c, Gens &gens, const PcSet &s, c
 // ================================================================================================ SNARK::prove
 std::vector<uint8_t> snark_prove_gpu(Instance &I, CompComm &comm, const uint8_t *vars32, size_t nvars, const std::vector<Fr> &inputs, SnarkGens &g,
                                      const void *tlabel, size_t tlabel_len, const uint8_t *seed32, SnarkTimings *tm) {
+    if (I.num_cons != comm.num_cons || I.num_vars != comm.num_vars || I.num_inputs != comm.num_inputs) throw Error(OTTI_ERR_BAD_ARG, "commitment belongs to another instance");
+    DeviceWitness wit(I, vars32, nvars, inputs);                 // uploaded (and checked for canonical scalars) inside the call
+    return snark_prove_resident(I, comm, wit, g, tlabel, tlabel_len, seed32, tm);
+}
+std::vector<uint8_t> snark_prove_resident(Instance &I, CompComm &comm, DeviceWitness &wit, SnarkGens &g, const void *tlabel, size_t tlabel_len,
+                                          const uint8_t *seed32, SnarkTimings *tm) {
     DevCtx &c = DevCtx::get();
     ActiveProof active;
     SpinPool::Session pool_session;
@@ -321,8 +327,7 @@ std::vector<uint8_t> snark_prove_gpu(Instance &I, CompComm &comm, const uint8_t 
     auto lap = [&](const char *what) { if (!trace) return; c.sync(); const double t = now_ms(); fprintf(stderr, "[otti] snark_prove %-34s %.3f ms\n", what, t - t_lap); t_lap = t; };
     ensure_gens_device(*g.eval);
     const DeviceDecomm &d = *comm.dec; const size_t N = d.N, M = d.M, H = N / 2;
-    DeviceWitness wit(I, vars32, nvars, inputs);
-    lap("witness upload");
+    if (wit.z.n != 2 * I.num_vars || wit.inputs.size() != I.num_inputs) throw Error(OTTI_ERR_BAD_ARG, "witness belongs to another instance");
     Transcript tr(tlabel, tlabel_len);
     RandomTape tape(seed32);
     SnarkProof S;

@@ -43,6 +43,22 @@ def test_snark_commitment_and_proof_bytes_identical_to_oracle(n, ni, kind):
         oa.SNARK.prove(inst, verifier_comm, oa.VarsAssignment.new(r["vars"]), inputs, gens, LABEL, SEED)   # no decommitment in a parsed commitment
 
 
+def test_snark_resident_witness_gives_the_same_proof():
+    r, nz = _case(1 << 10, 10, "compiler")
+    inst = oa.Instance.new(r["num_cons"], r["num_vars"], r["num_inputs"], r["A"], r["B"], r["C"])
+    gens = oa.SNARKGens.new(r["num_cons"], r["num_vars"], r["num_inputs"], nz)
+    comm = oa.ComputationCommitment.encode(inst, gens)
+    v, i = oa.VarsAssignment.new(r["vars"]), oa.InputsAssignment.new(r["inputs"])
+    want = oa.SNARK.prove(inst, comm, v, i, gens, LABEL, SEED).bytes
+    w = oa.Witness(inst, v, i)                                # uploaded once, proved from twice
+    assert oa.SNARK.prove(inst, comm, w, None, gens, LABEL, SEED).bytes == want
+    assert oa.SNARK.prove(inst, comm, w, None, gens, LABEL, SEED).bytes == want
+    other = oa.synth_r1cs(1 << 9, 10, 3)
+    small = oa.Instance.new(other["num_cons"], other["num_vars"], other["num_inputs"], other["A"], other["B"], other["C"])
+    with pytest.raises(oa.SpartanError):                      # a witness of another instance is refused
+        oa.SNARK.prove(inst, comm, oa.Witness(small, oa.VarsAssignment.new(other["vars"]), oa.InputsAssignment.new(other["inputs"])), None, gens, LABEL, SEED)
+
+
 def test_snark_proofs_repeat_and_differ_by_seed():
     r, nz = _case(256, 5, "uniform")
     inst = oa.Instance.new(r["num_cons"], r["num_vars"], r["num_inputs"], r["A"], r["B"], r["C"])
