@@ -69,6 +69,7 @@ struct DevCtx {
     Fr *d_results_alias = nullptr;                            // device address of h_results (zero-copy stores)
     unsigned long long *h_flag = nullptr, *d_flag_alias = nullptr, seq = 0;   // host-visible completion flag of the latest mailbox launch
     DevBuf<unsigned> d_counter;                               // arrival counter of the publishing workgroups
+    DevBuf<unsigned long long> d_counts;                      // two 64-bit tallies for the kernels that count (non-canonical / small scalars): no allocation per call
     Mailbox next_mailbox(int slot);
     GoBox *h_go = nullptr, *d_go_alias = nullptr; DevBuf<GoBox> d_go; unsigned long long go_issued = 0, go_published = 0;
     bool armed_ok() const;                                    // off under OTTI_ARMED=0, while kernel classes are being timed (a waiting kernel's duration includes the host), and
@@ -139,7 +140,7 @@ std::shared_ptr<DeviceShard> upload_instance_shard(const Instance &I, int rank, 
 struct PeBufs { Fr *LZ, *Rv, *a, *s, *b2, *s2, *rows, *extras; };      // R elements each (rows: 2 R, extras: 4 (log2 R + 1))
 DotProductProofLog dplog_prove_device(DevCtx &c, const DeviceGens &DG, const Gens &g, const PcView &v, const PeBufs &B, const Fr &LZ_blind, const Fr *y_known,
                                       const Fr &blind_y, CPoint &Cy_out, Transcript &tr, RandomTape &tape);
-size_t dev_witness_ingest(DevCtx &c, Fr *z, size_t n);                     // returns the number of non-canonical scalars (zeroed)
+size_t dev_witness_ingest(DevCtx &c, Fr *z, size_t n, size_t *n_small = nullptr);   // returns the number of non-canonical scalars (zeroed); n_small: how many are below 2^128
 void dev_gather_strided(DevCtx &c, const Fr *in, size_t stride, size_t offset, Fr *out, size_t n);   // out[i] = in[i*stride + offset]
 
 std::shared_ptr<DeviceInstance> upload_instance(const Instance &I);

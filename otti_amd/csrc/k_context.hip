@@ -79,6 +79,7 @@ DevCtx &DevCtx::get() {
     OTTI_HIP(hipHostGetDevicePointer((void **)&c->d_flag_alias, c->h_flag, 0));
     c->d_counter.alloc(1);
     OTTI_HIP(hipMemset(c->d_counter.p, 0, sizeof(unsigned)));
+    c->d_counts.alloc(2);
     OTTI_HIP(hipHostMalloc((void **)&c->h_go, sizeof(GoBox), hipHostMallocDefault));
     memset(c->h_go, 0, sizeof(GoBox));
     OTTI_HIP(hipHostGetDevicePointer((void **)&c->d_go_alias, c->h_go, 0));

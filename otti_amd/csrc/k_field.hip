@@ -26,23 +26,27 @@ void dev_fetch(DevCtx &c, const Fr *src, int slot, size_t n) { OTTI_HIP(hipMemcp
 
 // VarsAssignment::new on the device: canonical little-endian scalars (the caller's bytes, uploaded as they are) -> Montgomery form in
 // place; values >= l are counted (upstream: R1CSError::InvalidScalar) and left as zero.
-__global__ __launch_bounds__(kBlock) void k_witness_ingest(Fr *z, size_t n, unsigned long long *bad) {
-    unsigned mine = 0;
+// counts[0]: non-canonical scalars; counts[1]: scalars below 2^128 (the share of small values picks the commitment's MSM variant)
+__global__ __launch_bounds__(kBlock) void k_witness_ingest(Fr *z, size_t n, unsigned long long *counts) {
+    unsigned bad = 0, small = 0;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         Fr raw = z[i];
-        if (fr_raw_is_canonical(raw.v)) z[i] = fr_mul(raw, fr_R2()); else { z[i] = fr_zero(); mine++; }
+        if (fr_raw_is_canonical(raw.v)) { z[i] = fr_mul(raw, fr_R2()); small += (raw.v[4] | raw.v[5] | raw.v[6] | raw.v[7]) == 0 ? 1u : 0u; }
+        else { z[i] = fr_zero(); bad++; small++; }
     }
-    if (mine) atomicAdd(bad, (unsigned long long)mine);
+    for (int o = 32; o >= 1; o >>= 1) { bad += __shfl_down(bad, o); small += __shfl_down(small, o); }
+    if ((threadIdx.x & 63) == 0) { if (bad) atomicAdd(&counts[0], (unsigned long long)bad); if (small) atomicAdd(&counts[1], (unsigned long long)small); }
 }
-size_t dev_witness_ingest(DevCtx &c, Fr *z, size_t n) {
+size_t dev_witness_ingest(DevCtx &c, Fr *z, size_t n, size_t *n_small) {
+    if (n_small) *n_small = 0;
     if (!n) return 0;
-    DevBuf<unsigned long long> bad(1);
-    OTTI_HIP(hipMemsetAsync(bad.p, 0, sizeof(unsigned long long), c.stream));
-    hipLaunchKernelGGL(k_witness_ingest, grid_for(n), kBlock, 0, c.stream, z, n, bad.p);
-    unsigned long long h = 0;
-    OTTI_HIP(hipMemcpyAsync(&h, bad.p, sizeof h, hipMemcpyDeviceToHost, c.stream));
+    OTTI_HIP(hipMemsetAsync(c.d_counts.p, 0, 2 * sizeof(unsigned long long), c.stream));
+    hipLaunchKernelGGL(k_witness_ingest, grid_for(n), kBlock, 0, c.stream, z, n, c.d_counts.p);
+    unsigned long long h[2] = {0, 0};
+    OTTI_HIP(hipMemcpyAsync(h, c.d_counts.p, sizeof h, hipMemcpyDeviceToHost, c.stream));
     OTTI_HIP(hipStreamSynchronize(c.stream));
-    return (size_t)h;
+    if (n_small) *n_small = (size_t)h[1];
+    return (size_t)h[0];
 }
 __global__ __launch_bounds__(kBlock) void k_gather_strided(const Fr *in, size_t stride, size_t offset, Fr *out, size_t n) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = in[i * stride + offset];

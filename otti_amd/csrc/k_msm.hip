@@ -374,11 +374,10 @@ __global__ __launch_bounds__(kBlock) void k_count_small(const Fr *z, size_t n, u
 }
 double dev_small_fraction(DevCtx &c, const Fr *z, size_t n) {
     if (!n) return 0.0;
-    DevBuf<unsigned long long> cnt(1);
-    OTTI_HIP(hipMemsetAsync(cnt.p, 0, sizeof(unsigned long long), c.stream));
-    hipLaunchKernelGGL(k_count_small, grid_for(n), kBlock, 0, c.stream, z, n, cnt.p);
+    OTTI_HIP(hipMemsetAsync(c.d_counts.p, 0, sizeof(unsigned long long), c.stream));
+    hipLaunchKernelGGL(k_count_small, grid_for(n), kBlock, 0, c.stream, z, n, c.d_counts.p);
     unsigned long long h = 0;
-    OTTI_HIP(hipMemcpyAsync(&h, cnt.p, sizeof h, hipMemcpyDeviceToHost, c.stream));
+    OTTI_HIP(hipMemcpyAsync(&h, c.d_counts.p, sizeof h, hipMemcpyDeviceToHost, c.stream));
     OTTI_HIP(hipStreamSynchronize(c.stream));
     return (double)h / (double)n;
 }

@@ -99,8 +99,9 @@ DeviceWitness::DeviceWitness(const Instance &I, const uint8_t *vars32, size_t nv
     std::vector<Fr> tail(1 + inputs.size()); tail[0] = fr_one();
     for (size_t i = 0; i < inputs.size(); i++) tail[1 + i] = inputs[i];
     OTTI_HIP(hipMemcpyAsync(z.p + V, tail.data(), tail.size() * sizeof(Fr), hipMemcpyHostToDevice, c.stream));
-    if (dev_witness_ingest(c, z.p, nvars)) throw Error(OTTI_ERR_INVALID_SCALAR, "non-canonical scalar in assignment");   // synchronises: `tail` and the caller's buffer are free again
-    small_fraction = dev_small_fraction(c, z.p, V);
+    size_t n_small = 0;
+    if (dev_witness_ingest(c, z.p, nvars, &n_small)) throw Error(OTTI_ERR_INVALID_SCALAR, "non-canonical scalar in assignment");   // synchronises: `tail` and the caller's buffer are free again
+    small_fraction = V ? (double)(n_small + (V - nvars)) / (double)V : 0.0;        // the padding zeros count as small
 }
 
 namespace {
