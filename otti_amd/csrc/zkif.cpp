@@ -27,11 +27,13 @@ struct Buf {
     const uint8_t *p; size_t n;
     void chk(size_t off, size_t len) const { if (off > n || len > n - off) throw Error(OTTI_ERR_IO, "zkif: offset out of bounds"); }
     uint8_t u8(size_t o) const { chk(o, 1); return p[o]; }
-    uint16_t u16(size_t o) const { chk(o, 2); return (uint16_t)(p[o] | (p[o + 1] << 8)); }
-    uint32_t u32(size_t o) const { chk(o, 4); return (uint32_t)p[o] | ((uint32_t)p[o + 1] << 8) | ((uint32_t)p[o + 2] << 16) | ((uint32_t)p[o + 3] << 24); }
+    // FlatBuffers are little-endian, and so is every host this library is built for (x86-64): plain unaligned loads after ONE bounds test
+    uint16_t u16(size_t o) const { chk(o, 2); uint16_t v; memcpy(&v, p + o, 2); return v; }
+    uint32_t u32(size_t o) const { chk(o, 4); uint32_t v; memcpy(&v, p + o, 4); return v; }
     int32_t i32(size_t o) const { return (int32_t)u32(o); }
-    uint64_t u64(size_t o) const { return (uint64_t)u32(o) | ((uint64_t)u32(o + 4) << 32); }
+    uint64_t u64(size_t o) const { chk(o, 8); uint64_t v; memcpy(&v, p + o, 8); return v; }
 };
+static_assert(__BYTE_ORDER__ == __ORDER_LITTLE_ENDIAN__, "the zkInterface reader loads little-endian fields directly");
 struct Table {
     const Buf *b; size_t pos = 0; bool present = false;
     // absolute position of field `id`, or 0 when absent
