@@ -259,6 +259,10 @@ int32_t otti_stats_enable(int32_t on);
 /* restrict timing to one class (call after enable): two event records per launch are not free on the latency-bound round loop */
 int32_t otti_stats_select(const char *kernel_class);
 int32_t otti_stats_read(const char *kernel_class, uint64_t *count, double *total_ms);
+/* SNARK mode adds the classes pc_round (rounds of the batched product-circuit sum-checks) prod_layer hash_layer gather dot_many. */
+/* 1 when the calling thread's next proof would use armed launches (kernels queued ahead of their challenge): off under OTTI_ARMED=0,
+   while a class with armed kernels (msm_small sc_cubic sc_quad pc_round) is being timed, and with several proofs in flight */
+int32_t otti_armed_launches_on(int32_t *on);
 
 /* ---- multi-GPU plumbing: sum-check partial sums travel as 8 x u32 limbs widened to u64 lanes so that a plain integer
         sum all-reduce (RCCL ncclSum/ncclUint64, or gloo in CPU tests) followed by one normalisation gives the Fr sum ---- */

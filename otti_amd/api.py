@@ -105,6 +105,7 @@ _sig("otti_synth_r1cs_compiler_like", _i32, _u64, _u64, _u64, ctypes.POINTER(cty
 _sig("otti_bench_madd_peak", _i32, ctypes.POINTER(ctypes.c_double))
 _sig("otti_stats_enable", _i32, _i32)
 _sig("otti_stats_select", _i32, ctypes.c_char_p)
+_sig("otti_armed_launches_on", _i32, ctypes.POINTER(_i32))
 _sig("otti_stats_read", _i32, ctypes.c_char_p, ctypes.POINTER(_u64), ctypes.POINTER(ctypes.c_double))
 _sig("otti_lanes_pack", None, _vp, _sz, _vp)
 _sig("otti_lanes_unpack", None, _vp, _sz, _vp)
@@ -491,12 +492,16 @@ def _r1cs_to_py(rp):
     def ents(p, n):
         if not n:
             return np.zeros(0, dtype=ENTRY_DTYPE)
-        return np.ctypeslib.as_array(ctypes.cast(p, _u8p), shape=(n * ENTRY_DTYPE.itemsize,)).view(ENTRY_DTYPE).copy()
+        a = np.empty(n, dtype=ENTRY_DTYPE)                     # one memcpy (np.ctypeslib.as_array builds a ctypes array type per shape: seconds at 2^22)
+        ctypes.memmove(a.ctypes.data, ctypes.cast(p, _vp), n * ENTRY_DTYPE.itemsize)
+        return a
 
     def bytes32(p, n):
         if not n:
             return np.zeros((0, 32), dtype=np.uint8)
-        return np.ctypeslib.as_array(ctypes.cast(p, _u8p), shape=(n * 32,)).reshape(n, 32).copy()
+        a = np.empty((n, 32), dtype=np.uint8)
+        ctypes.memmove(a.ctypes.data, ctypes.cast(p, _vp), n * 32)
+        return a
 
     out = dict(num_cons=r.num_cons, num_vars=r.num_vars, num_inputs=r.num_inputs, A=ents(r.A, r.nA), B=ents(r.B, r.nB), C=ents(r.C, r.nC),
                vars=bytes32(r.vars32, r.nvars), inputs=bytes32(r.inputs32, r.ninputs))
@@ -546,13 +551,21 @@ def fr_to_ints(a):
     return [int.from_bytes(a[k].tobytes(), "little") * _RINV % L_ORDER for k in range(a.shape[0])]
 
 
-KERNEL_CLASSES = ("msm_rows", "msm_small", "msm_finish", "sc_cubic", "sc_quad", "spmv", "eq", "reduce", "poly_bound", "bullet", "other")
+KERNEL_CLASSES = ("msm_rows", "msm_small", "msm_finish", "sc_cubic", "sc_quad", "spmv", "eq", "reduce", "poly_bound", "bullet", "other",
+                  "pc_round", "prod_layer", "hash_layer", "gather", "dot_many")
 
 
 def stats_enable(on=True, only=None):
     _check(lib.otti_stats_enable(1 if on else 0))
     if on and only is not None:
         _check(lib.otti_stats_select(only.encode()))
+
+
+def armed_launches_on():
+    """whether the calling thread's next proof uses armed launches (see otti_armed_launches_on)"""
+    v = _i32()
+    _check(lib.otti_armed_launches_on(ctypes.byref(v)))
+    return bool(v.value)
 
 
 def madd_peak():

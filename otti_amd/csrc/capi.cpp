@@ -537,6 +537,28 @@ int32_t otti_k_armed_selftest(const uint8_t *A, const uint8_t *B, size_t len, co
         tk = dev_sc_quad_fold_eval_armed(c, a1.d.p, b1.d.p, h, 0); c.go(&rr, 1); c.wait_ticket(tk);
         if (memcmp(e_plain, c.h_results, 64)) throw Error(OTTI_ERR_INTERNAL, "armed round after an abort: sums differ from the plain launch");
         c.sync();
+        // armed, and the host stalls beyond the launch's deadline (shortened to 2 ms here): the leader gives up for the WHOLE grid (nothing
+        // folded, in any workgroup), says so, the host's wait fails at once, and the context is clean for the next round
+        if (len >= 16) {
+            const size_t q = h / 2;                                                      // both table pairs are down to q elements by now
+            download(c, before.data(), a1.d.p, q); c.sync();
+            struct Restore { DevCtx &c; unsigned long long d; ~Restore() { c.arm_deadline = d; } } restore{c, c.arm_deadline};
+            c.arm_deadline = 200000ull;                                                  // 2 ms of the 100 MHz clock
+            tk = dev_sc_quad_fold_eval_armed(c, a1.d.p, b1.d.p, q, 0);
+            { const auto t0 = std::chrono::steady_clock::now(); while (std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(20)) {} }
+            bool failed = false;
+            try { c.go(&rr, 1); c.wait_ticket(tk); } catch (const Error &) { failed = true; }
+            if (!failed) throw Error(OTTI_ERR_INTERNAL, "armed round past its deadline still delivered a result");
+            c.arm_deadline = restore.d;
+            download(c, after.data(), a1.d.p, q); c.sync();
+            if (memcmp(before.data(), after.data(), 32 * q)) throw Error(OTTI_ERR_INTERNAL, "armed round past its deadline wrote to its tables");
+            unsigned cnt = 1; OTTI_HIP(hipMemcpy(&cnt, c.d_counter.p, sizeof cnt, hipMemcpyDeviceToHost));
+            if (cnt) throw Error(OTTI_ERR_INTERNAL, "arrival counter left non-zero after a timed-out armed round");
+            tk = dev_sc_quad_fold_eval(c, a0.d.p, b0.d.p, q, rr, 0); c.wait_ticket(tk); e_plain[0] = c.h_results[0]; e_plain[1] = c.h_results[1];
+            tk = dev_sc_quad_fold_eval_armed(c, a1.d.p, b1.d.p, q, 0); c.go(&rr, 1); c.wait_ticket(tk);
+            if (memcmp(e_plain, c.h_results, 64)) throw Error(OTTI_ERR_INTERNAL, "armed round after a timed-out one: sums differ from the plain launch");
+            c.sync();
+        }
         return OTTI_OK;
     });
 }
@@ -572,10 +594,18 @@ struct EqPyramids {
     }
 };
 std::vector<Fr> fr_load_vec(const uint8_t *p, size_t n) { std::vector<Fr> v(n + 1); for (size_t i = 0; i < n; i++) v[i] = fr_load(p + 32 * i); return v; }
-struct StreamScope {                     // run the library's launch functions on a caller's stream for the duration of one call
+// Run the library's launch functions on a caller's stream for the duration of one call.  The launches share the context's scratch
+// (round partials, arrival counters, MSM partials, result slots), so work enqueued on one stream must not overlap work on another:
+// entering, the caller's stream waits for everything the context's own stream has been given; leaving, the context's own stream
+// waits for what was just enqueued — two calls on different caller streams are thereby ordered through the context's stream.
+struct StreamScope {
     DevCtx &c; hipStream_t old;
-    StreamScope(DevCtx &c_, void *s) : c(c_), old(c_.stream) { if (s) c.stream = (hipStream_t)s; }
-    ~StreamScope() { c.stream = old; }
+    void order(hipStream_t after, hipStream_t before) {
+        if (!c.ev_order) OTTI_HIP(hipEventCreateWithFlags(&c.ev_order, hipEventDisableTiming));
+        OTTI_HIP(hipEventRecord(c.ev_order, before)); OTTI_HIP(hipStreamWaitEvent(after, c.ev_order, 0));
+    }
+    StreamScope(DevCtx &c_, void *s) : c(c_), old(c_.stream) { if (s && (hipStream_t)s != old) { order((hipStream_t)s, old); c.stream = (hipStream_t)s; } }
+    ~StreamScope() { if (c.stream != old) { hipStream_t mine = c.stream; c.stream = old; try { order(old, mine); } catch (...) {} } }
 };
 }  // namespace
 }  // extern "C++"
@@ -731,12 +761,14 @@ int32_t otti_bench_madd_peak(double *madds_per_second) {
 }
 
 // ------------------------------------------------------------------------------------------------ kernel timing (HIP events on the library stream)
-static const char *kClassNames[KC_COUNT] = {"msm_rows", "msm_small", "msm_finish", "sc_cubic", "sc_quad", "spmv", "eq", "reduce", "poly_bound", "bullet", "other"};
+static const char *kClassNames[KC_COUNT] = {"msm_rows", "msm_small", "msm_finish", "sc_cubic", "sc_quad", "spmv", "eq", "reduce", "poly_bound", "bullet", "other",
+                                               "pc_round", "prod_layer", "hash_layer", "gather", "dot_many"};
 int32_t otti_stats_enable(int32_t on) { KStats::get().on = on != 0; KStats::get().mask = 0xffffffffu; KStats::get().reset(); return OTTI_OK; }
 int32_t otti_stats_select(const char *kernel_class) {
     for (int k = 0; k < KC_COUNT; k++) if (!strcmp(kernel_class, kClassNames[k])) { KStats::get().mask = 1u << k; return OTTI_OK; }
     return OTTI_ERR_BAD_ARG;
 }
+int32_t otti_armed_launches_on(int32_t *on) { return guarded([&] { if (!on) throw Error(OTTI_ERR_BAD_ARG, "null argument"); *on = DevCtx::get().armed_ok() ? 1 : 0; return OTTI_OK; }); }
 int32_t otti_stats_read(const char *kernel_class, uint64_t *count, double *total_ms) {
     return guarded([&] {
         KStats &s = KStats::get();

@@ -55,8 +55,13 @@ struct Mailbox { Fr *partials; unsigned *counter; Fr *host_results; unsigned lon
 // launched once the host knows the round's challenge.  An ARMED kernel is queued before that: its first workgroup spins on a pinned host
 // word until the host publishes the value (DevCtx::go), copies it to HBM for the other workgroups, and the round starts within a PCIe
 // read of the challenge being known.  Every spin has a deadline (3 s of s_memrealtime) and an abort value, so a grid always drains.
-struct GoBox { unsigned long long seq, pad[3]; Fr v[4]; };
-struct Armed { const GoBox *host; GoBox *dev; unsigned long long want; };   // want == 0: not armed (values come as kernel arguments)
+// ONE decision per armed launch: only the launch's first workgroup watches the host word and its deadline, and what it decides (the
+// value arrived / aborted / gave up) is what every other workgroup acts on (they watch dev->seq alone, with a backstop far beyond
+// the leader's deadline) — a grid never folds in part.  A leader that gives up says so in host->timed_out, so the host fails the
+// proof at once instead of waiting for a result that will not come.
+struct GoBox { unsigned long long seq, timed_out, pad[2]; Fr v[4]; };
+struct Armed { GoBox *host; GoBox *dev; unsigned long long want, deadline; };   // want == 0: not armed (values come as kernel arguments); deadline in 100 MHz ticks
+constexpr unsigned long long kArmDeadlineTicks = 3000000000ull;   // 30 s of s_memrealtime: longer than any host stall the prover's own 20 s result wait tolerates
 constexpr size_t kArmMaxLen = 65536;                         // sum-check tables up to this length fold in <= 64 workgroups: only those launches are armed
 
 struct DevCtx {
@@ -72,6 +77,10 @@ struct DevCtx {
     DevBuf<unsigned long long> d_counts;                      // two 64-bit tallies for the kernels that count (non-canonical / small scalars): no allocation per call
     Mailbox next_mailbox(int slot);
     GoBox *h_go = nullptr, *d_go_alias = nullptr; DevBuf<GoBox> d_go; unsigned long long go_issued = 0, go_published = 0;
+    unsigned long long arm_deadline = kArmDeadlineTicks;     // of the launches armed from now on (the self-test shortens it)
+    bool host_coherent = false;                               // the words kernels spin on / mail to are fine-grained coherent host memory (else: no armed launches)
+    void reset_arrival_counters();                            // after an aborted or timed-out launch: a grid may have left them non-zero (stream must be idle)
+    hipEvent_t ev_order = nullptr;                            // orders a caller's stream (otti_kd_*) against this context's own
     bool armed_ok() const;                                    // off under OTTI_ARMED=0, while kernel classes are being timed (a waiting kernel's duration includes the host), and
                                                               // while another proof is in flight in this process (a waiting grid holds wave slots the other proof's kernels could use: measured -15 % throughput with six in flight)
     Armed arm();                                              // for the next launch; the k-th armed launch consumes the k-th go()
@@ -101,7 +110,8 @@ constexpr size_t kHostEncodeRows = 8;
 constexpr size_t kHostPtsCap = 512;
 
 // per-kernel-class HIP-event timing on the library's own stream (bench.py's roofline numbers come from here)
-enum KClass { KC_MSM_ROWS = 0, KC_MSM_SMALL, KC_MSM_FINISH, KC_SC_CUBIC, KC_SC_QUAD, KC_SPMV, KC_EQ, KC_REDUCE, KC_BOUND, KC_BULLET, KC_OTHER, KC_COUNT };
+enum KClass { KC_MSM_ROWS = 0, KC_MSM_SMALL, KC_MSM_FINISH, KC_SC_CUBIC, KC_SC_QUAD, KC_SPMV, KC_EQ, KC_REDUCE, KC_BOUND, KC_BULLET, KC_OTHER,
+              KC_PC_ROUND, KC_PROD_LAYER, KC_HASH_LAYER, KC_GATHER, KC_DOT_MANY /* SNARK mode (k_snark.hip) */, KC_COUNT };
 struct KStats {
     bool on = false; unsigned mask = 0xffffffffu;            // bit k set: kernel class k is timed
     std::vector<hipEvent_t> pool; std::vector<int> cls; size_t used = 0;

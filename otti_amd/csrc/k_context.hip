@@ -38,6 +38,11 @@ struct CtxLease {
     ~CtxLease() { if (c) { CtxPool &P = ctx_pool(); std::lock_guard<std::mutex> lk(P.mu); P.idle.push_back(c); } }
 };
 }  // namespace
+static void mail_alloc(DevCtx &c, void **p, size_t bytes) {
+    if (hipHostMalloc(p, bytes, hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess) return;
+    (void)hipGetLastError(); c.host_coherent = false;
+    OTTI_HIP(hipHostMalloc(p, bytes, hipHostMallocDefault));
+}
 DevCtx &DevCtx::get() {
     thread_local CtxLease lease;
     if (lease.c) return *lease.c;
@@ -72,15 +77,20 @@ DevCtx &DevCtx::get() {
     OTTI_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     c->partials.alloc((size_t)kMaxBlocks * 4);
     c->results.alloc(kResultSlots);
-    OTTI_HIP(hipHostMalloc((void **)&c->h_results, kResultSlots * sizeof(Fr), hipHostMallocDefault));
+    // Words a kernel spins on (h_go) or mails results and flags to (h_results, h_flag) must be fine-grained coherent host memory: asked
+    // for explicitly (HIP_HOST_COHERENT=0 in a caller's environment would otherwise make the default allocation non-coherent and an
+    // armed kernel would never see go()).  If the runtime refuses the flags, the default allocation is used and launches are never armed.
+    c->host_coherent = true;
+    auto host_alloc = [&](void **p, size_t bytes) { mail_alloc(*c, p, bytes); };
+    host_alloc((void **)&c->h_results, kResultSlots * sizeof(Fr));
     OTTI_HIP(hipHostGetDevicePointer((void **)&c->d_results_alias, c->h_results, 0));
-    OTTI_HIP(hipHostMalloc((void **)&c->h_flag, 64, hipHostMallocDefault));
+    host_alloc((void **)&c->h_flag, 64);
     *c->h_flag = 0;
     OTTI_HIP(hipHostGetDevicePointer((void **)&c->d_flag_alias, c->h_flag, 0));
     c->d_counter.alloc(1);
     OTTI_HIP(hipMemset(c->d_counter.p, 0, sizeof(unsigned)));
     c->d_counts.alloc(2);
-    OTTI_HIP(hipHostMalloc((void **)&c->h_go, sizeof(GoBox), hipHostMallocDefault));
+    host_alloc((void **)&c->h_go, sizeof(GoBox));
     memset(c->h_go, 0, sizeof(GoBox));
     OTTI_HIP(hipHostGetDevicePointer((void **)&c->d_go_alias, c->h_go, 0));
     c->d_go.alloc(1);
@@ -107,7 +117,7 @@ void DevCtx::ensure_points(size_t rows, size_t splits) {
         d_points.alloc(want_rows * 32); msm_final.alloc(want_rows); points_cap = want_rows;
     }
     if (!h_pts) {
-        OTTI_HIP(hipHostMalloc((void **)&h_pts, kHostPtsCap * sizeof(Pt), hipHostMallocDefault));
+        mail_alloc(*this, (void **)&h_pts, kHostPtsCap * sizeof(Pt));
         OTTI_HIP(hipHostGetDevicePointer((void **)&d_pts_alias, h_pts, 0));
         d_counter2.alloc(1); OTTI_HIP(hipMemset(d_counter2.p, 0, sizeof(unsigned)));
     }
@@ -142,22 +152,34 @@ static std::atomic<int> g_active_proofs{0};
 ActiveProof::ActiveProof() { g_active_proofs.fetch_add(1, std::memory_order_relaxed); }
 int ActiveProof::count() { return g_active_proofs.load(std::memory_order_relaxed); }
 ActiveProof::~ActiveProof() { g_active_proofs.fetch_sub(1, std::memory_order_relaxed); }
+// kernel classes that have armed launches: timing one of them with HIP events would time the host's part of the round too
+constexpr unsigned kArmedClasses = (1u << KC_MSM_SMALL) | (1u << KC_SC_CUBIC) | (1u << KC_SC_QUAD) | (1u << KC_PC_ROUND);
 bool DevCtx::armed_ok() const {
     static const bool env_on = [] { const char *e = getenv("OTTI_ARMED"); return !(e && e[0] == '0'); }();
-    return env_on && !KStats::get().on && g_active_proofs.load(std::memory_order_relaxed) <= 1;
+    const KStats &ks = KStats::get();
+    return env_on && host_coherent && !(ks.on && (ks.mask & kArmedClasses)) && g_active_proofs.load(std::memory_order_relaxed) <= 1;
 }
-Armed DevCtx::arm() { Armed a; a.host = d_go_alias; a.dev = d_go.p; a.want = ++go_issued; return a; }
+Armed DevCtx::arm() { Armed a; a.host = d_go_alias; a.dev = d_go.p; a.want = ++go_issued; a.deadline = arm_deadline; return a; }
 void DevCtx::go(const Fr *v, int n) {
     if (go_published >= go_issued) throw Error(OTTI_ERR_INTERNAL, "go() without an armed launch");
     for (int i = 0; i < n && i < 4; i++) h_go->v[i] = v[i];
     __atomic_store_n(&h_go->seq, ++go_published, __ATOMIC_RELEASE);
 }
 void DevCtx::go_abort() {
-    if (go_published >= go_issued) return;
+    if (go_published >= go_issued && !__atomic_load_n(&h_go->timed_out, __ATOMIC_ACQUIRE)) return;
     __atomic_store_n(&h_go->seq, ~0ull, __ATOMIC_RELEASE);
     (void)hipStreamSynchronize(stream);
     go_published = go_issued;
+    __atomic_store_n(&h_go->timed_out, 0ull, __ATOMIC_RELEASE);
     __atomic_store_n(&h_go->seq, go_published, __ATOMIC_RELEASE);
+    reset_arrival_counters();                                // the context goes back to the pool clean
+}
+// An armed grid that was released by an abort or a deadline returns before its arrival count is complete, and a launch that was cut
+// short for any other reason may have counted in part: the next launch on this context must not inherit that.  Stream idle.
+void DevCtx::reset_arrival_counters() {
+    (void)hipMemsetAsync(d_counter.p, 0, sizeof(unsigned), stream);
+    if (d_counter2.p) (void)hipMemsetAsync(d_counter2.p, 0, sizeof(unsigned), stream);
+    (void)hipStreamSynchronize(stream);
 }
 void DevCtx::wait_ticket(unsigned long long ticket) {
     volatile unsigned long long *f = h_flag;
@@ -167,8 +189,15 @@ void DevCtx::wait_ticket(unsigned long long ticket) {
 #if defined(__x86_64__)
         _mm_pause();
 #endif
+        if ((spins & 0x3ff) == 0x3ff && __atomic_load_n(&h_go->timed_out, __ATOMIC_ACQUIRE)) {
+            // an armed launch gave up waiting for this thread (it was stopped for longer than the launch's deadline): its grid returned
+            // without touching anything, the launches queued behind it are released the same way, and the proof fails cleanly
+            go_abort();
+            throw Error(OTTI_ERR_INTERNAL, "an armed launch gave up waiting for the host (the proving thread was stalled beyond the launch's deadline)");
+        }
         if ((spins & 0xffff) == 0xffff && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) {
-            OTTI_HIP(hipStreamSynchronize(stream));          // surfaces a device fault as an error instead of spinning forever
+            if (go_published < go_issued) go_abort();         // release whatever is still armed, drain, clear the arrival counters
+            else { OTTI_HIP(hipStreamSynchronize(stream)); if (*f >= ticket) return; reset_arrival_counters(); }   // surfaces a device fault as an error instead of spinning forever
             if (*f >= ticket) return;
             throw Error(OTTI_ERR_INTERNAL, "sum-check round result never arrived");
         }

@@ -20,7 +20,7 @@ __global__ __launch_bounds__(kBlock) void k_gather(const Fr *table, const uint32
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = table[idx[i]];
 }
 void dev_gather(DevCtx &c, const Fr *table, const uint32_t *idx, Fr *out, size_t n) {
-    KScope ks(c, KC_OTHER);
+    KScope ks(c, KC_GATHER);
     hipLaunchKernelGGL(k_gather, grid_for(n), kBlock, 0, c.stream, table, idx, out, n);
 }
 
@@ -52,11 +52,11 @@ __global__ __launch_bounds__(kBlock) void k_hash_ops(const Fr *addr_f, const Fr 
     }
 }
 void dev_hash_mem(DevCtx &c, const Fr *eval_table, const Fr *audit_ts, Fr *out_init, Fr *out_audit, size_t M, const Fr &r, const Fr &gamma) {
-    KScope ks(c, KC_OTHER);
+    KScope ks(c, KC_HASH_LAYER);
     hipLaunchKernelGGL(k_hash_mem, grid_for(M), kBlock, 0, c.stream, eval_table, audit_ts, out_init, out_audit, M, r, fr_mul(r, r), gamma);
 }
 void dev_hash_ops(DevCtx &c, const Fr *addr_f, const Fr *deref, const Fr *read_ts, Fr *out_read, Fr *out_write, size_t N, const Fr &r, const Fr &gamma) {
-    KScope ks(c, KC_OTHER);
+    KScope ks(c, KC_HASH_LAYER);
     hipLaunchKernelGGL(k_hash_ops, grid_for(N), kBlock, 0, c.stream, addr_f, deref, read_ts, out_read, out_write, N, r, fr_mul(r, r), gamma);
 }
 
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(kBlock) void k_prod_layer(LayerList L, size_t q) {
 }
 void dev_prod_layer(DevCtx &c, const LayerList &L, size_t q) {
     if (!q || !L.n) return;
-    KScope ks(c, KC_OTHER);
+    KScope ks(c, KC_PROD_LAYER);
     hipLaunchKernelGGL(k_prod_layer, dim3((unsigned)grid_for(q), (unsigned)L.n), kBlock, 0, c.stream, L, q);
 }
 
@@ -157,7 +157,7 @@ static Mailbox pc_mailbox(DevCtx &c, int slot, int nblocks) {
 }
 unsigned long long dev_pc_eval(DevCtx &c, const PcList &L, size_t len, const EqSrc &E, int slot) {
     const size_t half = len / 2; const int g = many_grid(half, L.n); Mailbox mb = pc_mailbox(c, slot, g * L.n);
-    KScope ks(c, KC_SC_CUBIC);
+    KScope ks(c, KC_PC_ROUND);
     hipLaunchKernelGGL(k_pc_round<false>, dim3((unsigned)g, (unsigned)L.n), kBlock, 0, c.stream, L, half, fr_zero(), E, mb, Armed{nullptr, nullptr, 0});
     return mb.seq;
 }
@@ -165,7 +165,7 @@ unsigned long long dev_pc_fold_eval(DevCtx &c, const PcList &L, size_t len, cons
     if (len < 4) throw Error(OTTI_ERR_INTERNAL, "fold_eval needs len >= 4");
     const size_t q = len / 4; const int g = many_grid(q, L.n); Mailbox mb = pc_mailbox(c, slot, g * L.n);
     const Armed go = r ? Armed{nullptr, nullptr, 0} : c.arm();
-    KScope ks(c, KC_SC_CUBIC);
+    KScope ks(c, KC_PC_ROUND);
     hipLaunchKernelGGL(k_pc_round<true>, dim3((unsigned)g, (unsigned)L.n), kBlock, 0, c.stream, L, q, r ? *r : fr_zero(), E, mb, go);
     return mb.seq;
 }
@@ -200,7 +200,7 @@ unsigned long long dev_pc_export(DevCtx &c, const PcList &L, size_t len, bool fo
     if (slot + (size_t)3 * L.n * n_out > (size_t)kResultSlots) throw Error(OTTI_ERR_INTERNAL, "sum-check tail does not fit the pinned result buffer");
     Mailbox mb = c.next_mailbox(slot);
     const Armed go = (fold && !r) ? c.arm() : Armed{nullptr, nullptr, 0};
-    KScope ks(c, KC_SC_CUBIC);
+    KScope ks(c, KC_PC_ROUND);
     hipLaunchKernelGGL(k_pc_export, dim3(1, (unsigned)L.n), 64, 0, c.stream, L, n_out, fold ? 1 : 0, r ? *r : fr_zero(), mb, go);
     return mb.seq;
 }
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(kBlock) void k_dot_many(const Fr *E, PtrList L, siz
 }
 void dev_dot_many(DevCtx &c, const Fr *E, const PtrList &L, size_t n, Fr *partials, int slot) {
     const int g = many_grid(n, L.n);
-    KScope ks(c, KC_OTHER);
+    KScope ks(c, KC_DOT_MANY);
     hipLaunchKernelGGL(k_dot_many, dim3((unsigned)g, (unsigned)L.n), kBlock, 0, c.stream, E, L, n, partials);
     hipLaunchKernelGGL(k_reduce_many<1>, L.n, kBlock, 0, c.stream, (const Fr *)partials, g, c.d_results_alias + slot);
 }
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(kBlock) void k_sum3(AbcList L, size_t n, Fr *partia
 }
 void dev_sum3(DevCtx &c, const AbcList &L, size_t n, Fr *partials, int slot) {
     const int g = many_grid(n, L.n);
-    KScope ks(c, KC_OTHER);
+    KScope ks(c, KC_DOT_MANY);
     hipLaunchKernelGGL(k_sum3, dim3((unsigned)g, (unsigned)L.n), kBlock, 0, c.stream, L, n, partials);
     hipLaunchKernelGGL(k_reduce_many<1>, L.n, kBlock, 0, c.stream, (const Fr *)partials, g, c.d_results_alias + slot);
 }

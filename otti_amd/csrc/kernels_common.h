@@ -50,15 +50,17 @@ __device__ __forceinline__ bool arrive_and_check_last(unsigned *counter, unsigne
 }
 
 // ------------------------------------------------------------------------------------------------ armed launches (device.h)
-// Every workgroup calls this first.  Workgroup (0,0) waits for the host's value in pinned memory and republishes it in HBM, the others
-// wait for that copy.  Returns false in every thread of the workgroup when the launch was aborted or a deadline passed: the kernel then
-// returns at once.
+// Every workgroup calls this first.  Workgroup (0,0) — and only it — waits for the host's value in pinned memory against the launch's
+// deadline and republishes its DECISION in HBM: the value, or abort (host said so / deadline passed).  The others wait for that
+// decision alone; their own backstop (16 x the deadline: the leader never ran) only exists so that a grid always drains.
+// Returns false in every thread of the workgroup when the launch was aborted or gave up: the kernel then returns at once, having
+// touched nothing.
 template <int N> __device__ __forceinline__ bool armed_fetch(const Armed &a, Fr (&v)[N]) {
     static_assert(N >= 1 && N <= 4, "a GoBox carries four values");
     __shared__ Fr s_v[N]; __shared__ int s_ok;
     if (threadIdx.x == 0) {
         const bool leader = (blockIdx.x | blockIdx.y | blockIdx.z) == 0;
-        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime(), abort_bit = 1ull << 63, deadline = 300000000ull;   // 100 MHz
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime(), abort_bit = 1ull << 63;   // 100 MHz
         int ok = -1;
         Fr t[N];
         for (int k = 0; k < N; k++) t[k] = fr_zero();
@@ -66,8 +68,11 @@ template <int N> __device__ __forceinline__ bool armed_fetch(const Armed &a, Fr 
             while (ok < 0) {
                 const unsigned long long s = __hip_atomic_load(&a.host->seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
                 if (s == a.want) ok = 1;
-                else if (s == ~0ull || __builtin_amdgcn_s_memrealtime() - t0 > deadline) ok = 0;
-                else __builtin_amdgcn_s_sleep(2);
+                else if (s == ~0ull) ok = 0;
+                else if (__builtin_amdgcn_s_memrealtime() - t0 > a.deadline) {
+                    ok = 0;
+                    __hip_atomic_store(&a.host->timed_out, a.want, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                } else __builtin_amdgcn_s_sleep(2);
             }
             if (ok) {
                 // the values sit in pinned (uncached) host memory: plain 16-byte loads, all issued before the first is waited for — one
@@ -84,10 +89,11 @@ template <int N> __device__ __forceinline__ bool armed_fetch(const Armed &a, Fr 
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __hip_atomic_store(&a.dev->seq, ok ? a.want : (a.want | abort_bit), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
+            const unsigned long long backstop = a.deadline << 4;
             while (ok < 0) {
                 const unsigned long long s = __hip_atomic_load(&a.dev->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (s == a.want) ok = 1;
-                else if (s == (a.want | abort_bit) || __builtin_amdgcn_s_memrealtime() - t0 > deadline) ok = 0;
+                else if (s == (a.want | abort_bit) || __builtin_amdgcn_s_memrealtime() - t0 > backstop) ok = 0;
                 else __builtin_amdgcn_s_sleep(1);
             }
             if (ok) for (int k = 0; k < N; k++) load_words_sc1(t[k].v, &a.dev->v[k], 8);

@@ -611,16 +611,28 @@ int nizk_verify(const Instance &I, const std::vector<Fr> &inputs, const Gens &g,
 }
 
 // ================================================================================================ synthetic R1CS
+// f(i) for i in [0, n) on the host's cores (every index independent: the result does not depend on the split); large instances only
+template <class F> static void host_par_for(size_t n, F &&f) {
+    unsigned nt = n < ((size_t)1 << 16) ? 1u : std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    std::vector<std::thread> th;
+    auto run = [&](unsigned t) { for (size_t i = n * t / nt, e = n * (t + 1) / nt; i < e; i++) f(i); };
+    unsigned started = 1;
+    for (; started < nt; started++) { try { th.emplace_back(run, started); } catch (const std::system_error &) { break; } }
+    run(0);
+    for (unsigned t = started; t < nt; t++) run(t);
+    for (auto &x : th) x.join();
+}
+
 void synth_r1cs(size_t n, size_t ni, uint64_t seed, std::vector<otti_entry> &A, std::vector<otti_entry> &B, std::vector<otti_entry> &C,
                 std::vector<uint8_t> &vars32, std::vector<uint8_t> &inputs32) {
     size_t size_z = n + ni + 1;
     std::vector<Fr> Z(size_z);
-    for (size_t k = 0; k < size_z; k++) {
+    host_par_for(size_z, [&](size_t k) {
         Shake256 xof; uint8_t le[16], w[64];
         for (int i = 0; i < 8; i++) { le[i] = (uint8_t)(seed >> (8 * i)); le[8 + i] = (uint8_t)((uint64_t)k >> (8 * i)); }
         xof.absorb("otti-synth", 10); xof.absorb(le, 16); xof.squeeze(w, 64);
         Z[k] = fr_from_bytes_wide(w);
-    }
+    });
     Z[n] = fr_one();
     A.resize(n); B.resize(n); C.resize(n);
     uint8_t one_bytes[32]; fr_to_bytes(one_bytes, fr_one());
@@ -631,7 +643,7 @@ void synth_r1cs(size_t n, size_t ni, uint64_t seed, std::vector<otti_entry> &A, 
     acc = fr_inv(acc);
     std::vector<Fr> inv(n);
     for (size_t i = n; i-- > 0;) { if (fr_is_zero(zc[i])) { inv[i] = fr_zero(); continue; } inv[i] = fr_mul(acc, pre[i]); acc = fr_mul(acc, zc[i]); }
-    for (size_t i = 0; i < n; i++) {
+    host_par_for(n, [&](size_t i) {
         size_t a = i % size_z, b = (i + 2) % size_z, c = (i + 3) % size_z;
         A[i].row = i; A[i].col = a; memcpy(A[i].val, one_bytes, 32);
         B[i].row = i; B[i].col = b; memcpy(B[i].val, one_bytes, 32);
@@ -639,9 +651,9 @@ void synth_r1cs(size_t n, size_t ni, uint64_t seed, std::vector<otti_entry> &A, 
         C[i].row = i;
         if (fr_is_zero(Z[c])) { C[i].col = n; fr_to_bytes(C[i].val, ab); }
         else { C[i].col = c; fr_to_bytes(C[i].val, fr_mul(ab, inv[i])); }
-    }
+    });
     vars32.resize(32 * n); inputs32.resize(32 * ni);
-    for (size_t k = 0; k < n; k++) fr_to_bytes(&vars32[32 * k], Z[k]);
+    host_par_for(n, [&](size_t k) { fr_to_bytes(&vars32[32 * k], Z[k]); });
     for (size_t k = 0; k < ni; k++) fr_to_bytes(&inputs32[32 * k], Z[n + 1 + k]);
 }
 

@@ -18,6 +18,8 @@
 #include <algorithm>
 #include <thread>
 #include <exception>
+#include <system_error>
+#include <new>
 #include <chrono>
 
 namespace otti {
@@ -92,9 +94,13 @@ struct FileView {
         n = (size_t)st.st_size;
         if (n) {
             // MAP_POPULATE: the parser's threads walk the file in parallel; one batched population of the mapping is several times
-            // cheaper than a minor fault per 4 KiB page taken by sixteen threads contending for the address-space lock
-            void *m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
+            // cheaper than a minor fault per 4 KiB page taken by sixteen threads contending for the address-space lock.  It blocks
+            // until the whole file is resident, though: above kPopulateMax the mapping is only advised (read-ahead) and paged in as
+            // the passes walk it.
+            constexpr size_t kPopulateMax = (size_t)2 << 30;
+            void *m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE | (n <= kPopulateMax ? MAP_POPULATE : 0), fd, 0);
             if (m == MAP_FAILED) { close(fd); throw Error(OTTI_ERR_IO, std::string("cannot map ") + path); }
+            if (n > kPopulateMax) (void)madvise(m, n, MADV_WILLNEED);
             p = (const uint8_t *)m;
         }
     }
@@ -240,9 +246,23 @@ static uint8_t *copy_bytes(const std::vector<uint8_t> &v) {
     return p;
 }
 
+// run f(0 .. nt) on nt threads (the caller's included).  A thread that cannot be started (EAGAIN under a pids cgroup or
+// RLIMIT_NPROC) must not unwind through joinable std::threads (std::terminate): the shares that found no thread run here instead.
+template <class F> static void fan_out(unsigned nt, F &&f) {
+    std::vector<std::thread> th; th.reserve(nt);
+    unsigned started = 1;
+    for (; started < nt; started++) {
+        try { th.emplace_back(f, started); } catch (const std::system_error &) { break; }
+    }
+    f(0u);
+    for (unsigned t = started; t < nt; t++) f(t);
+    for (auto &x : th) x.join();
+}
+
 otti_r1cs *otti_r1cs_from(size_t nc, size_t nv, size_t ni, const std::vector<otti_entry> &A, const std::vector<otti_entry> &B,
                           const std::vector<otti_entry> &C, const std::vector<uint8_t> &vars, const std::vector<uint8_t> &inputs) {
     otti_r1cs *r = (otti_r1cs *)calloc(1, sizeof *r);
+    if (!r) throw std::bad_alloc();
     r->num_cons = nc; r->num_vars = nv; r->num_inputs = ni;
     r->A = copy_entries(A); r->nA = A.size(); r->B = copy_entries(B); r->nB = B.size(); r->C = copy_entries(C); r->nC = C.size();
     r->vars32 = copy_bytes(vars); r->nvars = vars.size() / 32; r->inputs32 = copy_bytes(inputs); r->ninputs = inputs.size() / 32;
@@ -330,15 +350,11 @@ otti_r1cs *zkif_load_impl(const char *circuit_path, const char *inputs_path, con
             }
         } catch (...) { err[t] = std::current_exception(); }
     };
-    {
-        std::vector<std::thread> th;
-        for (unsigned t = 1; t < nt; t++) th.emplace_back(work, t);
-        work(0);
-        for (auto &x : th) x.join();
-        for (auto &e : err) if (e) std::rethrow_exception(e);
-    }
+    fan_out(nt, work);
+    for (auto &e : err) if (e) std::rethrow_exception(e);
     lap("constraints (threads)");
     otti_r1cs *out = (otti_r1cs *)calloc(1, sizeof *out);
+    if (!out) throw std::bad_alloc();
     struct Guard { otti_r1cs *r; ~Guard() { if (r) otti_r1cs_free(r); } } guard{out};
     otti_entry **dst[3] = {&out->A, &out->B, &out->C}; size_t *cnt[3] = {&out->nA, &out->nB, &out->nC};
     for (int k = 0; k < 3; k++) {                                         // the threads' parts go straight into the arrays the caller will own
@@ -347,11 +363,8 @@ otti_r1cs *zkif_load_impl(const char *circuit_path, const char *inputs_path, con
         if (!arr) throw std::bad_alloc();
         *dst[k] = arr; *cnt[k] = total;
         std::vector<size_t> at(nt); size_t o = 0; for (unsigned t = 0; t < nt; t++) { at[t] = o; o += part[k][t].size(); }
-        std::vector<std::thread> th;
         auto cp = [&, k, arr](unsigned t) { if (!part[k][t].empty()) memcpy(arr + at[t], part[k][t].data(), part[k][t].size() * sizeof(otti_entry)); std::vector<otti_entry>().swap(part[k][t]); };
-        for (unsigned t = 1; t < nt; t++) th.emplace_back(cp, t);
-        cp(0);
-        for (auto &x : th) x.join();
+        fan_out(nt, cp);
     }
     lap("concatenate");
     out->num_cons = row; out->num_vars = map.num_vars; out->num_inputs = map.num_inputs;

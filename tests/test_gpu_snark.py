@@ -88,3 +88,33 @@ def test_spzk_without_nizk_runs_snark_mode(tmp_path):
     og = orc.OSnarkGens(back["num_cons"], back["num_vars"], back["num_inputs"], nz)
     want, _ = orc.snark_prove(oi, orc.OSnarkComm.encode(oi, og), back["vars"], back["inputs"], og, LABEL, SEED)
     assert open(pre + ".proof", "rb").read() == want
+
+
+def _golden_snark():
+    import json, os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "snark_proofs.json")
+    return {e["n"]: e for e in json.load(open(path))}
+
+
+@pytest.mark.parametrize("lg", [12, 16, 18, 20])
+def test_snark_sweep_sizes_match_committed_oracle_digests(lg):
+    """The sizes SNARK mode is benchmarked and swept on (2^20 is the bench line's `snark` extra): the oracle's SNARK prover takes
+    minutes there, so commitment and proof are compared with the digests tests/golden/make_golden_snark.py committed."""
+    import hashlib
+    g = _golden_snark()[1 << lg]
+    r = oa.synth_r1cs(1 << lg, g["num_inputs"], g["instance_seed"])
+    assert hashlib.sha256(r["vars"].tobytes() + r["inputs"].tobytes()).hexdigest() == g["witness_sha256"]
+    assert hashlib.sha256(r["A"].tobytes() + r["B"].tobytes() + r["C"].tobytes()).hexdigest() == g["matrices_sha256"]
+    inst = oa.Instance.new(r["num_cons"], r["num_vars"], r["num_inputs"], r["A"], r["B"], r["C"])
+    gens = oa.SNARKGens.new(r["num_cons"], r["num_vars"], r["num_inputs"], g["num_nz_entries"])
+    comm = oa.ComputationCommitment.encode(inst, gens)
+    assert len(comm.bytes) == g["commitment_len"] and hashlib.sha256(comm.bytes).hexdigest() == g["commitment_sha256"], "computation commitment differs from the oracle's"
+    inputs = oa.InputsAssignment.new(r["inputs"])
+    label, seed = g["label"].encode(), bytes.fromhex(g["tape_seed"])
+    proof = oa.SNARK.prove(inst, comm, oa.VarsAssignment.new(r["vars"]), inputs, gens, label, seed)
+    assert len(proof.bytes) == g["proof_len"] and hashlib.sha256(proof.bytes).hexdigest() == g["proof_sha256"], "SNARK proof differs from the oracle's"
+    vc = oa.ComputationCommitment.from_bytes(comm.bytes)
+    proof.verify(vc, inputs, gens, label)
+    bad = bytearray(proof.bytes); bad[(2 * len(bad)) // 3] ^= 0x40
+    with pytest.raises(oa.ProofVerifyError):
+        oa.SNARK(bytes(bad)).verify(vc, inputs, gens, label)

@@ -228,3 +228,25 @@ def test_oracle_snark_commitment_binds_the_matrices():
     B2 = r["B"].copy(); B2["col"][5] = (B2["col"][5] + 1) % 32
     c2 = orc.OSnarkComm.encode(orc.OInstance(32, 32, 2, r["A"], B2, r["C"]), g).bytes
     assert c1 != c2 and len(c1) == len(c2)
+
+
+def test_oracle_reproduces_the_committed_snark_digests():
+    """tests/golden/snark_proofs.json (make_golden_snark.py) pins SNARK mode at the sizes the GPU is benchmarked on; the oracle must
+    still produce those bytes — checked here at the sizes it proves in seconds (2^12 with one thread, 2^16 with four)."""
+    import otti_amd as oa
+    golden = {e["n"]: e for e in json.load(open(os.path.join(os.path.dirname(__file__), "golden", "snark_proofs.json")))}
+    assert {1 << 12, 1 << 16, 1 << 18, 1 << 20} <= set(golden)
+    try:
+        for lg, threads in ((12, 1), (16, 4)):
+            g = golden[1 << lg]
+            orc.set_threads(threads)
+            r = oa.synth_r1cs(g["n"], g["num_inputs"], g["instance_seed"])
+            assert hashlib.sha256(r["vars"].tobytes() + r["inputs"].tobytes()).hexdigest() == g["witness_sha256"]
+            oi = orc.OInstance(r["num_cons"], r["num_vars"], r["num_inputs"], r["A"], r["B"], r["C"])
+            og = orc.OSnarkGens(r["num_cons"], r["num_vars"], r["num_inputs"], g["num_nz_entries"])
+            oc = orc.OSnarkComm.encode(oi, og)
+            assert hashlib.sha256(oc.bytes).hexdigest() == g["commitment_sha256"]
+            pf, _ = orc.snark_prove(oi, oc, r["vars"], r["inputs"], og, g["label"].encode(), bytes.fromhex(g["tape_seed"]))
+            assert len(pf) == g["proof_len"] and hashlib.sha256(pf).hexdigest() == g["proof_sha256"]
+    finally:
+        orc.set_threads(1)
