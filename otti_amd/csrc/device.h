@@ -81,6 +81,10 @@ struct DevCtx {
     bool host_coherent = false;                               // the words kernels spin on / mail to are fine-grained coherent host memory (else: no armed launches)
     void reset_arrival_counters();                            // after an aborted or timed-out launch: a grid may have left them non-zero (stream must be idle)
     hipEvent_t ev_order = nullptr;                            // orders a caller's stream (otti_kd_*) against this context's own
+    struct TailMail *h_tail = nullptr, *d_tail_alias = nullptr;   // per-workgroup mail lines of the persistent sum-check tail (snark_dev.h), pinned
+    void ensure_tail_mail();
+    void wait_tail(int n_groups, unsigned long long seq);     // spin until every line carries seq (same failure handling as wait_ticket)
+    Armed arm_many(int count);                                // reserves `count` consecutive go() numbers for one persistent launch; .want = the first
     bool armed_ok() const;                                    // off under OTTI_ARMED=0, while kernel classes are being timed (a waiting kernel's duration includes the host), and
                                                               // while another proof is in flight in this process (a waiting grid holds wave slots the other proof's kernels could use: measured -15 % throughput with six in flight)
     Armed arm();                                              // for the next launch; the k-th armed launch consumes the k-th go()

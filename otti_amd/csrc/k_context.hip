@@ -13,6 +13,7 @@
 //   k_poly_bound_*       K9 DensePolynomial::bound
 //   k_bullet_step        K10 nizk/bullet.rs BulletReductionProof::prove scalar bookkeeping
 #include "kernels_common.h"
+#include "snark_dev.h"
 #include <atomic>
 
 namespace otti {
@@ -160,6 +161,7 @@ bool DevCtx::armed_ok() const {
     return env_on && host_coherent && !(ks.on && (ks.mask & kArmedClasses)) && g_active_proofs.load(std::memory_order_relaxed) <= 1;
 }
 Armed DevCtx::arm() { Armed a; a.host = d_go_alias; a.dev = d_go.p; a.want = ++go_issued; a.deadline = arm_deadline; return a; }
+Armed DevCtx::arm_many(int count) { Armed a; a.host = d_go_alias; a.dev = d_go.p; a.want = go_issued + 1; a.deadline = arm_deadline; go_issued += (unsigned long long)count; return a; }
 void DevCtx::go(const Fr *v, int n) {
     if (go_published >= go_issued) throw Error(OTTI_ERR_INTERNAL, "go() without an armed launch");
     for (int i = 0; i < n && i < 4; i++) h_go->v[i] = v[i];
@@ -200,6 +202,31 @@ void DevCtx::wait_ticket(unsigned long long ticket) {
             else { OTTI_HIP(hipStreamSynchronize(stream)); if (*f >= ticket) return; reset_arrival_counters(); }   // surfaces a device fault as an error instead of spinning forever
             if (*f >= ticket) return;
             throw Error(OTTI_ERR_INTERNAL, "sum-check round result never arrived");
+        }
+    }
+}
+void DevCtx::ensure_tail_mail() {
+    if (h_tail) return;
+    mail_alloc(*this, (void **)&h_tail, (size_t)kTailMaxGroups * sizeof(TailMail));
+    memset(h_tail, 0, (size_t)kTailMaxGroups * sizeof(TailMail));
+    OTTI_HIP(hipHostGetDevicePointer((void **)&d_tail_alias, h_tail, 0));
+}
+void DevCtx::wait_tail(int n_groups, unsigned long long want) {
+    const auto t0 = std::chrono::steady_clock::now();
+    int done = 0;                                             // lines [0, done) have arrived
+    for (unsigned spins = 0;; spins++) {
+        while (done < n_groups && __atomic_load_n(&h_tail[done].seq, __ATOMIC_ACQUIRE) >= want) done++;
+        if (done == n_groups) return;
+#if defined(__x86_64__)
+        _mm_pause();
+#endif
+        if ((spins & 0x3ff) == 0x3ff && __atomic_load_n(&h_go->timed_out, __ATOMIC_ACQUIRE)) {
+            go_abort();
+            throw Error(OTTI_ERR_INTERNAL, "the persistent sum-check launch gave up waiting for the host (the proving thread was stalled beyond the launch's deadline)");
+        }
+        if ((spins & 0xffff) == 0xffff && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) {
+            if (go_published < go_issued) go_abort(); else { (void)hipStreamSynchronize(stream); reset_arrival_counters(); }
+            throw Error(OTTI_ERR_INTERNAL, "sum-check round result never arrived (persistent launch)");
         }
     }
 }

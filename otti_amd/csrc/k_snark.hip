@@ -204,6 +204,111 @@ unsigned long long dev_pc_export(DevCtx &c, const PcList &L, size_t len, bool fo
     hipLaunchKernelGGL(k_pc_export, dim3(1, (unsigned)L.n), 64, 0, c.stream, L, n_out, fold ? 1 : 0, r ? *r : fr_zero(), mb, go);
     return mb.seq;
 }
+// ------------------------------------------------------------------------------------------------ the persistent tail (snark_dev.h)
+struct TailArgs {
+    PcList L; int W; uint32_t len0, t_out; int fold_on_load; Fr r; EqSrc E;
+    TailMail *mail; Fr *host_out; unsigned long long seq0; Armed go;        // go.want: the go() number of the first round's challenge
+};
+// sums acc[0..3) over the waves [0, active_waves) of the workgroup into s_tot[0..3) (LDS); every thread of the workgroup calls it
+__device__ __forceinline__ void tail_reduce3(Fr (&acc)[3], int active_waves, Fr (*s_part)[16], Fr *s_tot) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (wave < active_waves) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1)
+#pragma unroll
+            for (int k = 0; k < 3; k++) acc[k] = fr_add(acc[k], shfl_xor_fr(acc[k], off));
+        if (lane == 0) for (int k = 0; k < 3; k++) s_part[k][wave] = acc[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) { Fr t = s_part[threadIdx.x][0]; for (int w = 1; w < active_waves; w++) t = fr_add(t, s_part[threadIdx.x][w]); s_tot[threadIdx.x] = t; }
+    __syncthreads();
+}
+__device__ __forceinline__ void tail_post(TailMail *m, const Fr *s_tot, bool with_sums, unsigned long long seq) {
+    if (threadIdx.x == 0) {
+        if (with_sums) for (int k = 0; k < 3; k++) m->s[k] = s_tot[k];
+        __threadfence_system();
+        __hip_atomic_store(&m->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+__global__ __launch_bounds__(kTailThreads) void k_pc_tail(TailArgs a) {
+    __shared__ Fr T0[3 * kTailCap];                                    // three tables of kTailCap elements: A, B, C (96 KB of the CU's 160: one workgroup per CU)
+    __shared__ Fr s_part[3][16]; __shared__ Fr s_tot[3];
+    const int w = blockIdx.x, y = blockIdx.y, W = a.W, tid = threadIdx.x, nthr = blockDim.x;
+    const Fr *src[3] = {a.L.A[y], a.L.B[y], a.L.C[y]};
+    TailMail *const mail = a.mail + (size_t)y * W + w;
+    uint32_t L = a.len0 / (uint32_t)W;                                  // this workgroup's share of every table
+    // ---- load (folding by the previous round's challenge when the tables in HBM are one round behind); element j here is element j W + w there
+    for (uint32_t idx = tid; idx < 3 * L; idx += nthr) {
+        const uint32_t t = idx / L, j = idx - t * L; const size_t i = (size_t)j * W + w;
+        Fr v;
+        if (!src[t]) v = eq_at(a.E, i);                                 // product circuit: the shared eq table, materialised (t == 2 only)
+        else if (a.fold_on_load) { const Fr lo = src[t][i], hi = src[t][i + a.len0]; v = fr_add(lo, fr_mul(a.r, fr_sub(hi, lo))); }
+        else v = src[t][i];
+        T0[t * kTailCap + j] = v;
+    }
+    __syncthreads();
+    unsigned long long seq = a.seq0, want = a.go.want;
+    const uint32_t L_out = a.t_out / (uint32_t)W;
+    const int pt = tid % 3, q0 = tid / 3, qn = nthr / 3;                // thread -> evaluation point (0, 2, 3) and first pair; the last thread of 1024 idles
+    while (L > L_out) {
+        const uint32_t half = L / 2;
+        // ---- this round's sums: S_t = sum over pairs of (A_t B_t C_t), t in {0, 2, 3}
+        Fr acc = fr_zero();
+        if (tid < 3 * qn)
+            for (uint32_t p = q0; p < half; p += qn) {
+                Fr x[3];
+#pragma unroll
+                for (int t = 0; t < 3; t++) {
+                    const Fr lo = T0[t * kTailCap + p], hi = T0[t * kTailCap + p + half];
+                    if (pt == 0) x[t] = lo;
+                    else { const Fr d = fr_sub(hi, lo); Fr e = fr_add(hi, d); if (pt == 2) e = fr_add(e, d); x[t] = e; }   // 2 hi - lo, 3 hi - 2 lo
+                }
+                acc = fr_add(acc, fr_mul(fr_mul(x[0], x[1]), x[2]));
+            }
+        Fr acc3[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) acc3[k] = (k == pt && tid < 3 * qn) ? acc : fr_zero();
+        const uint32_t busy = min((uint32_t)(3 * qn), 3 * half);        // threads [0, busy) had a pair
+        tail_reduce3(acc3, (int)((busy + 63) / 64), s_part, s_tot);
+        tail_post(mail, s_tot, true, seq++);
+        // ---- the round's challenge, then bound_poly_var_top of the three tables in LDS
+        Fr rv[1]; Armed g = a.go; g.want = want++;
+        if (!armed_fetch<1>(g, rv)) return;
+        for (uint32_t idx = tid; idx < 3 * half; idx += nthr) {
+            const uint32_t t = idx / half, e = idx - t * half;
+            Fr *X = T0 + t * kTailCap;
+            const Fr lo = X[e];
+            X[e] = fr_add(lo, fr_mul(rv[0], fr_sub(X[e + half], lo)));
+        }
+        __syncthreads();
+        L = half;
+    }
+    // ---- hand the host-played tail over: table t of instance y at host_out[(3 y + t) * t_out ..), element j of this workgroup at j W + w
+    for (uint32_t idx = tid; idx < 3 * L; idx += nthr) {
+        const uint32_t t = idx / L, j = idx - t * L;
+        if (!src[t]) continue;
+        a.host_out[((size_t)3 * y + t) * a.t_out + (size_t)j * W + w] = T0[t * kTailCap + j];
+    }
+    __threadfence_system();
+    __syncthreads();
+    tail_post(mail, s_tot, false, seq);
+}
+unsigned long long dev_pc_tail(DevCtx &c, const PcList &L, int W, size_t len0, size_t t_out, const Fr *fold_r, const EqSrc &E, int slot) {
+    int rounds = 0; for (size_t l = len0; l > t_out; l >>= 1) rounds++;
+    if (W < 1 || (W & (W - 1)) || L.n < 1 || L.n * W > kTailMaxGroups || len0 / (size_t)W > (size_t)kTailCap || (len0 & (len0 - 1)) || (t_out & (t_out - 1)) ||
+        t_out < (size_t)W || len0 <= t_out || rounds < 1)
+        throw Error(OTTI_ERR_INTERNAL, "persistent sum-check tail: bad geometry");
+    if (slot + (size_t)3 * L.n * t_out > (size_t)kResultSlots) throw Error(OTTI_ERR_INTERNAL, "sum-check tail does not fit the pinned result buffer");
+    c.ensure_tail_mail();
+    TailArgs a;
+    a.L = L; a.W = W; a.len0 = (uint32_t)len0; a.t_out = (uint32_t)t_out; a.fold_on_load = fold_r ? 1 : 0; a.r = fold_r ? *fold_r : fr_zero(); a.E = E;
+    a.mail = c.d_tail_alias; a.host_out = c.d_results_alias + slot;
+    a.seq0 = c.seq + 1; c.seq += (unsigned long long)rounds + 1;
+    a.go = c.arm_many(rounds);
+    KScope ks(c, KC_PC_ROUND);
+    hipLaunchKernelGGL(k_pc_tail, dim3((unsigned)W, (unsigned)L.n), kTailThreads, 0, c.stream, a);
+    return a.seq0;
+}
 // element 0 of every table of the list -> c.h_results[slot ..)
 __global__ void k_pick0(PtrList L, Fr *out) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < L.n) out[i] = L.p[i][0]; }
 void dev_pick0(DevCtx &c, const PtrList &L, int slot) { if (L.n) hipLaunchKernelGGL(k_pick0, 1, 64, 0, c.stream, L, c.d_results_alias + slot); }

@@ -20,6 +20,22 @@ unsigned long long dev_pc_fold_eval(DevCtx &c, const PcList &L, size_t len, cons
 // the tables (folded by r first when fold is set) go to pinned host memory: table t of instance y at c.h_results[slot + (3 y + t) * len_out ..)
 unsigned long long dev_pc_export(DevCtx &c, const PcList &L, size_t len, bool fold, const Fr *r, int slot);
 
+// ---- the persistent tail of a layer's batched sum-check (k_pc_tail): ONE launch plays every round from the point where the tables of
+// an instance fit the LDS of W workgroups (kTailCap elements per table and workgroup) down to the host-played tail.  Workgroup (w, y)
+// holds the elements i = w (mod W) of instance y's tables (bound_poly_var_top pairs i with i + len/2: always in the same residue
+// class) in LDS for the whole launch; per round it mails its three partial sums to its own TailMail line in pinned host memory, waits
+// for the challenge (an armed fetch per round: consecutive go() numbers), folds in LDS.  The eq table of a product-circuit instance
+// is materialised in LDS here (a real third table, folded like the others; the host multiplies by the factor accumulated before).
+// No launch, no HBM round trip, no inter-workgroup hand-off per round: a round costs the host's hash plus ~3 us of arithmetic.
+constexpr int kTailCap = 1024, kTailThreads = 1024, kTailMaxGroups = 160;
+struct TailMail { Fr s[3]; unsigned long long seq, pad[3]; };        // 128 bytes per workgroup
+struct TailPlan { int W = 0; size_t k0 = 0; };                         // workgroups per instance; first round played by the tail (== ndev: no tail)
+// rounds played = log2(len0 / t_out) (>= 1).  Round j's partial sums of workgroup (w, y) arrive in c.h_tail[y * W + w] with seq = first_seq + j;
+// after the last fold the tables (t_out elements each) go to c.h_results[slot + (3 y + t) * t_out ..) and every workgroup posts first_seq + rounds.
+// fold_r: the source tables hold 2 * len0 elements and are folded by *fold_r on load (nullptr: they hold len0 elements as they are).
+// Consumes `rounds` go() values.  Returns first_seq.
+unsigned long long dev_pc_tail(DevCtx &c, const PcList &L, int W, size_t len0, size_t t_out, const Fr *fold_r, const EqSrc &E, int slot);
+
 void dev_gather(DevCtx &c, const Fr *table, const uint32_t *idx, Fr *out, size_t n);
 void dev_u32_to_fr(DevCtx &c, const uint32_t *in, Fr *out, size_t n);        // out[i] = in[i] as a field element (Montgomery form)
 void dev_hash_mem(DevCtx &c, const Fr *eval_table, const Fr *audit_ts, Fr *out_init, Fr *out_audit, size_t M, const Fr &r, const Fr &gamma);

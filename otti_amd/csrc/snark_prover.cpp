@@ -169,6 +169,12 @@ ProductCircuitEvalProofBatched pcbatch_prove(DevCtx &c, Circuits &C, const std::
     std::vector<Fr> claims = evals, rand, rprod;
     const Fr one = fr_one();
     struct Release { DevCtx &c; ~Release() { c.go_abort(); } } release{c};      // an exception below must not leave an armed kernel waiting
+    const bool arm_ok = c.armed_ok();
+    // OTTI_PC_TAIL=0 switches the persistent tail off; OTTI_PC_TAIL_CAP shrinks its per-workgroup capacity (tests: small instances then
+    // also take the route where the tail picks up tables that earlier launches folded in HBM)
+    static const bool tail_env = [] { const char *e = getenv("OTTI_PC_TAIL"); return !(e && e[0] == '0'); }();
+    static const size_t tail_cap = [] { const char *e = getenv("OTTI_PC_TAIL_CAP"); size_t v = e ? (size_t)atoi(e) : 0; return (v >= 2 && v <= (size_t)kTailCap && !(v & (v - 1))) ? v : (size_t)kTailCap; }();
+    const bool tail_ok = arm_ok && tail_env;
     for (size_t li = 0; li < nl; li++) {
         const size_t layer_id = nl - 1 - li, nr = rand.size(), h = (size_t)1 << nr;      // elements per side in this layer, one round per variable
         const bool with_dotp = layer_id == 0 && D && D->n;
@@ -178,6 +184,20 @@ ProductCircuitEvalProofBatched pcbatch_prove(DevCtx &c, Circuits &C, const std::
         if (with_dotp) for (int i = 0; i < D->n; i++) { P.A[P.n] = D->l[i]; P.B[P.n] = D->r[i]; P.C[P.n] = D->w[i]; P.n++; }
         const int ni = P.n;
         const size_t lgT = std::min<size_t>(nr, ni >= 8 ? 4 : 5), T = (size_t)1 << lgT, ndev = nr - lgT;
+        // The persistent tail (k_pc_tail, snark_dev.h): from round k0 on — the first round whose tables fit the LDS of W workgroups per
+        // instance — ONE launch plays every remaining device round.  Only while this is the process's single proof in flight (its grid
+        // must be resident as a whole: the workgroups wait for the host, the host for all of them) and no kernel class it belongs to is
+        // being timed; otherwise, and for the rounds before k0, a launch per round as before.
+        size_t k0 = ndev; int tailW = 1;
+        if (ndev && tail_ok) {
+            int Wmax = 1; while (2 * Wmax * ni <= kTailMaxGroups && (size_t)(2 * Wmax) <= T) Wmax *= 2;
+            const size_t cap_all = tail_cap * (size_t)Wmax;
+            k0 = 0; while ((h >> k0) > cap_all) k0++;
+            if (k0 >= ndev) k0 = ndev;                           // (cannot happen for cap_all >= 2 T; kept for a shrunken test capacity)
+            else { const size_t len0 = h >> k0; tailW = 1; while (tailW < Wmax && len0 / (size_t)tailW > 128) tailW *= 2; while (len0 / (size_t)tailW > tail_cap) tailW *= 2; }
+        }
+        const bool tail = k0 < ndev;
+        unsigned long long tail_seq = 0;
         // eq(rand, .) on the device: pyramids over the last n_lo variables and the n_hi before them
         const size_t n_lo = std::min<size_t>(nr, 12), n_hi = nr - n_lo;
         if (n_hi > 13) throw Error(OTTI_ERR_BAD_ARG, "product circuit over more than 2^25 elements");
@@ -191,25 +211,41 @@ ProductCircuitEvalProofBatched pcbatch_prove(DevCtx &c, Circuits &C, const std::
         };
         // launch k >= 1 folds by r_{k-1} and yields the sums of round k (k < ndev) or the exported tail (k == ndev).  Armed (device.h), it is
         // queued one round ahead and starts the moment the host publishes r_{k-1}.
-        const bool arm_ok = c.armed_ok();
-        auto armed = [&](size_t k) { return arm_ok && k >= 1 && k <= ndev && (h >> (k - 1)) * (size_t)ni <= kArmMaxLen; };   // small grids only (device.h)
+        auto armed = [&](size_t k) { return arm_ok && k >= 1 && k < k0 + (tail ? 0 : 1) && k <= ndev && (h >> (k - 1)) * (size_t)ni <= kArmMaxLen; };   // small grids only (device.h); never the tail's own launch
         std::vector<unsigned long long> tick(ndev + 2, 0);
+        auto launch_tail = [&](const Fr *r) { tail_seq = dev_pc_tail(c, P, tailW, h >> k0, T, r, eq_src(nr - k0), kPcTailSlot); };
         auto launch_for = [&](size_t k, const Fr *r) {
             const size_t len_in = h >> (k - 1);
+            if (tail && k == k0) { launch_tail(r); return; }
             tick[k] = k < ndev ? dev_pc_fold_eval(c, P, len_in, r, eq_src(nr - k - 1), kSumSlot) : dev_pc_export(c, P, len_in, true, r, kPcTailSlot);
         };
-        if (ndev) { tick[0] = dev_pc_eval(c, P, h, eq_src(nr - 1), kSumSlot); if (armed(1)) launch_for(1, nullptr); }
+        if (tail && k0 == 0) launch_tail(nullptr);
+        else if (ndev) { tick[0] = dev_pc_eval(c, P, h, eq_src(nr - 1), kSumSlot); if (armed(1)) launch_for(1, nullptr); }
         else tick[0] = dev_pc_export(c, P, h, false, nullptr, kPcTailSlot);
         std::vector<Fr> coeff = tr.challenge_vector("rand_coeffs_next_layer", claims.size());
         Fr e = fr_zero(); for (size_t k = 0; k < claims.size(); k++) e = fr_add(e, fr_mul(claims[k], coeff[k]));
         LayerProofBatched &L = pf.layers[li];
         rprod.clear();
         std::vector<std::vector<Fr>> tA(ni), tB(ni), tC(ni); std::vector<Fr> tE; bool tail_built = false;   // host tail: T elements per table
-        Fr cj = one;
+        Fr cj = one, cj_tail = one;                         // cj_tail: the eq factor accumulated before the tail took over (its eq table carries the rest)
         size_t len = h;
         for (size_t j = 0; j < nr; j++) {                    // SumcheckInstanceProof::prove_cubic_batched
             Fr c0 = fr_zero(), c2 = fr_zero(), c3 = fr_zero();
-            if (j < ndev) {
+            if (j < ndev && tail && j >= k0) {
+                // a round of the persistent launch: W partial sums per instance, in the workgroups' own mail lines; the eq table is a real
+                // third table there, so the sums already carry the bound variable's factor — only the factor of the rounds before k0 is missing
+                if (j == k0) cj_tail = cj;
+                c.wait_tail(ni * tailW, tail_seq + (j - k0));
+                Fr p0 = fr_zero(), p2 = fr_zero(), p3 = fr_zero();
+                for (int k = 0; k < ni; k++) {
+                    const TailMail *m = c.h_tail + (size_t)k * tailW;
+                    Fr s0 = m[0].s[0], s2 = m[0].s[1], s3 = m[0].s[2];
+                    for (int w = 1; w < tailW; w++) { s0 = fr_add(s0, m[w].s[0]); s2 = fr_add(s2, m[w].s[1]); s3 = fr_add(s3, m[w].s[2]); }
+                    Fr &a0 = k < np ? p0 : c0, &a2 = k < np ? p2 : c2, &a3 = k < np ? p3 : c3;
+                    a0 = fr_add(a0, fr_mul(s0, coeff[k])); a2 = fr_add(a2, fr_mul(s2, coeff[k])); a3 = fr_add(a3, fr_mul(s3, coeff[k]));
+                }
+                c0 = fr_add(c0, fr_mul(cj_tail, p0)); c2 = fr_add(c2, fr_mul(cj_tail, p2)); c3 = fr_add(c3, fr_mul(cj_tail, p3));
+            } else if (j < ndev) {
                 c.wait_ticket(tick[j]);
                 const Fr &tau = rand[j];
                 const Fr w0 = fr_sub(one, tau), dw = fr_sub(fr_add(tau, tau), one), w2 = fr_add(w0, fr_add(dw, dw)), w3 = fr_add(w2, dw);
@@ -223,7 +259,7 @@ ProductCircuitEvalProofBatched pcbatch_prove(DevCtx &c, Circuits &C, const std::
                 c0 = fr_add(c0, fr_mul(f0, p0)); c2 = fr_add(c2, fr_mul(f2, p2)); c3 = fr_add(c3, fr_mul(f3, p3));
             } else {
                 if (!tail_built) {
-                    c.wait_ticket(tick[ndev]);
+                    if (tail) c.wait_tail(ni * tailW, tail_seq + (ndev - k0)); else c.wait_ticket(tick[ndev]);
                     for (int k = 0; k < ni; k++) {
                         const Fr *base = &c.h_results[kPcTailSlot + (size_t)3 * k * T];
                         tA[k].assign(base, base + T); tB[k].assign(base + T, base + 2 * T);
@@ -254,8 +290,11 @@ ProductCircuitEvalProofBatched pcbatch_prove(DevCtx &c, Circuits &C, const std::
             const Fr r_j = tr.challenge_scalar("challenge_nextround");
             rprod.push_back(r_j);
             if (j < ndev) {
-                if (armed(j + 1)) c.go(&r_j, 1); else launch_for(j + 1, &r_j);
-                if (armed(j + 2)) launch_for(j + 2, nullptr);
+                if (tail && j >= k0) c.go(&r_j, 1);              // the persistent launch folds and goes on (or exports, after its last round)
+                else {
+                    if (armed(j + 1)) c.go(&r_j, 1); else launch_for(j + 1, &r_j);
+                    if (armed(j + 2)) launch_for(j + 2, nullptr);
+                }
             }
             if (j < ndev) cj = fr_mul(cj, fr_add(fr_mul(rand[j], r_j), fr_mul(fr_sub(one, rand[j]), fr_sub(one, r_j))));
             else {

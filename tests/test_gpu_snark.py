@@ -118,3 +118,18 @@ def test_snark_sweep_sizes_match_committed_oracle_digests(lg):
     bad = bytearray(proof.bytes); bad[(2 * len(bad)) // 3] ^= 0x40
     with pytest.raises(oa.ProofVerifyError):
         oa.SNARK(bytes(bad)).verify(vc, inputs, gens, label)
+
+
+@pytest.mark.parametrize("env", [{"OTTI_PC_TAIL": "0"}, {"OTTI_PC_TAIL_CAP": "16"}, {"OTTI_PC_TAIL_CAP": "128"}, {"OTTI_ARMED": "0"}, {}])
+def test_persistent_tail_variants_give_the_oracles_proof(env):
+    """The layered sum-checks of R1CSEvalProof three ways — a launch per round (tail off / nothing armed), the persistent tail with
+    its full LDS capacity (small instances: whole layers in one launch), and with a shrunken capacity (the tail then takes over tables
+    that earlier launches folded in HBM, as it does at 2^16 and beyond) — must all produce the oracle's bytes (committed digest, 2^12)."""
+    import os, subprocess, sys
+    g = _golden_snark()[1 << 12]
+    e = dict(os.environ); e.update(env)
+    res = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "snark_tail_worker.py"), "12"], env=e,
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout + res.stderr
+    line = [ln for ln in res.stdout.splitlines() if ln.startswith("DIGEST")][-1].split()
+    assert line[1] == g["commitment_sha256"] and line[2] == g["proof_sha256"], (env, res.stderr)
