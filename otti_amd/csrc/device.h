@@ -4,6 +4,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <vector>
+#include <cstddef>
 #include "spartan.h"
 
 namespace otti {
@@ -59,7 +60,23 @@ struct Mailbox { Fr *partials; unsigned *counter; Fr *host_results; unsigned lon
 // value arrived / aborted / gave up) is what every other workgroup acts on (they watch dev->seq alone, with a backstop far beyond
 // the leader's deadline) — a grid never folds in part.  A leader that gives up says so in host->timed_out, so the host fails the
 // proof at once instead of waiting for a result that will not come.
-struct GoBox { unsigned long long seq, timed_out, pad[2]; Fr v[4]; };
+// Layout: the sequence number, a tag and the first value share one 64-byte line, so a poll that finds the number it waits for has the
+// value in the same batch of loads (one PCIe round trip, not two).  The tag = go_tag(seq, values) makes a batch self-validating: the
+// loads of one poll may be served at different times, and a batch that mixes old and new words fails the tag and is simply polled
+// again.  timed_out (written by the DEVICE) sits in a line of its own.
+struct alignas(64) GoBox { unsigned long long seq, tag, pad[2]; Fr v[4]; unsigned long long timed_out, pad2[3]; };
+static_assert(sizeof(GoBox) == 192 && offsetof(GoBox, v) == 32 && offsetof(GoBox, timed_out) == 160, "GoBox layout is read by hand-written loads");
+// the same function on both sides of the bus: every 64-bit word of the n values, rotated by its position, folded into the sequence number
+HD unsigned long long go_tag(unsigned long long seq, const Fr *v, int n) {
+    unsigned long long h = seq * 0x9e3779b97f4a7c15ull;
+    for (int k = 0; k < n; k++)
+        for (int j = 0; j < 4; j++) {
+            const unsigned long long w = (unsigned long long)v[k].v[2 * j] | ((unsigned long long)v[k].v[2 * j + 1] << 32);
+            const int rot = ((4 * k + j) * 5 + 1) & 63;
+            h ^= (w << rot) | (w >> ((64 - rot) & 63));
+        }
+    return h;
+}
 struct Armed { GoBox *host; GoBox *dev; unsigned long long want, deadline; };   // want == 0: not armed (values come as kernel arguments); deadline in 100 MHz ticks
 constexpr unsigned long long kArmDeadlineTicks = 3000000000ull;   // 30 s of s_memrealtime: longer than any host stall the prover's own 20 s result wait tolerates
 constexpr size_t kArmMaxLen = 65536;                         // sum-check tables up to this length fold in <= 64 workgroups: only those launches are armed

@@ -164,7 +164,9 @@ Armed DevCtx::arm() { Armed a; a.host = d_go_alias; a.dev = d_go.p; a.want = ++g
 Armed DevCtx::arm_many(int count) { Armed a; a.host = d_go_alias; a.dev = d_go.p; a.want = go_issued + 1; a.deadline = arm_deadline; go_issued += (unsigned long long)count; return a; }
 void DevCtx::go(const Fr *v, int n) {
     if (go_published >= go_issued) throw Error(OTTI_ERR_INTERNAL, "go() without an armed launch");
-    for (int i = 0; i < n && i < 4; i++) h_go->v[i] = v[i];
+    if (n > 4) n = 4;
+    for (int i = 0; i < n; i++) h_go->v[i] = v[i];
+    h_go->tag = go_tag(go_published + 1, v, n);
     __atomic_store_n(&h_go->seq, ++go_published, __ATOMIC_RELEASE);
 }
 void DevCtx::go_abort() {

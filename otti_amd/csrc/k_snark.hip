@@ -208,13 +208,15 @@ unsigned long long dev_pc_export(DevCtx &c, const PcList &L, size_t len, bool fo
 struct TailArgs {
     PcList L; int W; uint32_t len0, t_out; int fold_on_load; Fr r; EqSrc E;
     TailMail *mail; Fr *host_out; unsigned long long seq0; Armed go;        // go.want: the go() number of the first round's challenge
+    unsigned long long *stamps;                                             // OTTI_TAIL_STAMPS: wall_clock64 (100 MHz) of workgroup (0,0) at the phase boundaries, 8 per round
 };
 // sums acc[0..3) over the waves [0, active_waves) of the workgroup into s_tot[0..3) (LDS); every thread of the workgroup calls it
-__device__ __forceinline__ void tail_reduce3(Fr (&acc)[3], int active_waves, Fr (*s_part)[16], Fr *s_tot) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+__device__ __forceinline__ void tail_reduce3(Fr (&acc)[3], uint32_t busy, Fr (*s_part)[16], Fr *s_tot) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, active_waves = (int)((busy + 63) / 64);
     if (wave < active_waves) {
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1)
+        int top = 64; if (busy < 64) { top = 1; while ((uint32_t)top < busy) top <<= 1; }      // lanes at and beyond `busy` hold zero: only as many levels as there is data
+#pragma unroll 1
+        for (int off = top >> 1; off >= 1; off >>= 1)
 #pragma unroll
             for (int k = 0; k < 3; k++) acc[k] = fr_add(acc[k], shfl_xor_fr(acc[k], off));
         if (lane == 0) for (int k = 0; k < 3; k++) s_part[k][wave] = acc[k];
@@ -249,6 +251,8 @@ __global__ __launch_bounds__(kTailThreads) void k_pc_tail(TailArgs a) {
     __syncthreads();
     unsigned long long seq = a.seq0, want = a.go.want;
     const uint32_t L_out = a.t_out / (uint32_t)W;
+    unsigned long long *stamp = (a.stamps && tid == 0 && w == 0 && y == 0) ? a.stamps : nullptr; int rnd = 0;
+    if (stamp) stamp[0] = wall_clock64();
     const int pt = tid % 3, q0 = tid / 3, qn = nthr / 3;                // thread -> evaluation point (0, 2, 3) and first pair; the last thread of 1024 idles
     while (L > L_out) {
         const uint32_t half = L / 2;
@@ -269,11 +273,15 @@ __global__ __launch_bounds__(kTailThreads) void k_pc_tail(TailArgs a) {
 #pragma unroll
         for (int k = 0; k < 3; k++) acc3[k] = (k == pt && tid < 3 * qn) ? acc : fr_zero();
         const uint32_t busy = min((uint32_t)(3 * qn), 3 * half);        // threads [0, busy) had a pair
-        tail_reduce3(acc3, (int)((busy + 63) / 64), s_part, s_tot);
+        if (stamp) stamp[8 * rnd + 1] = wall_clock64();               // sums done
+        tail_reduce3(acc3, busy, s_part, s_tot);
+        if (stamp) stamp[8 * rnd + 2] = wall_clock64();               // reduced
         tail_post(mail, s_tot, true, seq++);
+        if (stamp) stamp[8 * rnd + 3] = wall_clock64();               // mailed
         // ---- the round's challenge, then bound_poly_var_top of the three tables in LDS
         Fr rv[1]; Armed g = a.go; g.want = want++;
         if (!armed_fetch<1>(g, rv)) return;
+        if (stamp) stamp[8 * rnd + 4] = wall_clock64();               // challenge here
         for (uint32_t idx = tid; idx < 3 * half; idx += nthr) {
             const uint32_t t = idx / half, e = idx - t * half;
             Fr *X = T0 + t * kTailCap;
@@ -282,6 +290,7 @@ __global__ __launch_bounds__(kTailThreads) void k_pc_tail(TailArgs a) {
         }
         __syncthreads();
         L = half;
+        if (stamp) { stamp[8 * rnd + 5] = wall_clock64(); rnd++; stamp[8 * rnd] = stamp[8 * (rnd - 1) + 5]; }   // folded = next round's start
     }
     // ---- hand the host-played tail over: table t of instance y at host_out[(3 y + t) * t_out ..), element j of this workgroup at j W + w
     for (uint32_t idx = tid; idx < 3 * L; idx += nthr) {
@@ -305,6 +314,21 @@ unsigned long long dev_pc_tail(DevCtx &c, const PcList &L, int W, size_t len0, s
     a.mail = c.d_tail_alias; a.host_out = c.d_results_alias + slot;
     a.seq0 = c.seq + 1; c.seq += (unsigned long long)rounds + 1;
     a.go = c.arm_many(rounds);
+    static const bool want_stamps = getenv("OTTI_TAIL_STAMPS") != nullptr;
+    static thread_local unsigned long long *h_stamps = nullptr, *d_stamps = nullptr;
+    a.stamps = nullptr;
+    if (want_stamps) {
+        if (!h_stamps) { OTTI_HIP(hipHostMalloc((void **)&h_stamps, 8 * 32 * 8, hipHostMallocDefault)); OTTI_HIP(hipHostGetDevicePointer((void **)&d_stamps, h_stamps, 0)); }
+        else {                                                    // the previous launch's stamps (its kernel has long finished: the host went through all its rounds)
+            const unsigned long long *t = h_stamps; const int nr_ = (int)t[8 * 31];
+            for (int r = 0; r < nr_ && r < 30; r++)
+                fprintf(stderr, "[otti] k_pc_tail W=%d L=%llu round %d: sums %.2f | reduce %.2f | mail %.2f | wait for the challenge %.2f | fold %.2f us\n", (int)t[8 * 31 + 1], t[8 * 31 + 2] >> r, r,
+                        0.01 * (double)(t[8 * r + 1] - t[8 * r]), 0.01 * (double)(t[8 * r + 2] - t[8 * r + 1]), 0.01 * (double)(t[8 * r + 3] - t[8 * r + 2]),
+                        0.01 * (double)(t[8 * r + 4] - t[8 * r + 3]), 0.01 * (double)(t[8 * r + 5] - t[8 * r + 4]));
+        }
+        memset(h_stamps, 0, 8 * 32 * 8); h_stamps[8 * 31] = (unsigned long long)rounds; h_stamps[8 * 31 + 1] = (unsigned long long)W; h_stamps[8 * 31 + 2] = len0 / (size_t)W;
+        a.stamps = d_stamps;
+    }
     KScope ks(c, KC_PC_ROUND);
     hipLaunchKernelGGL(k_pc_tail, dim3((unsigned)W, (unsigned)L.n), kTailThreads, 0, c.stream, a);
     return a.seq0;

@@ -65,27 +65,33 @@ template <int N> __device__ __forceinline__ bool armed_fetch(const Armed &a, Fr 
         Fr t[N];
         for (int k = 0; k < N; k++) t[k] = fr_zero();
         if (leader) {
+            // One poll = the header (sequence number, tag) and the N values in ONE batch of system-scope 16-byte loads, all issued before
+            // the first is waited for: a poll that finds its number has the values too — one PCIe round trip from go() to the challenge.
+            // The loads of a batch may be served at different moments; go_tag() tells a batch that mixes old and new words (polled again).
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            const GoBox *box = a.host;
             while (ok < 0) {
-                const unsigned long long s = __hip_atomic_load(&a.host->seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
-                if (s == a.want) ok = 1;
-                else if (s == ~0ull) ok = 0;
+                u32x4 hd, w[8];
+                if constexpr (N == 1)
+                    asm volatile("global_load_dwordx4 %0, %3, off sc0 sc1\n\tglobal_load_dwordx4 %1, %3, off offset:32 sc0 sc1\n\tglobal_load_dwordx4 %2, %3, off offset:48 sc0 sc1\n\t"
+                                 "s_waitcnt vmcnt(0)" : "=&v"(hd), "=&v"(w[0]), "=&v"(w[1]) : "v"(box) : "memory");
+                else
+                    asm volatile("global_load_dwordx4 %0, %9, off sc0 sc1\n\tglobal_load_dwordx4 %1, %9, off offset:32 sc0 sc1\n\tglobal_load_dwordx4 %2, %9, off offset:48 sc0 sc1\n\t"
+                                 "global_load_dwordx4 %3, %9, off offset:64 sc0 sc1\n\tglobal_load_dwordx4 %4, %9, off offset:80 sc0 sc1\n\tglobal_load_dwordx4 %5, %9, off offset:96 sc0 sc1\n\t"
+                                 "global_load_dwordx4 %6, %9, off offset:112 sc0 sc1\n\tglobal_load_dwordx4 %7, %9, off offset:128 sc0 sc1\n\tglobal_load_dwordx4 %8, %9, off offset:144 sc0 sc1\n\t"
+                                 "s_waitcnt vmcnt(0)" : "=&v"(hd), "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&v"(w[4]), "=&v"(w[5]), "=&v"(w[6]), "=&v"(w[7]) : "v"(box) : "memory");
+                const unsigned long long s = (unsigned long long)hd[0] | ((unsigned long long)hd[1] << 32), tag = (unsigned long long)hd[2] | ((unsigned long long)hd[3] << 32);
+                if (s == a.want) {
+                    for (int k = 0; k < N; k++) for (int i = 0; i < 4; i++) { t[k].v[i] = w[2 * k][i]; t[k].v[4 + i] = w[2 * k + 1][i]; }
+                    if (go_tag(a.want, t, N) == tag) { ok = 1; break; }
+                }
+                if (s == ~0ull) ok = 0;
                 else if (__builtin_amdgcn_s_memrealtime() - t0 > a.deadline) {
                     ok = 0;
                     __hip_atomic_store(&a.host->timed_out, a.want, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-                } else __builtin_amdgcn_s_sleep(2);
+                } else __builtin_amdgcn_s_sleep(1);
             }
-            if (ok) {
-                // the values sit in pinned (uncached) host memory: plain 16-byte loads, all issued before the first is waited for — one
-                // PCIe round trip for the lot (8-byte atomics would be waited for one by one)
-                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-                const u32x4 *src = reinterpret_cast<const u32x4 *>(&a.host->v[0]);
-                u32x4 w[2 * N];
-                for (int i = 0; i < 2 * N; i++) w[i] = __builtin_nontemporal_load(src + i);
-                for (int k = 0; k < N; k++) {
-                    for (int i = 0; i < 4; i++) { t[k].v[i] = w[2 * k][i]; t[k].v[4 + i] = w[2 * k + 1][i]; }
-                    store_words_sc1(&a.dev->v[k], t[k].v, 8);
-                }
-            }
+            if (ok) for (int k = 0; k < N; k++) store_words_sc1(&a.dev->v[k], t[k].v, 8);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __hip_atomic_store(&a.dev->seq, ok ? a.want : (a.want | abort_bit), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {

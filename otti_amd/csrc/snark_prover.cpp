@@ -13,6 +13,7 @@
 #include "snark_dev.h"
 #include "pool.h"
 #include <chrono>
+#include <functional>
 #include <thread>
 
 namespace otti {
@@ -175,7 +176,12 @@ ProductCircuitEvalProofBatched pcbatch_prove(DevCtx &c, Circuits &C, const std::
     static const bool tail_env = [] { const char *e = getenv("OTTI_PC_TAIL"); return !(e && e[0] == '0'); }();
     static const size_t tail_cap = [] { const char *e = getenv("OTTI_PC_TAIL_CAP"); size_t v = e ? (size_t)atoi(e) : 0; return (v >= 2 && v <= (size_t)kTailCap && !(v & (v - 1))) ? v : (size_t)kTailCap; }();
     const bool tail_ok = arm_ok && tail_env;
+    SpinPool &pool = SpinPool::get();
+    const int host_threads = std::min(8, pool.workers() + 1);
+    static const bool trace = getenv("OTTI_TRACE") != nullptr;
+    double tr_tail_first_ms = 0, tr_tail_sum_ms = 0, tr_tail_wait_ms = 0, tr_tail_ms = 0, tr_launch_ms = 0, tr_host_ms = 0, tr_layer0_ms = 0; size_t tr_tail_rounds = 0, tr_launch_rounds = 0, tr_host_rounds = 0, tr_tail_layers = 0;
     for (size_t li = 0; li < nl; li++) {
+        const double tr_layer_start = trace ? now_ms() : 0;
         const size_t layer_id = nl - 1 - li, nr = rand.size(), h = (size_t)1 << nr;      // elements per side in this layer, one round per variable
         const bool with_dotp = layer_id == 0 && D && D->n;
         if (with_dotp) { if (D->len != h) throw Error(OTTI_ERR_INTERNAL, "dot-product circuits do not match the input layer"); claims.insert(claims.end(), dotp_evals.begin(), dotp_evals.end()); }
@@ -183,7 +189,9 @@ ProductCircuitEvalProofBatched pcbatch_prove(DevCtx &c, Circuits &C, const std::
         for (int i = 0; i < np; i++) { P.A[P.n] = C.left(i, layer_id); P.B[P.n] = C.right(i, layer_id); P.C[P.n] = nullptr; P.n++; }
         if (with_dotp) for (int i = 0; i < D->n; i++) { P.A[P.n] = D->l[i]; P.B[P.n] = D->r[i]; P.C[P.n] = D->w[i]; P.n++; }
         const int ni = P.n;
-        const size_t lgT = std::min<size_t>(nr, ni >= 8 ? 4 : 5), T = (size_t)1 << lgT, ndev = nr - lgT;
+        // the host plays the last lgT rounds of every layer (and the small layers entirely): with its helper threads a round over tables of
+        // 32 (18-instance batches) or 128 (4-instance batches) elements costs it less than a device round's ~18 us of hand-overs
+        const size_t lgT = std::min<size_t>(nr, host_threads >= 4 ? (ni >= 8 ? 5 : 7) : (ni >= 8 ? 4 : 5)), T = (size_t)1 << lgT, ndev = nr - lgT;
         // The persistent tail (k_pc_tail, snark_dev.h): from round k0 on — the first round whose tables fit the LDS of W workgroups per
         // instance — ONE launch plays every remaining device round.  Only while this is the process's single proof in flight (its grid
         // must be resident as a whole: the workgroups wait for the host, the host for all of them) and no kernel class it belongs to is
@@ -229,13 +237,20 @@ ProductCircuitEvalProofBatched pcbatch_prove(DevCtx &c, Circuits &C, const std::
         std::vector<std::vector<Fr>> tA(ni), tB(ni), tC(ni); std::vector<Fr> tE; bool tail_built = false;   // host tail: T elements per table
         Fr cj = one, cj_tail = one;                         // cj_tail: the eq factor accumulated before the tail took over (its eq table carries the rest)
         size_t len = h;
+        if (trace) { tr_layer0_ms += now_ms() - tr_layer_start; if (tail) tr_tail_layers++; }
         for (size_t j = 0; j < nr; j++) {                    // SumcheckInstanceProof::prove_cubic_batched
+            const double tr_round_start = trace ? now_ms() : 0;
             Fr c0 = fr_zero(), c2 = fr_zero(), c3 = fr_zero();
             if (j < ndev && tail && j >= k0) {
                 // a round of the persistent launch: W partial sums per instance, in the workgroups' own mail lines; the eq table is a real
                 // third table there, so the sums already carry the bound variable's factor — only the factor of the rounds before k0 is missing
                 if (j == k0) cj_tail = cj;
-                c.wait_tail(ni * tailW, tail_seq + (j - k0));
+                {
+                    const double tw = trace ? now_ms() : 0;
+                    if (trace) { c.wait_tail(1, tail_seq + (j - k0)); tr_tail_first_ms += now_ms() - tw; }     // (trace only: when the first line is in)
+                    c.wait_tail(ni * tailW, tail_seq + (j - k0));
+                    if (trace) tr_tail_wait_ms += now_ms() - tw;
+                }
                 Fr p0 = fr_zero(), p2 = fr_zero(), p3 = fr_zero();
                 for (int k = 0; k < ni; k++) {
                     const TailMail *m = c.h_tail + (size_t)k * tailW;
@@ -245,6 +260,7 @@ ProductCircuitEvalProofBatched pcbatch_prove(DevCtx &c, Circuits &C, const std::
                     a0 = fr_add(a0, fr_mul(s0, coeff[k])); a2 = fr_add(a2, fr_mul(s2, coeff[k])); a3 = fr_add(a3, fr_mul(s3, coeff[k]));
                 }
                 c0 = fr_add(c0, fr_mul(cj_tail, p0)); c2 = fr_add(c2, fr_mul(cj_tail, p2)); c3 = fr_add(c3, fr_mul(cj_tail, p3));
+                if (trace) tr_tail_sum_ms += now_ms() - tr_round_start;
             } else if (j < ndev) {
                 c.wait_ticket(tick[j]);
                 const Fr &tau = rand[j];
@@ -270,19 +286,29 @@ ProductCircuitEvalProofBatched pcbatch_prove(DevCtx &c, Circuits &C, const std::
                     tail_built = true;
                 }
                 const size_t half = len / 2;
-                for (int k = 0; k < ni; k++) {
-                    const std::vector<Fr> &A = tA[k], &B = tB[k], &Cc = k < np ? tE : tC[k];
-                    Fr s0 = fr_zero(), s2 = fr_zero(), s3 = fr_zero();
-                    for (size_t i = 0; i < half; i++) {
-                        const Fr da = fr_sub(A[i + half], A[i]), db = fr_sub(B[i + half], B[i]), dc = fr_sub(Cc[i + half], Cc[i]);
-                        s0 = fr_add(s0, fr_mul(fr_mul(A[i], B[i]), Cc[i]));
-                        Fr x = fr_add(A[i + half], da), y = fr_add(B[i + half], db), z = fr_add(Cc[i + half], dc);
-                        s2 = fr_add(s2, fr_mul(fr_mul(x, y), z));
-                        x = fr_add(x, da); y = fr_add(y, db); z = fr_add(z, dc);
-                        s3 = fr_add(s3, fr_mul(fr_mul(x, y), z));
+                // the instances are independent: spread over the prover's helper threads while a round is more than a few microseconds of work
+                const int nt = (half * (size_t)ni >= 32) ? std::min(host_threads, ni) : 1;
+                Fr part[8][3];
+                auto eval_share = [&](int t) {
+                    Fr q0 = fr_zero(), q2 = fr_zero(), q3 = fr_zero();
+                    for (int k = t; k < ni; k += nt) {
+                        const std::vector<Fr> &A = tA[k], &B = tB[k], &Cc = k < np ? tE : tC[k];
+                        Fr s0 = fr_zero(), s2 = fr_zero(), s3 = fr_zero();
+                        for (size_t i = 0; i < half; i++) {
+                            const Fr da = fr_sub(A[i + half], A[i]), db = fr_sub(B[i + half], B[i]), dc = fr_sub(Cc[i + half], Cc[i]);
+                            s0 = fr_add(s0, fr_mul(fr_mul(A[i], B[i]), Cc[i]));
+                            Fr x = fr_add(A[i + half], da), y = fr_add(B[i + half], db), z = fr_add(Cc[i + half], dc);
+                            s2 = fr_add(s2, fr_mul(fr_mul(x, y), z));
+                            x = fr_add(x, da); y = fr_add(y, db); z = fr_add(z, dc);
+                            s3 = fr_add(s3, fr_mul(fr_mul(x, y), z));
+                        }
+                        q0 = fr_add(q0, fr_mul(s0, coeff[k])); q2 = fr_add(q2, fr_mul(s2, coeff[k])); q3 = fr_add(q3, fr_mul(s3, coeff[k]));
                     }
-                    c0 = fr_add(c0, fr_mul(s0, coeff[k])); c2 = fr_add(c2, fr_mul(s2, coeff[k])); c3 = fr_add(c3, fr_mul(s3, coeff[k]));
-                }
+                    part[t][0] = q0; part[t][1] = q2; part[t][2] = q3;
+                };
+                if (nt > 1) { std::function<void()> tasks[8]; for (int t = 0; t < nt; t++) tasks[t] = [&eval_share, t] { eval_share(t); }; pool.parallel(tasks, nt); }
+                else eval_share(0);
+                for (int t = 0; t < nt; t++) { c0 = fr_add(c0, part[t][0]); c2 = fr_add(c2, part[t][1]); c3 = fr_add(c3, part[t][2]); }
             }
             Fr evals4[4] = {c0, fr_sub(e, c0), c2, c3}, poly[4];
             unipoly_from_evals(poly, evals4, 4);
@@ -300,12 +326,18 @@ ProductCircuitEvalProofBatched pcbatch_prove(DevCtx &c, Circuits &C, const std::
             else {
                 const size_t half = len / 2;
                 auto fold = [&](std::vector<Fr> &t) { for (size_t i = 0; i < half; i++) t[i] = fr_add(t[i], fr_mul(r_j, fr_sub(t[i + half], t[i]))); t.resize(half); };
-                for (int k = 0; k < ni; k++) { fold(tA[k]); fold(tB[k]); if (k >= np) fold(tC[k]); }
-                fold(tE);
+                const int nt = (half * (size_t)ni >= 64) ? std::min(host_threads, ni) : 1;
+                auto fold_share = [&](int t) { for (int k = t; k < ni; k += nt) { fold(tA[k]); fold(tB[k]); if (k >= np) fold(tC[k]); } if (t == nt - 1) fold(tE); };
+                if (nt > 1) { std::function<void()> tasks[8]; for (int t = 0; t < nt; t++) tasks[t] = [&fold_share, t] { fold_share(t); }; pool.parallel(tasks, nt); }
+                else fold_share(0);
             }
             e = unipoly_eval(poly, 4, r_j);
             L.coeffs.push_back(poly[0]); L.coeffs.push_back(poly[2]); L.coeffs.push_back(poly[3]);      // UniPoly::compress
             len /= 2;
+            if (trace) {
+                const double dt = now_ms() - tr_round_start;
+                if (j < ndev && tail && j >= k0) { tr_tail_ms += dt; tr_tail_rounds++; } else if (j < ndev) { tr_launch_ms += dt; tr_launch_rounds++; } else { tr_host_ms += dt; tr_host_rounds++; }
+            }
         }
         if (!tail_built) {                                   // a layer without rounds: the tables are single elements
             c.wait_ticket(tick[0]);
@@ -324,6 +356,10 @@ ProductCircuitEvalProofBatched pcbatch_prove(DevCtx &c, Circuits &C, const std::
         for (int i = 0; i < np; i++) claims[i] = fr_add(L.left[i], fr_mul(r_layer, fr_sub(L.right[i], L.left[i])));
         std::vector<Fr> ext = {r_layer}; ext.insert(ext.end(), rprod.begin(), rprod.end()); rand = ext;
     }
+    if (trace)
+        fprintf(stderr, "[otti] pcbatch ni=%d layers=%zu (tail in %zu): %zu tail rounds %.3f ms (%.1f us each: first mail in after %.1f, all after %.1f, summed and combined after %.1f), %zu launch rounds %.3f ms (%.1f us each), %zu host rounds %.3f ms, layer set-up %.3f ms\n",
+                np, nl, tr_tail_layers, tr_tail_rounds, tr_tail_ms, tr_tail_rounds ? 1e3 * tr_tail_ms / tr_tail_rounds : 0.0, tr_tail_rounds ? 1e3 * tr_tail_first_ms / tr_tail_rounds : 0.0, tr_tail_rounds ? 1e3 * tr_tail_wait_ms / tr_tail_rounds : 0.0, tr_tail_rounds ? 1e3 * tr_tail_sum_ms / tr_tail_rounds : 0.0, tr_launch_rounds, tr_launch_ms,
+                tr_launch_rounds ? 1e3 * tr_launch_ms / tr_launch_rounds : 0.0, tr_host_rounds, tr_host_ms, tr_layer0_ms);
     rand_out = rand;
     return pf;
 }
