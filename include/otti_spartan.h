@@ -201,6 +201,10 @@ int32_t otti_k_sc_quad_fold_round(const uint8_t *h_A, const uint8_t *h_B, size_t
  * plain launch's results; any disagreement between the three ways is OTTI_ERR_INTERNAL. */
 int32_t otti_k_armed_selftest(const uint8_t *A, const uint8_t *B, size_t len, const uint8_t *r, uint32_t hold_us, uint8_t *out2, uint8_t *e2);
 int32_t otti_k_msm_rows(otti_gens *gens, const uint8_t *h_Z, size_t L, size_t R, const uint8_t *h_blinds, uint8_t *h_out32, float *kernel_ms);
+/* PolyEvalProof::verify's C_LZ on the device [dense_mlpoly.rs PolyEvalProof::verify -> GroupElement::vartime_multiscalar_mul, RECALL]:
+   out = compress(sum_i s[i] * decompress(C[i])), n >= 256 compressed ristretto255 points, scalars in Montgomery form.  Batch decompression,
+   LDS-bucket Pippenger, window recombination on the host.  OTTI_ERR_VERIFY_DECOMPRESS if an encoding does not decode. */
+int32_t otti_k_row_sum(const uint8_t *h_compressed32, size_t n, const uint8_t *h_scalars_mont32, uint8_t *h_out32);
 
 /* ---- the kernels the prover actually launches for phase one, the evaluation proof and the bullet reduction (host pointers, as above).
         No reference counterpart beyond the upstream functions named; these exist so that a failing proof points at a kernel. ---- */

@@ -124,6 +124,7 @@ _sig("otti_k_sc_quad_round", _i32, _vp, _vp, _sz, _vp, _fp)
 _sig("otti_k_sc_quad_fold_round", _i32, _vp, _vp, _sz, _vp, _vp, _vp, _fp)
 _sig("otti_k_armed_selftest", _i32, _vp, _vp, _sz, _vp, ctypes.c_uint32, _vp, _vp)
 _sig("otti_k_msm_rows", _i32, _vp, _vp, _sz, _sz, _vp, _vp, _fp)
+_sig("otti_k_row_sum", _i32, _vp, _sz, _vp, _vp)
 _sig("otti_k_eq_pyramid", _i32, _vp, _sz, _vp)
 _sig("otti_k_sc_cubic3_round", _i32, _vp, _vp, _vp, _sz, _vp, _vp, _fp)
 _sig("otti_k_sc_cubic3_fold_round", _i32, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _fp)
@@ -552,7 +553,7 @@ def fr_to_ints(a):
 
 
 KERNEL_CLASSES = ("msm_rows", "msm_small", "msm_finish", "sc_cubic", "sc_quad", "spmv", "eq", "reduce", "poly_bound", "bullet", "other",
-                  "pc_round", "prod_layer", "hash_layer", "gather", "dot_many")
+                  "pc_round", "prod_layer", "hash_layer", "gather", "dot_many", "decode", "msm_var")
 
 
 def stats_enable(on=True, only=None):
@@ -692,6 +693,15 @@ class kernels:
         out = np.zeros((2, n // 2, 32), dtype=np.uint8); e = np.zeros((2, 32), dtype=np.uint8)
         _check(lib.otti_k_armed_selftest(_ptr(A), _ptr(B), n, _ptr(r), hold_us, _ptr(out), _ptr(e)))
         return out, e
+
+    @staticmethod
+    def row_sum(compressed, scalars_mont):
+        """the verifier's variable-base sum on the device: compress(sum_i s[i] * decompress(C[i]))"""
+        C = np.ascontiguousarray(compressed, dtype=np.uint8).reshape(-1, 32); s = _scalars(scalars_mont, "s")
+        assert C.shape[0] == s.shape[0]
+        out = np.zeros(32, dtype=np.uint8)
+        _check(lib.otti_k_row_sum(_ptr(C), C.shape[0], _ptr(s), _ptr(out)))
+        return out
 
     @staticmethod
     def msm_rows(gens, Z, L, R, blinds):

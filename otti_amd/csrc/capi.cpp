@@ -562,6 +562,22 @@ int32_t otti_k_armed_selftest(const uint8_t *A, const uint8_t *B, size_t len, co
         return OTTI_OK;
     });
 }
+// The verifier's variable-base sum (spartan.h RowSumBeginHook / FinishHook): sum_i s[i] * decode(C[i]) on the device — batch decompression
+// (k_decode_niels), LDS-bucket Pippenger (k_msm_var), window recombination on the host.  No host fallback here: this entry exists to test the device path.
+int32_t otti_k_row_sum(const uint8_t *compressed32, size_t n, const uint8_t *scalars_mont32, uint8_t *out32) {
+    return guarded([&] {
+        if (!compressed32 || !scalars_mont32 || !out32 || n < 256) throw Error(OTTI_ERR_BAD_ARG, "null argument or fewer than 256 points");
+        if (!g_row_sum_begin_hook || !g_row_sum_finish_hook) throw Error(OTTI_ERR_NO_DEVICE, "no device path registered");
+        DevCtx::get();                                             // NoDevice surfaces here rather than as a declined job
+        RowSumJob *job = g_row_sum_begin_hook(reinterpret_cast<const CPoint *>(compressed32), n);
+        if (!job) throw Error(OTTI_ERR_NO_DEVICE, "the device declined the row sum");
+        std::vector<Fr> s(n); memcpy(s.data(), scalars_mont32, 32 * n);
+        Pt sum; const int rc = g_row_sum_finish_hook(job, s.data(), sum);
+        if (rc == OTTI_ERR_VERIFY_DECOMPRESS) throw Error(OTTI_ERR_VERIFY_DECOMPRESS, "a point does not decode");
+        if (rc) throw Error(OTTI_ERR_INTERNAL, "device row sum failed");
+        pt_encode(out32, sum); return OTTI_OK;
+    });
+}
 int32_t otti_k_msm_rows(otti_gens *gens, const uint8_t *Z, size_t L, size_t R, const uint8_t *blinds, uint8_t *out32, float *ms) {
     return guarded([&] {
         DevCtx &c = DevCtx::get(); Gens &g = *gens->g;
@@ -762,7 +778,7 @@ int32_t otti_bench_madd_peak(double *madds_per_second) {
 
 // ------------------------------------------------------------------------------------------------ kernel timing (HIP events on the library stream)
 static const char *kClassNames[KC_COUNT] = {"msm_rows", "msm_small", "msm_finish", "sc_cubic", "sc_quad", "spmv", "eq", "reduce", "poly_bound", "bullet", "other",
-                                               "pc_round", "prod_layer", "hash_layer", "gather", "dot_many"};
+                                               "pc_round", "prod_layer", "hash_layer", "gather", "dot_many", "decode", "msm_var"};
 int32_t otti_stats_enable(int32_t on) { KStats::get().on = on != 0; KStats::get().mask = 0xffffffffu; KStats::get().reset(); return OTTI_OK; }
 int32_t otti_stats_select(const char *kernel_class) {
     for (int k = 0; k < KC_COUNT; k++) if (!strcmp(kernel_class, kClassNames[k])) { KStats::get().mask = 1u << k; return OTTI_OK; }

@@ -98,6 +98,7 @@ struct DevCtx {
     bool host_coherent = false;                               // the words kernels spin on / mail to are fine-grained coherent host memory (else: no armed launches)
     void reset_arrival_counters();                            // after an aborted or timed-out launch: a grid may have left them non-zero (stream must be idle)
     hipEvent_t ev_order = nullptr;                            // orders a caller's stream (otti_kd_*) against this context's own
+    std::vector<struct RowSumSlot *> row_slots;               // the verifier's variable-base sums in flight on this context (prover.cpp), buffers kept across proofs
     struct TailMail *h_tail = nullptr, *d_tail_alias = nullptr;   // per-workgroup mail lines of the persistent sum-check tail (snark_dev.h), pinned
     void ensure_tail_mail();
     void wait_tail(int n_groups, unsigned long long seq);     // spin until every line carries seq (same failure handling as wait_ticket)
@@ -125,6 +126,7 @@ struct DevCtx {
     Pt *d_pts_alias = nullptr; DevBuf<unsigned> d_counter2;
     void ensure_points(size_t rows, size_t splits);
 };
+struct RowSumSlot { DevBuf<uint8_t> comp; DevBuf<Niels> pts; DevBuf<Fr> sc; DevBuf<Pt> out; DevBuf<unsigned> bad; bool busy = false; };
 struct ActiveProof { ActiveProof(); ~ActiveProof(); static int count(); };       // RAII around one prove call: counts the proofs in flight in this process
 constexpr int kResultSlots = 2048;                          // 64 KB pinned: round sums, sum-check tails (SNARK: up to 18 x 3 tables x 16 elements)
 constexpr size_t kHostEncodeRows = 8;
@@ -132,7 +134,8 @@ constexpr size_t kHostPtsCap = 512;
 
 // per-kernel-class HIP-event timing on the library's own stream (bench.py's roofline numbers come from here)
 enum KClass { KC_MSM_ROWS = 0, KC_MSM_SMALL, KC_MSM_FINISH, KC_SC_CUBIC, KC_SC_QUAD, KC_SPMV, KC_EQ, KC_REDUCE, KC_BOUND, KC_BULLET, KC_OTHER,
-              KC_PC_ROUND, KC_PROD_LAYER, KC_HASH_LAYER, KC_GATHER, KC_DOT_MANY /* SNARK mode (k_snark.hip) */, KC_COUNT };
+              KC_PC_ROUND, KC_PROD_LAYER, KC_HASH_LAYER, KC_GATHER, KC_DOT_MANY /* SNARK mode (k_snark.hip) */,
+              KC_DECODE, KC_MSM_VAR /* verifier (k_msm.hip) */, KC_COUNT };
 struct KStats {
     bool on = false; unsigned mask = 0xffffffffu;            // bit k set: kernel class k is timed
     std::vector<hipEvent_t> pool; std::vector<int> cls; size_t used = 0;
@@ -232,6 +235,11 @@ void dev_bullet_step(DevCtx &c, Fr *a, Fr *b, Fr *s, size_t R, size_t n_cur, boo
 unsigned long long dev_bullet_round(DevCtx &c, const DeviceGens &g, size_t R, size_t n_cur, bool fold, const Fr &u, const Fr &u_inv, const Fr *a_in,
                                     const Fr *b_in, const Fr *s_in, Fr *a_out, Fr *b_out, Fr *s_out, const Fr *extra_s, const uint32_t *extra_base,
                                     bool armed = false);
+// ---- verifier: decompression of n ristretto255 points into affine Niels form (bad: count of encodings that do not decode), and the
+// variable-base MSM over them: out[w * splits + s] = sum over the points of split s of digit_w(scalar) * point — window sums the host
+// combines (253 doublings: a sequential chain a host core runs 30 x faster than a GPU lane).  Returns the window width c it used.
+void dev_decode_niels(DevCtx &c, const uint8_t *compressed_dev, size_t n, Niels *out, unsigned *bad);
+int dev_msm_var(DevCtx &c, const Niels *pts, const Fr *scalars, size_t n, Pt *out, size_t out_cap, int *n_windows, int *n_splits);
 double dev_madd_peak(DevCtx &c);                                          // mixed point additions per second, whole chip (the MSM's ALU roof)
 void dev_scale(DevCtx &c, const Fr *in, const Fr &k, Fr *out, size_t n);
 void dev_fill_one(DevCtx &c, Fr *p, size_t n);

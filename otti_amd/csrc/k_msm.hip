@@ -534,6 +534,103 @@ std::shared_ptr<DeviceGens> build_device_gens(const Gens &g, int c) {
     return d;
 }
 
+// ------------------------------------------------------------------------------------------------ verifier: variable-base MSM
+// PolyEvalProof::verify needs  C_LZ = sum_i L[i] * C_i  over the sqrt(V) row commitments of the proof (dense_mlpoly.rs
+// PolyEvalProof::verify -> vartime_multiscalar_mul [RECALL]): points nobody has a table for, uniform 253-bit scalars.  Pippenger with the
+// buckets in LDS: workgroup (window w, split s) takes the signed radix-2^c digits of window w of up to kVarChunk scalars, sorts the point
+// indices by bucket with an LDS counting sort (histogram by LDS atomics, prefix, scatter), then thread b walks bucket b's list with mixed
+// additions (the decoded points are affine: 7 multiplications each) — about eight per bucket, by the choice of c — and the weighted
+// bucket sum  sum_b b * B_b  is formed in 2 log2(#buckets) parallel steps: a suffix scan (T_b = sum_{j >= b} B_j), then a tree over the
+// T_b.  The workgroup's result is one extended point per (window, split); the host adds the splits and runs the 253 doublings of the
+// window recombination (a dependent chain: ~25 us on a host core against ~300 us on a GPU lane).
+constexpr int kVarChunk = 2048, kVarMaxBuckets = kBlock;        // one bucket per thread at most: c <= 9
+struct VarMsmArgs { const Niels *pts; const Fr *sc; uint32_t n, chunk; int c, W, splits; uint32_t K[9]; Pt *out; };
+__global__ __launch_bounds__(kBlock) void k_msm_var(VarMsmArgs A) {
+    __shared__ uint16_t s_key[kVarChunk], s_list[kVarChunk];        // per point: (|digit| - 1) | sign << 15, 0xffff for a zero digit; point indices sorted by bucket
+    __shared__ uint32_t s_start[kVarMaxBuckets + 1], s_fill[kVarMaxBuckets];
+    __shared__ P10 s_bkt[kVarMaxBuckets];
+    const int w = blockIdx.x, tid = threadIdx.x;
+    const uint32_t i0 = blockIdx.y * A.chunk, n_here = min(A.chunk, A.n - i0), nb = 1u << (A.c - 1);
+    for (uint32_t b = tid; b <= nb; b += kBlock) { s_start[b] = 0; if (b < nb) s_fill[b] = 0; }
+    __syncthreads();
+    for (uint32_t i = tid; i < n_here; i += kBlock) {
+        uint32_t r9[9]; recode_scalar(r9, A.sc[i0 + i], A.K);
+        const int d = recoded_digit(r9, w, A.c);
+        uint16_t key = 0xffffu;
+        if (d) { const uint32_t mag = (uint32_t)(d < 0 ? -d : d); key = (uint16_t)((mag - 1) | (d < 0 ? 0x8000u : 0u)); atomicAdd(&s_start[mag], 1u); }   // counts land one slot up: the prefix below turns them into starts
+        s_key[i] = key;
+    }
+    __syncthreads();
+    if (tid == 0) { uint32_t run = 0; for (uint32_t b = 0; b <= nb; b++) { run += s_start[b]; s_start[b] = run; } }      // s_start[b] = first list slot of bucket b (index |d| - 1)
+    __syncthreads();
+    for (uint32_t i = tid; i < n_here; i += kBlock) {
+        const uint16_t key = s_key[i];
+        if (key == 0xffffu) continue;
+        const uint32_t b = key & 0x7fffu;
+        s_list[s_start[b] + atomicAdd(&s_fill[b], 1u)] = (uint16_t)(i | (key & 0x8000u));
+    }
+    __syncthreads();
+    for (uint32_t b = tid; b < nb; b += kBlock) {
+        P10 acc = p10_identity();
+        for (uint32_t k = s_start[b]; k < s_start[b + 1]; k++) {
+            const uint16_t e16 = s_list[k];
+            N10 e = n10_unpack(A.pts[i0 + (e16 & 0x7fffu)]);
+            if (e16 & 0x8000u) e = n10_negate(e);
+            acc = p10_madd(acc, e);
+        }
+        s_bkt[b] = acc;
+    }
+    __syncthreads();
+    // sum_b (b + 1) * B_b  (0-based b): suffix scan, then the sum of the suffix sums
+    const F10 d2 = f10_const(fp_2D());
+    for (uint32_t off = 1; off < nb; off <<= 1) {
+        const bool have = (uint32_t)tid + off < nb;
+        P10 v = p10_identity();
+        if (have) v = s_bkt[tid + off];
+        __syncthreads();
+        if (have) s_bkt[tid] = p10_add(s_bkt[tid], v, d2);
+        __syncthreads();
+    }
+    for (uint32_t sft = nb >> 1; sft >= 1; sft >>= 1) {
+        for (uint32_t b = tid; b < sft; b += kBlock) s_bkt[b] = p10_add(s_bkt[b], s_bkt[b + sft], d2);
+        __syncthreads();
+    }
+    if (tid == 0) A.out[(size_t)w * A.splits + blockIdx.y] = p10_pack(s_bkt[0]);
+}
+int dev_msm_var(DevCtx &c, const Niels *pts, const Fr *scalars, size_t n, Pt *out, size_t out_cap, int *n_windows, int *n_splits) {
+    if (!n || n > ((size_t)1 << 24)) throw Error(OTTI_ERR_INTERNAL, "msm_var: bad size");
+    VarMsmArgs A;
+    const size_t splits = (n + kVarChunk - 1) / kVarChunk, chunk = (n + splits - 1) / splits;
+    int lg = 0; while (((size_t)1 << lg) < chunk) lg++;
+    A.c = std::max(5, std::min(9, lg - 2));                    // ~8 points per bucket: 2^(c-1) buckets for `chunk` points
+    A.W = 253 / A.c + 1; A.splits = (int)splits; A.pts = pts; A.sc = scalars; A.n = (uint32_t)n; A.chunk = (uint32_t)chunk; A.out = out;
+    if ((size_t)A.W * splits > out_cap) throw Error(OTTI_ERR_INTERNAL, "msm_var: result buffer too small");
+    for (int i = 0; i < 9; i++) A.K[i] = 0;
+    for (int w = 0; w < A.W; w++) { int bit = A.c - 1 + A.c * w; A.K[bit >> 5] |= 1u << (bit & 31); }
+    KScope ks(c, KC_MSM_VAR);
+    hipLaunchKernelGGL(k_msm_var, dim3((unsigned)A.W, (unsigned)splits), kBlock, 0, c.stream, A);
+    if (n_windows) *n_windows = A.W;
+    if (n_splits) *n_splits = (int)splits;
+    return A.c;
+}
+// RFC 9496 4.3.1 Decode, one lane per point, straight into the affine Niels form the mixed addition reads (Z = 1 after Decode)
+__global__ __launch_bounds__(64) void k_decode_niels(const uint8_t *in, size_t n, Niels *out, unsigned *bad) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint8_t b[32];
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(in + 32 * i);
+    for (int k = 0; k < 8; k++) { const uint32_t x = src[k]; b[4 * k] = (uint8_t)x; b[4 * k + 1] = (uint8_t)(x >> 8); b[4 * k + 2] = (uint8_t)(x >> 16); b[4 * k + 3] = (uint8_t)(x >> 24); }
+    Pt p;
+    if (!pt_decode(p, b)) { atomicAdd(bad, 1u); out[i] = niels_identity(); return; }
+    Niels nl; nl.yplusx = fp_add(p.Y, p.X); nl.yminusx = fp_sub(p.Y, p.X); nl.xy2d = fp_mul(p.T, fp_2D());
+    out[i] = nl;
+}
+void dev_decode_niels(DevCtx &c, const uint8_t *compressed_dev, size_t n, Niels *out, unsigned *bad) {
+    if (!n) return;
+    KScope ks(c, KC_DECODE);
+    hipLaunchKernelGGL(k_decode_niels, (unsigned)((n + 63) / 64), 64, 0, c.stream, compressed_dev, n, out, bad);
+}
+
 // ------------------------------------------------------------------------------------------------ the ALU roof of the MSM, measured
 // Whole-chip throughput of the mixed point addition the bulk MSM is made of (p10_madd, operands in registers, every CU busy): what
 // bench.py prices k_msm_rows<0> against (roofline.alu.peak), measured in the run that reports it.  tools/mulbench.hip is the same loop.

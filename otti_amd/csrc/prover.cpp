@@ -72,7 +72,57 @@ static bool fixed_base_msm_on_device(const Gens &g, const Fr *s, size_t n, Pt &o
         return true;
     } catch (const Error &) { return false; }
 }
-static const bool g_hook_registered = [] { g_fixed_base_msm_hook = fixed_base_msm_on_device; return true; }();
+// the verifiers' variable-base sums over decompressed row commitments (spartan.h g_row_sum_*_hook): decompression starts when the
+// commitments are known, the LDS-bucket Pippenger (k_msm.hip k_msm_var) runs when the scalars are, the host recombines the windows
+struct RowSumJob { DevCtx *c; RowSumSlot *slot; size_t n; };
+static RowSumJob *row_sum_begin_on_device(const CPoint *C, size_t n) {
+    if (n < 256 || n > ((size_t)1 << 20)) return nullptr;        // a few points: the host's own Pippenger is faster than two launches
+    try {
+        DevCtx &c = DevCtx::get();
+        RowSumSlot *slot = nullptr;
+        for (RowSumSlot *s : c.row_slots) if (!s->busy) { slot = s; break; }
+        if (!slot) { if (c.row_slots.size() >= 8) return nullptr; c.row_slots.push_back(new RowSumSlot()); slot = c.row_slots.back(); }
+        if (slot->comp.n < 32 * n) { slot->comp.alloc(32 * n); slot->pts.alloc(n); slot->sc.alloc(n); }
+        if (!slot->bad.p) slot->bad.alloc(1);
+        static_assert(sizeof(CPoint) == 32, "compressed points are uploaded as they lie in the proof");
+        OTTI_HIP(hipMemcpyAsync(slot->comp.p, C, 32 * n, hipMemcpyHostToDevice, c.stream));
+        OTTI_HIP(hipMemsetAsync(slot->bad.p, 0, sizeof(unsigned), c.stream));
+        dev_decode_niels(c, slot->comp.p, n, slot->pts.p, slot->bad.p);
+        slot->busy = true;
+        return new RowSumJob{&c, slot, n};
+    } catch (const Error &) { return nullptr; }
+}
+static int row_sum_finish_on_device(RowSumJob *job, const Fr *s, Pt &out) {
+    std::unique_ptr<RowSumJob> own(job);
+    struct Free { RowSumSlot *s; ~Free() { s->busy = false; } } release{job->slot};
+    DevCtx &c = *job->c; RowSumSlot &S = *job->slot; const size_t n = job->n;
+    try {
+        if (!s) { OTTI_HIP(hipStreamSynchronize(c.stream)); return 0; }       // dropped: the decompression launch must not outlive the slot's lease
+        if (&c != &DevCtx::get()) throw Error(OTTI_ERR_INTERNAL, "row sum finished on another thread than it was begun on");
+        OTTI_HIP(hipMemcpyAsync(S.sc.p, s, n * sizeof(Fr), hipMemcpyHostToDevice, c.stream));
+        const size_t cap = 64 * ((n + 2047) / 2048);             // at most 51 windows (c = 5) x splits
+        if (S.out.n < cap) S.out.alloc(cap);
+        int W = 0, splits = 0;
+        const int cbits = dev_msm_var(c, S.pts.p, S.sc.p, n, S.out.p, S.out.n, &W, &splits);
+        std::vector<Pt> part((size_t)W * splits); unsigned bad = 0;
+        OTTI_HIP(hipMemcpyAsync(part.data(), S.out.p, part.size() * sizeof(Pt), hipMemcpyDeviceToHost, c.stream));
+        OTTI_HIP(hipMemcpyAsync(&bad, S.bad.p, sizeof bad, hipMemcpyDeviceToHost, c.stream));
+        OTTI_HIP(hipStreamSynchronize(c.stream));
+        if (bad) return OTTI_ERR_VERIFY_DECOMPRESS;
+        // sum_w 2^(c w) * (sum over splits): Horner from the top window, c doublings per step
+        Pt acc = pt_identity();
+        for (int w = W - 1; w >= 0; w--) {
+            if (w != W - 1) for (int k = 0; k < cbits; k++) acc = pt_dbl(acc);
+            for (int sp = 0; sp < splits; sp++) acc = pt_add(acc, part[(size_t)w * splits + sp]);
+        }
+        out = acc;
+        return 0;
+    } catch (const Error &) { (void)hipStreamSynchronize(c.stream); return -1; }     // the caller falls back to the host cores
+}
+static const bool g_hook_registered = [] {
+    g_fixed_base_msm_hook = fixed_base_msm_on_device; g_row_sum_begin_hook = row_sum_begin_on_device; g_row_sum_finish_hook = row_sum_finish_on_device;
+    return true;
+}();
 
 DeviceWitness::DeviceWitness(const Instance &I, const std::vector<Fr> &vars_padded, const std::vector<Fr> &inputs_) : inputs(inputs_) {
     DevCtx &c = DevCtx::get();

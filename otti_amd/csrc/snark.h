@@ -64,6 +64,16 @@ struct VerifyFail { int code; };
 Pt dec(const CPoint &c);                                     // throws VerifyFail{OTTI_ERR_VERIFY_DECOMPRESS}
 void require(bool ok);                                       // throws VerifyFail{OTTI_ERR_VERIFY_INTERNAL}
 Pt host_msm_wide(const Fr *sc, const Pt *pts, size_t n);
+// sum_i s[i] * decode(C[i]) over the row commitments of a polynomial commitment (PolyEvalProof::verify's C_LZ).  Construct it as soon as
+// the commitments are known (with a device their decompression starts right away, spartan.h RowSumBeginHook), call finish() when the
+// scalars are; without a device, or when it declines, both steps run on the host cores inside finish().  Throws VerifyFail.
+struct RowSum {
+    RowSumJob *job = nullptr; const CPoint *C; size_t n;
+    RowSum(const CPoint *C_, size_t n_);
+    RowSum(const RowSum &) = delete; RowSum &operator=(const RowSum &) = delete;
+    ~RowSum();
+    Pt finish(const Fr *s);
+};
 void dotproductlog_verify(const DotProductProofLog &pf, size_t n, const Gens &g, const PcView &v, Transcript &tr, const Fr *a, const CPoint &Cx, const CPoint &Cy);
 
 // GPU (snark_prover.cpp)

@@ -227,23 +227,13 @@ void pcbatch_verify(const ProductCircuitEvalProofBatched &pf, const std::vector<
     claims_out = claims;
 }
 // PolyEvalProof::verify_plain: the commitment opens to Zr (blind zero) at r
-void polyeval_verify_plain(const DotProductProofLog &pf, const PcSet &s, const Gens &g, const std::vector<Fr> &r, const Fr &Zr, const std::vector<CPoint> &comm, Transcript &tr) {
-    require(r.size() == s.num_vars && comm.size() == s.L && pf.L_vec.size() == ilog2(s.R));
+void polyeval_verify_plain(const DotProductProofLog &pf, const PcSet &s, const Gens &g, const std::vector<Fr> &r, const Fr &Zr, const std::vector<CPoint> &comm, RowSum &rows, Transcript &tr) {
+    require(r.size() == s.num_vars && comm.size() == s.L && rows.n == s.L && rows.C == comm.data() && pf.L_vec.size() == ilog2(s.R));
     CPoint C_Zr; { Term t = {s.g1, Zr}; g.commit_terms_c(C_Zr.b, &t, 1); }
     tr.append_protocol_name("polynomial evaluation proof");
     const size_t lv = s.num_vars / 2;
     std::vector<Fr> Lv = eq_evals_host(r.data(), lv), Rv = eq_evals_host(r.data() + lv, s.num_vars - lv);
-    std::vector<Pt> Cs(s.L);
-    {
-        const size_t nt = std::min<size_t>({s.L / 128 + 1, (size_t)16, (size_t)std::max(1u, std::thread::hardware_concurrency())});
-        std::vector<int> bad(nt, 0); std::vector<std::thread> th;
-        auto work = [&](size_t t) { try { for (size_t i = t; i < s.L; i += nt) Cs[i] = dec(comm[i]); } catch (const VerifyFail &f) { bad[t] = f.code; } };
-        for (size_t t = 1; t < nt; t++) th.emplace_back(work, t);
-        work(0);
-        for (auto &x : th) x.join();
-        for (int b : bad) if (b) throw VerifyFail{b};
-    }
-    CPoint C_LZ; pt_encode(C_LZ.b, host_msm_wide(Lv.data(), Cs.data(), s.L));
+    CPoint C_LZ; pt_encode(C_LZ.b, rows.finish(Lv.data()));
     const PcView pv = {s.h_n, s.g1, s.h1, s.R};
     dotproductlog_verify(pf, s.R, g, pv, tr, Rv.data(), C_LZ, C_Zr);
 }
@@ -266,6 +256,9 @@ void hash_verify_helper(const std::vector<Fr> &rand_mem, const Evals4 &claims, c
 // R1CSEvalProof::verify
 void evalproof_verify(const EvalProof &E, const CompComm &c, const std::vector<Fr> &rx, const std::vector<Fr> &ry, const Fr evals[3], const SnarkGens &g, Transcript &tr) {
     tr.append_protocol_name("Sparse polynomial evaluation proof");
+    // the three polynomial commitments whose rows the closing evaluation proofs sum are known now: with a device they decompress while
+    // the host verifies the layered sum-checks
+    RowSum rows_derefs(E.comm_derefs.data(), E.comm_derefs.size()), rows_ops(c.comm_ops.data(), c.comm_ops.size()), rows_mem(c.comm_mem.data(), c.comm_mem.size());
     const size_t nm = std::max(rx.size(), ry.size()), N = c.num_ops, M = c.num_mem_cells;
     std::vector<Fr> rxe(nm - rx.size(), fr_zero()), rye(nm - ry.size(), fr_zero());     // equalize: zeros in FRONT of the shorter point
     rxe.insert(rxe.end(), rx.begin(), rx.end()); rye.insert(rye.end(), ry.begin(), ry.end());
@@ -310,19 +303,19 @@ void evalproof_verify(const EvalProof &E, const CompComm &c, const std::vector<F
         std::vector<Fr> ev(8, fr_zero()), rj;
         for (int k = 0; k < 3; k++) { ev[k] = E.h_deref_row[k]; ev[3 + k] = E.h_deref_col[k]; }
         const Fr j = joint(ev, "evals_ops_val", "challenge_combine_n_to_one", "joint_claim_eval", rand_ops, rj);
-        polyeval_verify_plain(E.pe_derefs, g.derefs, *g.eval, rj, j, E.comm_derefs, tr);
+        polyeval_verify_plain(E.pe_derefs, g.derefs, *g.eval, rj, j, E.comm_derefs, rows_derefs, tr);
     }
     for (int k = 0; k < 3; k++) require(fr_eq(claims_dotp[3 * k], E.h_deref_row[k]) && fr_eq(claims_dotp[3 * k + 1], E.h_deref_col[k]) && fr_eq(claims_dotp[3 * k + 2], E.h_val[k]));
     {
         std::vector<Fr> ev(16, fr_zero()), rj;
         for (int k = 0; k < 3; k++) { ev[k] = E.h_row_addr[k]; ev[3 + k] = E.h_row_read_ts[k]; ev[6 + k] = E.h_col_addr[k]; ev[9 + k] = E.h_col_read_ts[k]; ev[12 + k] = E.h_val[k]; }
         const Fr j = joint(ev, "claim_evals_ops", "challenge_combine_n_to_one", "joint_claim_eval_ops", rand_ops, rj);
-        polyeval_verify_plain(E.pe_ops, g.ops, *g.eval, rj, j, c.comm_ops, tr);
+        polyeval_verify_plain(E.pe_ops, g.ops, *g.eval, rj, j, c.comm_ops, rows_ops, tr);
     }
     {
         std::vector<Fr> rj;
         const Fr j = joint({E.h_row_audit, E.h_col_audit}, "claim_evals_mem", "challenge_combine_two_to_one", "joint_claim_eval_mem", rand_mem, rj);
-        polyeval_verify_plain(E.pe_mem, g.mem, *g.eval, rj, j, c.comm_mem, tr);
+        polyeval_verify_plain(E.pe_mem, g.mem, *g.eval, rj, j, c.comm_mem, rows_mem, tr);
     }
     Evals4 crow, ccol;                                                // the product layer's claims at (rand_mem, rand_ops)
     crow.init = claims_mem[0]; crow.audit = claims_mem[1]; ccol.init = claims_mem[2]; ccol.audit = claims_mem[3];

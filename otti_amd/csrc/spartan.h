@@ -69,6 +69,7 @@ std::unique_ptr<Gens> gens_new(size_t num_cons, size_t num_vars, size_t num_inpu
 // sum_{i<n} s[i] * g.P[i] from g's resident device window table; false = not available (the caller computes it on the host)
 typedef bool (*FixedBaseMsmHook)(const Gens &g, const Fr *s, size_t n, Pt &out);
 extern FixedBaseMsmHook g_fixed_base_msm_hook;
+
 // a DotProductProofGens inside a generator stream: gens_n.G = P[0 .. R), gens_n.h = P[h_n], gens_1 = (P[g1], h = P[h1])
 struct PcView { uint32_t h_n, g1, h1; size_t R; };
 std::vector<Pt> derive_generators(const char *label, size_t count);      // MultiCommitGens::new stream
@@ -78,6 +79,17 @@ std::vector<Fr> eq_evals_host(const Fr *r, size_t ell);                  // EqPo
 // ---------------------------------------------------------------------------------------------- proof layout
 typedef uint8_t Cmp[32];
 struct CPoint { uint8_t b[32]; };
+// The verifiers' VARIABLE-base sums  sum_i s[i] * decode(C[i])  over the sqrt(V) row commitments of a polynomial commitment
+// (PolyEvalProof::verify: the points come from the proof / the computation commitment, so no table exists for them).  With a device:
+// begin() uploads the compressed points and starts their decompression at once — the commitments are known long before the
+// scalars, which depend on the last sum-check challenges — and finish() runs the LDS-bucket Pippenger over them (k_msm.hip
+// k_msm_var) and combines the windows on the host.  finish() returns 0, or OTTI_ERR_VERIFY_DECOMPRESS when a point does not decode
+// (what the host path reports); either call may decline (nullptr / negative) and the caller then does the work on the host cores.
+struct RowSumJob;
+typedef RowSumJob *(*RowSumBeginHook)(const CPoint *C, size_t n);
+typedef int (*RowSumFinishHook)(RowSumJob *job, const Fr *s, Pt &out);   // consumes the job (also on failure); s == nullptr: just drop it
+extern RowSumBeginHook g_row_sum_begin_hook;
+extern RowSumFinishHook g_row_sum_finish_hook;
 struct DotProductProof { CPoint delta, beta; std::vector<Fr> z; Fr z_delta, z_beta; };
 struct ZKSumcheckProof { std::vector<CPoint> comm_polys, comm_evals; std::vector<DotProductProof> proofs; };
 struct KnowledgeProof { CPoint alpha; Fr z1, z2; };

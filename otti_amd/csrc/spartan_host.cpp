@@ -394,6 +394,29 @@ Pt host_msm_wide(const Fr *sc, const Pt *pts, size_t n) {
     Pt acc = part[0]; for (size_t t = 1; t < nt; t++) acc = pt_add(acc, part[t]);
     return acc;
 }
+RowSumBeginHook g_row_sum_begin_hook = nullptr;
+RowSumFinishHook g_row_sum_finish_hook = nullptr;
+RowSum::RowSum(const CPoint *C_, size_t n_) : C(C_), n(n_) { if (g_row_sum_begin_hook && g_row_sum_finish_hook && !getenv("OTTI_VERIFY_HOST")) job = g_row_sum_begin_hook(C, n); }
+RowSum::~RowSum() { if (job) { Pt t; (void)g_row_sum_finish_hook(job, nullptr, t); } }
+Pt RowSum::finish(const Fr *s) {
+    if (job) {
+        Pt out; RowSumJob *j = job; job = nullptr;
+        const int rc = g_row_sum_finish_hook(j, s, out);
+        if (rc == 0) return out;
+        if (rc == OTTI_ERR_VERIFY_DECOMPRESS) throw VerifyFail{rc};
+    }
+    std::vector<Pt> Cs(n);
+    {   // decompression of the row commitments (an inverse square root each), striped over the host cores
+        const size_t nt = std::min<size_t>({n / 64 + 1, (size_t)16, (size_t)std::max(1u, std::thread::hardware_concurrency())});
+        std::vector<int> bad(nt, 0); std::vector<std::thread> th;
+        auto work = [&](size_t t) { try { for (size_t i = t; i < n; i += nt) Cs[i] = dec(C[i]); } catch (const VerifyFail &f) { bad[t] = f.code; } };
+        for (size_t t = 1; t < nt; t++) th.emplace_back(work, t);
+        work(0);
+        for (auto &x : th) x.join();
+        for (int b : bad) if (b) throw VerifyFail{b};
+    }
+    return host_msm_wide(s, Cs.data(), n);
+}
 using Deferred = std::vector<std::function<void()>>;
 void run_deferred(Deferred &d) {
     if (d.empty()) return;
@@ -527,6 +550,7 @@ int r1cs_verify_host(const NizkProof &P, size_t N, size_t V, const std::vector<F
         tr.append_message("poly_commitment", "poly_commitment_end", 19);
         std::vector<Fr> tau = tr.challenge_vector("challenge_tau", nrx);
         CPoint claim_phase1; pt_encode(claim_phase1.b, commit_scalar_pt(g, g.sc_1, fr_zero(), fr_zero()));
+        RowSum rows(P.comm_vars.data(), Lsz);                             // with a device: the row commitments start decompressing now
         Deferred later;                                                   // P, g and the CPoints it captures live until run_deferred below
         SpinPool::Session pool_session;
         const bool trace = getenv("OTTI_TRACE") != nullptr; auto t_lap = std::chrono::steady_clock::now();
@@ -553,18 +577,7 @@ int r1cs_verify_host(const NizkProof &P, size_t N, size_t V, const std::vector<F
             tr.append_protocol_name("polynomial evaluation proof");
             size_t rl = nry - 1, lv = rl / 2;
             std::vector<Fr> Lv = eq_evals_host(ry.data() + 1, lv), Rv = eq_evals_host(ry.data() + 1 + lv, rl - lv);
-            std::vector<Pt> Cs(Lsz);
-            {   // decompression of the row commitments (an inverse square root each), striped over the host cores
-                const size_t nt = std::min<size_t>({Lsz / 64 + 1, (size_t)8, (size_t)std::max(1u, std::thread::hardware_concurrency())});
-                std::vector<int> bad(nt, 0); std::vector<std::thread> th;
-                auto work = [&](size_t t) { try { for (size_t i = t; i < Lsz; i += nt) Cs[i] = dec(P.comm_vars[i]); } catch (const VerifyFail &f) { bad[t] = f.code; } };
-                for (size_t t = 1; t < nt; t++) th.emplace_back(work, t);
-                work(0);
-                for (auto &x : th) x.join();
-                for (int b : bad) if (b) throw VerifyFail{b};
-            }
-            lap("decompress row commitments");
-            CPoint C_LZ; pt_encode(C_LZ.b, host_msm_wide(Lv.data(), Cs.data(), Lsz));
+            CPoint C_LZ; pt_encode(C_LZ.b, rows.finish(Lv.data()));
             lap("C_LZ");
             require(P.polyeval.L_vec.size() == ilog2(Rsz));
             const PcView pv = {g.pc_n.h, g.pc_1.G[0], g.pc_1.h, Rsz};

@@ -177,3 +177,27 @@ def test_armed_round_released_aborted_and_reused(rng, n, hold_us):
     out, e = K.armed_selftest(A, B, r, hold_us)
     fa, fb = orc.fold_top(A, r), orc.fold_top(B, r)
     assert eq(out[0], fa) and eq(out[1], fb) and eq(e, orc.sc_quad_evals(fa, fb))
+
+
+# ------------------------------------------------------------------------------------------------ verifier: variable-base row sums (k_decode_niels, k_msm_var)
+@pytest.mark.parametrize("n,lgv", [(256, 16), (512, 18), (1024, 20), (2048, 22), (4096, 24)])
+def test_row_sum_on_device_equals_the_oracles_commitment(rng, n, lgv):
+    """PolyEvalProof::verify's C_LZ = sum_i L[i] * C_i on the device: batch decompression, LDS-bucket Pippenger (one and several splits,
+    c = 6 ... 9), host window recombination.  Points with a known answer: the generator stream itself, whose commitment the oracle forms
+    its own way (orc_commit_rows, one row, blind 0); scalars uniform with the special shapes the recoding must survive."""
+    og = orc.OGens(1 << lgv, 1 << lgv, 1)
+    assert og.R == n
+    C = og.points()[:n]
+    s = orc.rand_fr(rng, n)
+    special = orc.fr_from_ints([0, 1, orc.L_ORDER - 1, 255, 256, 2 ** 252, int("80" * 31, 16), 2 ** 128 - 1])
+    s[:len(special)] = special
+    want = orc.commit_rows(og, s, 1, n, orc.fr_from_ints([0]))
+    assert eq(K.row_sum(C, s), want[0])
+    z = orc.fr_from_ints([0] * n)                              # all-zero scalars: the identity
+    assert eq(K.row_sum(C, z), np.zeros(32, dtype=np.uint8))
+    bad = C.copy(); bad[n // 3] = np.frombuffer(bytes([1] + [0] * 31), dtype=np.uint8)     # s = 1 is odd: not a ristretto255 encoding
+    with pytest.raises(oa.ProofVerifyError):
+        K.row_sum(bad, s)
+    bad = C.copy(); bad[n - 1, 31] |= 0x80                     # non-canonical field element
+    with pytest.raises(oa.ProofVerifyError):
+        K.row_sum(bad, s)
