@@ -553,11 +553,22 @@ __global__ __launch_bounds__(kBlock) void k_msm_var(VarMsmArgs A) {
     const uint32_t i0 = blockIdx.y * A.chunk, n_here = min(A.chunk, A.n - i0), nb = 1u << (A.c - 1);
     for (uint32_t b = tid; b <= nb; b += kBlock) { s_start[b] = 0; if (b < nb) s_fill[b] = 0; }
     __syncthreads();
+    // The TOP window holds only the 253 - c (W - 1) leading bits of a scalar (often a single one) plus the recoding carry: few digit
+    // values, so few buckets would take all the points (one thread adding a thousand points in a row).  A window whose digits have at most
+    // vmax magnitudes therefore splits every bucket into m = #buckets / pow2(vmax) sub-buckets by point index: the lists stay ~8 long
+    // whatever the window, the sub-buckets of a digit are summed by a short tree, and the weighted sum runs over pow2(vmax) buckets.
+    const int top_bits = 253 - A.c * (A.W - 1);
+    const uint32_t vmax = (w == A.W - 1 && top_bits < A.c - 1) ? (1u << top_bits) + 1u : nb;
+    uint32_t V2 = 1; while (V2 < vmax) V2 <<= 1;
+    const uint32_t m = nb / V2;                                         // sub-buckets per digit magnitude (1 for the regular windows)
     for (uint32_t i = tid; i < n_here; i += kBlock) {
         uint32_t r9[9]; recode_scalar(r9, A.sc[i0 + i], A.K);
         const int d = recoded_digit(r9, w, A.c);
         uint16_t key = 0xffffu;
-        if (d) { const uint32_t mag = (uint32_t)(d < 0 ? -d : d); key = (uint16_t)((mag - 1) | (d < 0 ? 0x8000u : 0u)); atomicAdd(&s_start[mag], 1u); }   // counts land one slot up: the prefix below turns them into starts
+        if (d) {
+            const uint32_t mag = (uint32_t)(d < 0 ? -d : d), slot = (mag - 1) * m + (i & (m - 1));
+            key = (uint16_t)(slot | (d < 0 ? 0x8000u : 0u)); atomicAdd(&s_start[slot + 1], 1u);      // counts land one slot up: the prefix below turns them into starts
+        }
         s_key[i] = key;
     }
     __syncthreads();
@@ -581,18 +592,23 @@ __global__ __launch_bounds__(kBlock) void k_msm_var(VarMsmArgs A) {
         s_bkt[b] = acc;
     }
     __syncthreads();
-    // sum_b (b + 1) * B_b  (0-based b): suffix scan, then the sum of the suffix sums
     const F10 d2 = f10_const(fp_2D());
-    for (uint32_t off = 1; off < nb; off <<= 1) {
-        const bool have = (uint32_t)tid + off < nb;
-        P10 v = p10_identity();
-        if (have) v = s_bkt[tid + off];
-        __syncthreads();
-        if (have) s_bkt[tid] = p10_add(s_bkt[tid], v, d2);
+    // the sub-buckets of a digit: bucket v ends up at slot v * m
+    for (uint32_t sft = m >> 1; sft >= 1; sft >>= 1) {
+        if ((uint32_t)tid < nb && ((uint32_t)tid & (m - 1)) < sft) s_bkt[tid] = p10_add(s_bkt[tid], s_bkt[tid + sft], d2);
         __syncthreads();
     }
-    for (uint32_t sft = nb >> 1; sft >= 1; sft >>= 1) {
-        for (uint32_t b = tid; b < sft; b += kBlock) s_bkt[b] = p10_add(s_bkt[b], s_bkt[b + sft], d2);
+    // sum_v (v + 1) * B_v  (0-based v < V2, at stride m): suffix scan, then the sum of the suffix sums
+    for (uint32_t off = 1; off < V2; off <<= 1) {
+        const bool have = (uint32_t)tid + off < V2;
+        P10 v = p10_identity();
+        if (have) v = s_bkt[((uint32_t)tid + off) * m];
+        __syncthreads();
+        if (have) s_bkt[(uint32_t)tid * m] = p10_add(s_bkt[(uint32_t)tid * m], v, d2);
+        __syncthreads();
+    }
+    for (uint32_t sft = V2 >> 1; sft >= 1; sft >>= 1) {
+        if ((uint32_t)tid < sft) s_bkt[(uint32_t)tid * m] = p10_add(s_bkt[(uint32_t)tid * m], s_bkt[((uint32_t)tid + sft) * m], d2);
         __syncthreads();
     }
     if (tid == 0) A.out[(size_t)w * A.splits + blockIdx.y] = p10_pack(s_bkt[0]);

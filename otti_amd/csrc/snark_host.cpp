@@ -2,6 +2,7 @@
 #include "snark.h"
 #include <algorithm>
 #include <thread>
+#include <chrono>
 
 namespace otti {
 
@@ -229,11 +230,15 @@ void pcbatch_verify(const ProductCircuitEvalProofBatched &pf, const std::vector<
 // PolyEvalProof::verify_plain: the commitment opens to Zr (blind zero) at r
 void polyeval_verify_plain(const DotProductProofLog &pf, const PcSet &s, const Gens &g, const std::vector<Fr> &r, const Fr &Zr, const std::vector<CPoint> &comm, RowSum &rows, Transcript &tr) {
     require(r.size() == s.num_vars && comm.size() == s.L && rows.n == s.L && rows.C == comm.data() && pf.L_vec.size() == ilog2(s.R));
+    const auto t_b = std::chrono::steady_clock::now();
     CPoint C_Zr; { Term t = {s.g1, Zr}; g.commit_terms_c(C_Zr.b, &t, 1); }
+    if (getenv("OTTI_TRACE")) fprintf(stderr, "[otti]   polyeval_verify_plain: C_Zr %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_b).count());
     tr.append_protocol_name("polynomial evaluation proof");
     const size_t lv = s.num_vars / 2;
     std::vector<Fr> Lv = eq_evals_host(r.data(), lv), Rv = eq_evals_host(r.data() + lv, s.num_vars - lv);
+    static const bool trace = getenv("OTTI_TRACE") != nullptr; const auto t_a = std::chrono::steady_clock::now();
     CPoint C_LZ; pt_encode(C_LZ.b, rows.finish(Lv.data()));
+    if (trace) fprintf(stderr, "[otti]   polyeval_verify_plain: C_Zr + eq tables + row sum %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_a).count());
     const PcView pv = {s.h_n, s.g1, s.h1, s.R};
     dotproductlog_verify(pf, s.R, g, pv, tr, Rv.data(), C_LZ, C_Zr);
 }
@@ -255,6 +260,8 @@ void hash_verify_helper(const std::vector<Fr> &rand_mem, const Evals4 &claims, c
 }
 // R1CSEvalProof::verify
 void evalproof_verify(const EvalProof &E, const CompComm &c, const std::vector<Fr> &rx, const std::vector<Fr> &ry, const Fr evals[3], const SnarkGens &g, Transcript &tr) {
+    const bool trace = getenv("OTTI_TRACE") != nullptr; auto t_lap = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) { if (!trace) return; const auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[otti] evalproof_verify %-32s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t_lap).count()); t_lap = t; };
     tr.append_protocol_name("Sparse polynomial evaluation proof");
     // the three polynomial commitments whose rows the closing evaluation proofs sum are known now: with a device they decompress while
     // the host verifies the layered sum-checks
@@ -285,8 +292,11 @@ void evalproof_verify(const EvalProof &E, const CompComm &c, const std::vector<F
     }
     std::vector<Fr> claims_prod(12), claims_ops, claims_dotp, rand_ops, claims_mem, none, rand_mem;
     for (int k = 0; k < 3; k++) { claims_prod[k] = E.eval_row.read[k]; claims_prod[3 + k] = E.eval_row.write[k]; claims_prod[6 + k] = E.eval_col.read[k]; claims_prod[9 + k] = E.eval_col.write[k]; }
+    lap("commitments appended, jobs begun");
     pcbatch_verify(E.proof_ops, claims_prod, claims_dotp_circuit, N, tr, claims_ops, claims_dotp, rand_ops);
+    lap("batched layered sum-check: ops");
     pcbatch_verify(E.proof_mem, {E.eval_row.init, E.eval_row.audit, E.eval_col.init, E.eval_col.audit}, {}, M, tr, claims_mem, none, rand_mem);
+    lap("batched layered sum-check: mem");
     require(claims_dotp.size() == 9 && rand_mem.size() == nm);
     // ---- HashLayerProof::verify
     tr.append_protocol_name("Sparse polynomial hash layer proof");
@@ -304,6 +314,7 @@ void evalproof_verify(const EvalProof &E, const CompComm &c, const std::vector<F
         for (int k = 0; k < 3; k++) { ev[k] = E.h_deref_row[k]; ev[3 + k] = E.h_deref_col[k]; }
         const Fr j = joint(ev, "evals_ops_val", "challenge_combine_n_to_one", "joint_claim_eval", rand_ops, rj);
         polyeval_verify_plain(E.pe_derefs, g.derefs, *g.eval, rj, j, E.comm_derefs, rows_derefs, tr);
+        lap("polyeval derefs");
     }
     for (int k = 0; k < 3; k++) require(fr_eq(claims_dotp[3 * k], E.h_deref_row[k]) && fr_eq(claims_dotp[3 * k + 1], E.h_deref_col[k]) && fr_eq(claims_dotp[3 * k + 2], E.h_val[k]));
     {
@@ -311,11 +322,13 @@ void evalproof_verify(const EvalProof &E, const CompComm &c, const std::vector<F
         for (int k = 0; k < 3; k++) { ev[k] = E.h_row_addr[k]; ev[3 + k] = E.h_row_read_ts[k]; ev[6 + k] = E.h_col_addr[k]; ev[9 + k] = E.h_col_read_ts[k]; ev[12 + k] = E.h_val[k]; }
         const Fr j = joint(ev, "claim_evals_ops", "challenge_combine_n_to_one", "joint_claim_eval_ops", rand_ops, rj);
         polyeval_verify_plain(E.pe_ops, g.ops, *g.eval, rj, j, c.comm_ops, rows_ops, tr);
+        lap("polyeval ops");
     }
     {
         std::vector<Fr> rj;
         const Fr j = joint({E.h_row_audit, E.h_col_audit}, "claim_evals_mem", "challenge_combine_two_to_one", "joint_claim_eval_mem", rand_mem, rj);
         polyeval_verify_plain(E.pe_mem, g.mem, *g.eval, rj, j, c.comm_mem, rows_mem, tr);
+        lap("polyeval mem");
     }
     Evals4 crow, ccol;                                                // the product layer's claims at (rand_mem, rand_ops)
     crow.init = claims_mem[0]; crow.audit = claims_mem[1]; ccol.init = claims_mem[2]; ccol.audit = claims_mem[3];

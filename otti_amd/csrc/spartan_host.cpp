@@ -399,10 +399,13 @@ RowSumFinishHook g_row_sum_finish_hook = nullptr;
 RowSum::RowSum(const CPoint *C_, size_t n_) : C(C_), n(n_) { if (g_row_sum_begin_hook && g_row_sum_finish_hook && !getenv("OTTI_VERIFY_HOST")) job = g_row_sum_begin_hook(C, n); }
 RowSum::~RowSum() { if (job) { Pt t; (void)g_row_sum_finish_hook(job, nullptr, t); } }
 Pt RowSum::finish(const Fr *s) {
+    static const bool trace = getenv("OTTI_TRACE") != nullptr; const auto t0 = std::chrono::steady_clock::now();
+    struct Lap { bool on; std::chrono::steady_clock::time_point t0; size_t n; bool dev; ~Lap() { if (on) fprintf(stderr, "[otti]   row sum over %zu points (%s) %.3f ms\n", n, dev ? "device" : "host", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); } } lap{trace, t0, n, job != nullptr};
     if (job) {
         Pt out; RowSumJob *j = job; job = nullptr;
         const int rc = g_row_sum_finish_hook(j, s, out);
         if (rc == 0) return out;
+        lap.dev = false;
         if (rc == OTTI_ERR_VERIFY_DECOMPRESS) throw VerifyFail{rc};
     }
     std::vector<Pt> Cs(n);
@@ -527,13 +530,17 @@ void dotproductlog_verify(const DotProductProofLog &pf, size_t n, const Gens &g,
     require(v.R == n && g.P.size() >= n + 2);
     tr.append_protocol_name("dot product proof (log)");
     tr.append_point("Cx", Cx.b); tr.append_point("Cy", Cy.b);
+    static const bool trace = getenv("OTTI_TRACE") != nullptr; auto t_lap = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) { if (!trace) return; const auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[otti]   dotproductlog_verify n=%zu %-22s %.3f ms\n", n, what, std::chrono::duration<double, std::milli>(t - t_lap).count()); t_lap = t; };
     Pt Gamma = pt_add(dec(Cx), dec(Cy)), g_hat, Gamma_hat; Fr a_hat;
     bullet_verify(pf, n, a, tr, Gamma, g, g_hat, Gamma_hat, a_hat);
+    lap("bullet_verify");
     tr.append_point("delta", pf.delta.b); tr.append_point("beta", pf.beta.b);
     Fr c = tr.challenge_scalar("c");
     Pt lhs = pt_add(host_scalarmul(pt_add(host_scalarmul(Gamma_hat, c), dec(pf.beta)), a_hat), dec(pf.delta));
     Pt rhs = pt_add(host_scalarmul(pt_add(g_hat, host_scalarmul(g.P[v.g1], a_hat)), pf.z1), host_scalarmul(g.P[v.h1], pf.z2));
     require(pt_eq(lhs, rhs));
+    lap("closing equation");
 }
 // R1CSProof::verify: `tr` already carries the caller's protocol name (NIZK / SNARK); returns the challenges the transcript produced
 int r1cs_verify_host(const NizkProof &P, size_t N, size_t V, const std::vector<Fr> &inputs, const Fr inst_evals[3], const Gens &g, Transcript &tr,
