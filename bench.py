@@ -316,9 +316,12 @@ def main():
     gold = golden_digest("nizk", n) if (args.dist == "uniform" and (shard or world == 1)) else None
     digest_ok = None if gold is None else (gold["proof_sha256"] in digests)
     assert digest_ok is not False, "the timed proof differs from the oracle's committed digest for this size"
-    t0 = time.perf_counter()
-    proofs[-1].verify(inst, inputs, gens, label)
-    t_verify = time.perf_counter() - t0
+    t_verify_calls = []
+    for _ in range(3):                                       # the first call allocates the verifier's device buffers (kept with the context afterwards)
+        t0 = time.perf_counter()
+        proofs[-1].verify(inst, inputs, gens, label)
+        t_verify_calls.append(time.perf_counter() - t0)
+    t_verify = min(t_verify_calls)
     elapsed = max_over_ranks(elapsed)
     if shard:
         same_on_every_rank(proofs[-1].bytes, "ranks of a sharded proof returned different bytes")
@@ -612,7 +615,10 @@ def main():
         oa.stats_enable(False)
         sdig = {hashlib.sha256(p.bytes).hexdigest() for p in sp_list}
         assert len(sdig) == 1
-        t0 = time.perf_counter(); sp_list[-1].verify(oa.ComputationCommitment.from_bytes(scomm.bytes), inputs, sgens, slabel); t_sverify = time.perf_counter() - t0
+        vcomm = oa.ComputationCommitment.from_bytes(scomm.bytes); sv = []
+        for _ in range(3):
+            t0 = time.perf_counter(); sp_list[-1].verify(vcomm, inputs, sgens, slabel); sv.append(time.perf_counter() - t0)
+        t_sverify = min(sv)
         best = min(sms)
         sgold = golden_digest("snark", n) if args.dist == "uniform" else None
         s_ok = None if sgold is None else (sgold["proof_sha256"] in sdig and sgold["commitment_sha256"] == hashlib.sha256(scomm.bytes).hexdigest())
@@ -635,7 +641,7 @@ def main():
             cpu_s = {"value": round((1 << slg2) / ct3, 1), "unit": "constraints/s", "cores": orc.lib.orc_get_threads(), "kind": "port",
                      "sample": f"one SNARK::prove of the 2^{slg2} instance by the plain-C oracle, {ct3:.2f} s"}
         snark = {"value": round(n / (best * 1e-3), 1), "unit": "constraints/s", "ms_per_proof": round(best, 3), "encode_ms": round(1e3 * t_encode, 1),
-                 "verify_ms": round(1e3 * t_sverify, 2), "proof_bytes": len(sp_list[-1].bytes), "commitment_bytes": len(scomm.bytes),
+                 "verify_ms": round(1e3 * t_sverify, 2), "verify_first_call_ms": round(1e3 * sv[0], 2), "proof_bytes": len(sp_list[-1].bytes), "commitment_bytes": len(scomm.bytes),
                  "stage_ms": {k: round(v, 3) for k, v in sp_list[-1].stage_ms.items()}, "roofline": s_roof, "armed_launches": s_armed,
                  "kernel_ms_per_proof": {k: round(v[1], 3) for k, v in s_break.items() if v[0]}, "kernel_launches_per_proof": {k: v[0] for k, v in s_break.items() if v[0]},
                  "proof_sha256": next(iter(sdig)), "equals_oracle_digest": s_ok, "oracle_parity_2^12": sp2.bytes == op2, "cpu_baseline": cpu_s,
@@ -665,7 +671,7 @@ def main():
         "kernel_ms_per_proof": {k: round(v[1], 3) for k, v in breakdown.items() if v[0]},
         "kernel_launches_per_proof": {k: v[0] for k, v in breakdown.items() if v[0]},
         "whole_proof_algorithmic_GBps": round(proof_gbps, 2), "whole_proof_hbm_frac": round(proof_gbps / (HBM_PEAK_GBPS * (world if shard else 1)), 6),
-        "prepare_device_ms": round(1e3 * t_prepare, 1), "witness_upload_ms": round(1e3 * t_upload, 2), "verify_ms": round(1e3 * t_verify, 2),
+        "prepare_device_ms": round(1e3 * t_prepare, 1), "witness_upload_ms": round(1e3 * t_upload, 2), "verify_ms": round(1e3 * t_verify, 2), "verify_first_call_ms": round(1e3 * t_verify_calls[0], 2),
         "proof_bytes": len(final_proof), "proof_sha256": next(iter(digests)), "equals_oracle_digest": digest_ok, "oracle_parity_2^12": parity_ok,
         "wall_s": round(time.perf_counter() - t_start, 1),
     }

@@ -8,6 +8,8 @@
 #include <numeric>
 #include <thread>
 #include <functional>
+#include <atomic>
+#include <system_error>
 
 namespace otti {
 
@@ -420,18 +422,55 @@ Pt RowSum::finish(const Fr *s) {
     }
     return host_msm_wide(s, Cs.data(), n);
 }
-using Deferred = std::vector<std::function<void()>>;
-void run_deferred(Deferred &d) {
-    if (d.empty()) return;
-    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    const size_t nt = std::min<size_t>({d.size(), (size_t)8, (size_t)hw});
-    std::vector<int> codes(nt, 0); std::vector<std::thread> th;
-    auto work = [&](size_t t) { try { for (size_t i = t; i < d.size(); i += nt) d[i](); } catch (const VerifyFail &f) { codes[t] = f.code; } catch (...) { codes[t] = OTTI_ERR_VERIFY_INTERNAL; } };
-    for (size_t t = 1; t < nt; t++) th.emplace_back(work, t);
-    work(0);
-    for (auto &x : th) x.join();
-    for (int c : codes) if (c) throw VerifyFail{c};
-}
+// Group equations that do not feed the transcript — most of the verifier's arithmetic: per sum-check round two checks with a
+// variable-base scalar multiplication each — are handed to a few background threads AS THEY ARISE, while the calling thread walks on
+// through the rounds (whose hashed commitments are the sequential path); finish() drains what is left and reports the first failure.
+// Lock-free: the producer fills a slot and bumps `count`; workers claim slots with a compare-exchange on `next`.
+class Deferred {
+public:
+    Deferred() {
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        unsigned nw = hw >= 12 ? 6 : hw >= 6 ? hw - 3 : 0;                // beside the caller and its spinning helpers (pool.h)
+        if (const char *e = getenv("OTTI_VERIFY_THREADS")) { int v = atoi(e); if (v >= 0 && v <= 32) nw = (unsigned)v; }
+        try { for (unsigned i = 0; i < nw; i++) th_.emplace_back([this] { work(false); }); } catch (const std::system_error &) {}
+    }
+    Deferred(const Deferred &) = delete; Deferred &operator=(const Deferred &) = delete;
+    ~Deferred() { closing_.store(true, std::memory_order_release); for (auto &t : th_) t.join(); }
+    void push_back(std::function<void()> f) {
+        const size_t c = count_.load(std::memory_order_relaxed);
+        if (c >= kSlots) { run_one(f); return; }                          // (never in practice: two checks per round, at most 2 x 64 rounds + a few)
+        items_[c] = std::move(f);
+        count_.store(c + 1, std::memory_order_release);
+    }
+    void finish() {                                                       // throws VerifyFail
+        closing_.store(true, std::memory_order_release);
+        work(true);
+        for (auto &t : th_) t.join();
+        th_.clear();
+        if (const int c = code_.load()) throw VerifyFail{c};
+    }
+private:
+    static constexpr size_t kSlots = 512;
+    std::function<void()> items_[kSlots];
+    std::atomic<size_t> count_{0}, next_{0};
+    std::atomic<bool> closing_{false};
+    std::atomic<int> code_{0};
+    std::vector<std::thread> th_;
+    void run_one(const std::function<void()> &f) {
+        try { f(); } catch (const VerifyFail &e) { int z = 0; code_.compare_exchange_strong(z, e.code); } catch (...) { int z = 0; code_.compare_exchange_strong(z, (int)OTTI_ERR_VERIFY_INTERNAL); }
+    }
+    void work(bool until_empty) {
+        for (;;) {
+            size_t i = next_.load(std::memory_order_relaxed);
+            if (i < count_.load(std::memory_order_acquire)) { if (next_.compare_exchange_weak(i, i + 1, std::memory_order_acq_rel)) run_one(items_[i]); continue; }
+            if (until_empty || closing_.load(std::memory_order_acquire)) { if (next_.load() >= count_.load(std::memory_order_acquire)) return; continue; }
+#if defined(__x86_64__)
+            _mm_pause();
+#endif
+        }
+    }
+};
+void run_deferred(Deferred &d) { d.finish(); }
 
 void knowledge_verify(const KnowledgeProof &pf, const Gens &g, Transcript &tr, const CPoint &C, Deferred &later) {
     tr.append_protocol_name("knowledge proof");
