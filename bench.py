@@ -606,12 +606,16 @@ def main():
         sp_list.append(oa.SNARK.prove(inst, scomm, wit, None, sgens, slabel, seed))
         s_break = oa.stats_read()
         s_dom = max(s_break, key=lambda k: s_break[k][1])
-        oa.stats_enable(True, only=s_dom)
+        # the timed proofs run as a caller runs them (armed launches and the persistent sum-check tail on).  A class that has armed
+        # launches cannot be timed with them on (a waiting kernel's duration includes the host), so when such a class dominates its
+        # launch durations come from the instrumented proof above (nothing armed there), not from the timed proofs.
+        s_timed_stats = s_dom not in ("pc_round", "msm_small", "sc_cubic", "sc_quad")
+        oa.stats_enable(s_timed_stats, only=s_dom if s_timed_stats else None)
         s_armed = oa.armed_launches_on()
         sms = []
         for _ in range(3):
             t0 = time.perf_counter(); spf = oa.SNARK.prove(inst, scomm, wit, None, sgens, slabel, seed); sms.append(1e3 * (time.perf_counter() - t0)); sp_list.append(spf)
-        s_stats = dict(oa.stats_read())
+        s_stats = dict(oa.stats_read()) if s_timed_stats else dict(s_break)
         oa.stats_enable(False)
         sdig = {hashlib.sha256(p.bytes).hexdigest() for p in sp_list}
         assert len(sdig) == 1
@@ -625,6 +629,9 @@ def main():
         assert s_ok is not False, "SNARK commitment / proof differ from the oracle's committed digests for this size"
         Nz = 1 << max(1, (nz - 1).bit_length()); Mm = 1 << max((N - 1).bit_length(), (2 * V - 1).bit_length())
         s_roof = roofline_of(s_dom, s_stats, s_break, lambda c_: snark_class_bytes_per_proof(c_, N, V, nnz, Nz, Mm), 1)
+        if s_roof is not None:
+            s_roof.pop("alu", None)                            # (two window widths in one class here: the addition rate is the headline's figure)
+            s_roof["launch_durations_from"] = "the timed proofs" if s_timed_stats else "one instrumented proof with nothing armed (per-round launches, no persistent tail): the class has armed launches"
         # oracle parity at 2^12 and the CPU figure on a bounded sample (2^16: the oracle's SNARK prover is half a minute at 2^20)
         rs2 = oa.synth_r1cs(1 << 12, ni, 1)
         si2 = oa.Instance.new(1 << 12, 1 << 12, ni, rs2["A"], rs2["B"], rs2["C"]); sg2 = oa.SNARKGens.new(1 << 12, 1 << 12, ni, 1 << 12)

@@ -1,0 +1,44 @@
+"""bench.py's N > 1 line must be gradeable before a multi-GPU node shows up: the driver's own launch command rehearsed with two rank
+processes (GPU test: both share the box's one card, gloo bookkeeping — OTTI_BENCH_REHEARSE=1), and the rehearsal line kept under
+profiles/ checked for the same keys on the CPU."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _check_sharded_line(d, world):
+    assert d["n_gpus"] == world and d["scaling"] == "strong" and d["unit"] == "constraints/s" and d["value"] > 0
+    assert d["equals_oracle_digest"] in (True, None)
+    cb = d["cpu_baseline"]
+    assert cb and cb["value"] > 0 and cb["cores"] >= 1 and cb["kind"] == "port" and cb["proof_equals_gpu_proof"] is True
+    rf = d["roofline"]
+    assert rf and rf["kernel"] == "msm_rows" and 0 < rf["frac"] < 1 and rf["alu"]["peak_isa"] > rf["alu"]["achieved"] > 0
+    tr = d["transports"]
+    assert tr and tr["mailbox"]["ms_per_proof"] > 0                      # the mailbox always works; RCCL is timed, or its refusal recorded (two ranks on one card)
+    assert ("ms_per_proof" in tr["rccl"]) or tr["rccl"].get("error")
+    sw = {k: v for k, v in d["sweep"].items() if k.startswith("2^")}
+    assert sw and all(("skipped" in v) or (v["ms_per_proof"] > 0 and v["equals_oracle_digest"] in (True, None)) for v in sw.values())
+    assert "sharded over %d GPUs" % world in d["config"]["parallelism"]
+
+
+def test_committed_two_rank_rehearsal_line_carries_cpu_baseline_transports_and_sweep():
+    path = os.path.join(ROOT, "profiles", "r3_bench_rehearse_2ranks_one_gpu.json")
+    d = json.load(open(path))
+    _check_sharded_line(d, 2)
+    assert any(k in d["sweep"] for k in ("2^22", "2^24")), "the rehearsal kept under profiles/ covers north_star's target size"
+
+
+@pytest.mark.gpu
+def test_two_rank_rehearsal_of_the_drivers_command(tmp_path):
+    env = dict(os.environ); env["OTTI_BENCH_REHEARSE"] = "1"; env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29533",
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--log2-constraints", "16", "--sweep", "14", "--in-flight", "-1"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1]
+    _check_sharded_line(json.loads(line), 2)
