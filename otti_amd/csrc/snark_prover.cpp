@@ -176,6 +176,7 @@ ProductCircuitEvalProofBatched pcbatch_prove(DevCtx &c, Circuits &C, const std::
     static const bool tail_env = [] { const char *e = getenv("OTTI_PC_TAIL"); return !(e && e[0] == '0'); }();
     static const size_t tail_cap = [] { const char *e = getenv("OTTI_PC_TAIL_CAP"); size_t v = e ? (size_t)atoi(e) : 0; return (v >= 2 && v <= (size_t)kTailCap && !(v & (v - 1))) ? v : (size_t)kTailCap; }();
     const bool tail_ok = arm_ok && tail_env;
+    static const size_t pc_arm_max = [] { const char *e = getenv("OTTI_PC_ARM_MAX"); return e ? (size_t)atoll(e) : (size_t)1 << 22; }();     // (the sum-check kernels of the R1CS proof arm up to kArmMaxLen; here a round more or less ahead costs nothing else)
     SpinPool &pool = SpinPool::get();
     const int host_threads = std::min(8, pool.workers() + 1);
     static const bool trace = getenv("OTTI_TRACE") != nullptr;
@@ -219,7 +220,7 @@ ProductCircuitEvalProofBatched pcbatch_prove(DevCtx &c, Circuits &C, const std::
         };
         // launch k >= 1 folds by r_{k-1} and yields the sums of round k (k < ndev) or the exported tail (k == ndev).  Armed (device.h), it is
         // queued one round ahead and starts the moment the host publishes r_{k-1}.
-        auto armed = [&](size_t k) { return arm_ok && k >= 1 && k < k0 + (tail ? 0 : 1) && k <= ndev && (h >> (k - 1)) * (size_t)ni <= kArmMaxLen; };   // small grids only (device.h); never the tail's own launch
+        auto armed = [&](size_t k) { return arm_ok && k >= 1 && k < k0 + (tail ? 0 : 1) && k <= ndev && (h >> (k - 1)) * (size_t)ni <= pc_arm_max; };   // small grids only (device.h); never the tail's own launch
         std::vector<unsigned long long> tick(ndev + 2, 0);
         auto launch_tail = [&](const Fr *r) { tail_seq = dev_pc_tail(c, P, tailW, h >> k0, T, r, eq_src(nr - k0), kPcTailSlot); };
         auto launch_for = [&](size_t k, const Fr *r) {
