@@ -309,6 +309,7 @@ def main():
     stats = dict(oa.stats_read())
     oa.stats_enable(False)
     madd_peak = oa.madd_peak()                                 # the MSM's ALU roof, measured in this run (after the timed region)
+    frmul_peak = oa.fr_mul_peak()                              # the streaming kernels' second roof: Montgomery products in GF(l) per second
 
     # correctness of what was timed
     digests = {hashlib.sha256(p.bytes).hexdigest() for p in proofs}
@@ -534,6 +535,21 @@ def main():
     roofline = roofline_of(dom, stats, breakdown, lambda c_: class_bytes_per_proof(c_, N, V, nnz), world if shard else 1)
     if roofline is not None and world > 1:
         roofline["note"] = "N > 1: fixed to the class that dominates at N = 1 (the witness commitment), priced on this rank's 1/%d share of the scalars" % world
+    # ---- the second roof of the "streaming" classes: they carry 7-13 Montgomery products per 192 bytes, so the multiplier binds before HBM does.
+    # products per proof by the kernels' own arithmetic (k_sumcheck.hip, k_sparse.hip): phase one 7 per pair in the first round and 13 per
+    # quad in the fused fold + sums rounds (10 N in all); phase two 2 per pair, then 6 per quad (8 V over tables of 2 V); the two sparse
+    # products one per non-zero entry (+ 3 per output row for the fused combination); eq tables one per element written
+    products = {"sc_cubic": 10 * N, "sc_quad": 8 * (2 * V) // 2, "spmv": 2 * nnz + 3 * 2 * V, "eq": N + 2 * V}
+    field_mul = {"peak": round(frmul_peak / 1e9, 2), "unit": "G Montgomery products/s", "classes": {},
+                 "note": "peak = otti_bench_fr_mul_peak measured in this run (fr_mul chains in registers, every CU busy): 104 v_mad_u64_u32 + 104 carry adds + ~55 moves, "
+                         "shifts and the conditional subtraction = ~265 issue slots per product at ~4.8 cycles each — the instruction count binds, not the multiplier "
+                         "alone (its 32.6 T lane-ops/s would allow 313 G products/s); classes: products per proof / summed device time of the class in one instrumented proof "
+                         "(most launches of a sum-check are rounds too short to fill the chip, so the whole-proof rate sits far below the roof; profiles/*kbw* has the rates at size)"}
+    for cls, nprod in products.items():
+        if breakdown.get(cls, (0, 0))[0]:
+            rate = nprod / (world if shard else 1) / (breakdown[cls][1] * 1e-3)
+            field_mul["classes"][cls] = {"products_per_proof": int(nprod), "ms_per_proof": round(breakdown[cls][1], 3), "achieved": round(rate / 1e9, 2), "frac": round(rate / frmul_peak, 4),
+                                         "hbm_frac": round(class_bytes_per_proof(cls, N, V, nnz) / (world if shard else 1) / (breakdown[cls][1] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
     whole = algorithmic_bytes(N, V, nnz)
     proof_gbps = whole / (ms_per_step * 1e-3) / 1e9
 
@@ -684,6 +700,7 @@ def main():
                                   ("1 independent proof per GPU" if world > 1 else "single GPU"),
                    "msm_window_bits": cbits, "msm_table_GB": round(table_bytes / 1e9, 2), "armed_launches": armed_on},
         "roofline": roofline,
+        "field_mul": field_mul,
         "cpu_baseline": cpu_baseline,
         "transports": transports,
         "sweep": sweep,

@@ -256,6 +256,9 @@ int32_t otti_dev_stream_destroy(void *stream);
 /* the integer-ALU roof the bulk MSM is priced against: whole-chip throughput of its mixed point addition (operands in registers,
    every CU busy), measured now (about 10 ms of GPU time) */
 int32_t otti_bench_madd_peak(double *madds_per_second);
+/* the second roof of the streaming kernels (sum-check rounds, sparse products, eq tables): whole-chip throughput of the Montgomery
+   product in GF(l), operands in registers, measured now (about 10 ms of GPU time) */
+int32_t otti_bench_fr_mul_peak(double *products_per_second);
 
 /* per-kernel-class timing with HIP events recorded on the library's own stream around every launch of that class.
    classes: msm_rows (>= 2^16 scalars per launch: the witness commitment) msm_small msm_finish sc_cubic sc_quad spmv eq reduce poly_bound bullet other.  enable(1) also resets the counters. */

@@ -106,6 +106,7 @@ _sig("otti_bench_madd_peak", _i32, ctypes.POINTER(ctypes.c_double))
 _sig("otti_stats_enable", _i32, _i32)
 _sig("otti_stats_select", _i32, ctypes.c_char_p)
 _sig("otti_armed_launches_on", _i32, ctypes.POINTER(_i32))
+_sig("otti_bench_fr_mul_peak", _i32, ctypes.POINTER(ctypes.c_double))
 _sig("otti_stats_read", _i32, ctypes.c_char_p, ctypes.POINTER(_u64), ctypes.POINTER(ctypes.c_double))
 _sig("otti_lanes_pack", None, _vp, _sz, _vp)
 _sig("otti_lanes_unpack", None, _vp, _sz, _vp)
@@ -560,6 +561,13 @@ def stats_enable(on=True, only=None):
     _check(lib.otti_stats_enable(1 if on else 0))
     if on and only is not None:
         _check(lib.otti_stats_select(only.encode()))
+
+
+def fr_mul_peak():
+    """whole-chip Montgomery products in GF(l) per second (the streaming kernels' second roof), measured now"""
+    v = ctypes.c_double()
+    _check(lib.otti_bench_fr_mul_peak(ctypes.byref(v)))
+    return v.value
 
 
 def armed_launches_on():

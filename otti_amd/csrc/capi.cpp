@@ -776,6 +776,10 @@ int32_t otti_bench_madd_peak(double *madds_per_second) {
     return guarded([&] { if (!madds_per_second) throw Error(OTTI_ERR_BAD_ARG, "null argument"); *madds_per_second = dev_madd_peak(DevCtx::get()); return OTTI_OK; });
 }
 
+int32_t otti_bench_fr_mul_peak(double *products_per_second) {
+    return guarded([&] { if (!products_per_second) throw Error(OTTI_ERR_BAD_ARG, "null argument"); *products_per_second = dev_fr_mul_peak(DevCtx::get()); return OTTI_OK; });
+}
+
 // ------------------------------------------------------------------------------------------------ kernel timing (HIP events on the library stream)
 static const char *kClassNames[KC_COUNT] = {"msm_rows", "msm_small", "msm_finish", "sc_cubic", "sc_quad", "spmv", "eq", "reduce", "poly_bound", "bullet", "other",
                                                "pc_round", "prod_layer", "hash_layer", "gather", "dot_many", "decode", "msm_var"};

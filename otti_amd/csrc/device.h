@@ -241,6 +241,7 @@ unsigned long long dev_bullet_round(DevCtx &c, const DeviceGens &g, size_t R, si
 void dev_decode_niels(DevCtx &c, const uint8_t *compressed_dev, size_t n, Niels *out, unsigned *bad);
 int dev_msm_var(DevCtx &c, const Niels *pts, const Fr *scalars, size_t n, Pt *out, size_t out_cap, int *n_windows, int *n_splits);
 double dev_madd_peak(DevCtx &c);                                          // mixed point additions per second, whole chip (the MSM's ALU roof)
+double dev_fr_mul_peak(DevCtx &c);                                        // Montgomery products in GF(l) per second, whole chip (the streaming kernels' second roof)
 void dev_scale(DevCtx &c, const Fr *in, const Fr &k, Fr *out, size_t n);
 void dev_fill_one(DevCtx &c, Fr *p, size_t n);
 

@@ -48,6 +48,28 @@ size_t dev_witness_ingest(DevCtx &c, Fr *z, size_t n, size_t *n_small) {
     if (n_small) *n_small = (size_t)h[1];
     return (size_t)h[0];
 }
+// Whole-chip throughput of the Montgomery product in GF(l) (operands in registers, every CU busy): what the sum-check, sparse-product
+// and eq kernels are priced against beside the HBM roof — at 7-13 products per 192 bytes they are bounded by the multiplier first.
+__global__ __launch_bounds__(kBlock) void k_fr_mul_peak(Fr *io, int iters) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    Fr x = io[2 * i], y = io[2 * i + 1];
+    for (int k = 0; k < iters; k++) { x = fr_mul(x, y); y = fr_mul(y, x); }
+    io[2 * i] = fr_add(x, y);
+}
+double dev_fr_mul_peak(DevCtx &c) {
+    const int blocks = 2048, iters = 250; const size_t n = (size_t)blocks * kBlock;
+    DevBuf<Fr> io(2 * n);
+    dev_fill_one(c, io.p, 2 * n);
+    double best = 0;
+    for (int rep = 0; rep < 4; rep++) {                                  // the first launch warms up; best of the rest
+        OTTI_HIP(hipEventRecord(c.ev0, c.stream));
+        hipLaunchKernelGGL(k_fr_mul_peak, blocks, kBlock, 0, c.stream, io.p, iters);
+        OTTI_HIP(hipEventRecord(c.ev1, c.stream)); OTTI_HIP(hipEventSynchronize(c.ev1));
+        float ms = 0; OTTI_HIP(hipEventElapsedTime(&ms, c.ev0, c.ev1));
+        if (rep && ms > 0) best = std::max(best, 2.0 * (double)n * iters / (ms * 1e-3));
+    }
+    return best;
+}
 __global__ __launch_bounds__(kBlock) void k_gather_strided(const Fr *in, size_t stride, size_t offset, Fr *out, size_t n) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = in[i * stride + offset];
 }
