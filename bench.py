@@ -494,11 +494,16 @@ def main():
     parity_ok = sp.bytes == op
     del si, sg, sp
 
-    def traffic_of(kernel_name):
+    def traffic_of(kernel_name, snark_run=False):
         """HBM bytes of the kernel's largest launch from a SEPARATE rocprofv3 --pmc pass kept under profiles/ (never measured in this run)"""
-        for cand in ("r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json"):
+        for cand in (("r3_snark_pmc_traffic.json",) if snark_run else ("r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json")):
             try:
                 pm = json.load(open(os.path.join(ROOT, "profiles", cand)))
+                names = [k_.strip() for k_ in (kernel_name or "").split("/")]                     # a class may name two kernels: the first that was profiled
+                hit = next((k_ for k_ in names if k_ in pm["kernels"]), None)
+                if hit is None and names and names[0] + "<true>" in pm["kernels"]:
+                    hit = names[0] + "<true>"
+                kernel_name = hit
                 if lg == pm.get("log2_constraints", 20) and cbits == pm.get("msm_window_bits", 12) and kernel_name in pm["kernels"]:
                     return pm["kernels"][kernel_name]["traffic_bytes_corrected"], ("profiles/%s: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, largest launch "
                                                                                      "of the kernel (not measured in this run)" % cand)
@@ -506,7 +511,7 @@ def main():
                 pass
         return None, None
 
-    def roofline_of(dom_, stats_, breakdown_, bytes_fn, share):
+    def roofline_of(dom_, stats_, breakdown_, bytes_fn, share, snark_run=False):
         cnt, tot_ms = stats_[dom_]
         per_proof = breakdown_[dom_][0]                             # launches of that class in one proof
         if not (cnt and per_proof):
@@ -514,7 +519,7 @@ def main():
         avg_ms = tot_ms / cnt
         bytes_per_launch = bytes_fn(dom_) / per_proof / share
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-        traffic, traffic_src = traffic_of(KERNEL_NAMES.get(dom_))
+        traffic, traffic_src = traffic_of(KERNEL_NAMES.get(dom_), snark_run)
         rf = {"bound": "hbm", "kernel": dom_, "kernel_name": KERNEL_NAMES.get(dom_, dom_), "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
               "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic, "traffic_source": traffic_src, "launches": cnt,
               "launches_per_proof": per_proof, "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(bytes_per_launch),
@@ -660,7 +665,7 @@ def main():
         s_ok = None if sgold is None else (sgold["proof_sha256"] in sdig and sgold["commitment_sha256"] == hashlib.sha256(scomm.bytes).hexdigest())
         assert s_ok is not False, "SNARK commitment / proof differ from the oracle's committed digests for this size"
         Nz = 1 << max(1, (nz - 1).bit_length()); Mm = 1 << max((N - 1).bit_length(), (2 * V - 1).bit_length())
-        s_roof = roofline_of(s_dom, s_stats, s_break, lambda c_: snark_class_bytes_per_proof(c_, N, V, nnz, Nz, Mm), 1)
+        s_roof = roofline_of(s_dom, s_stats, s_break, lambda c_: snark_class_bytes_per_proof(c_, N, V, nnz, Nz, Mm), 1, snark_run=True)
         if s_roof is not None:
             s_roof.pop("alu", None)                            # (two window widths in one class here: the addition rate is the headline's figure)
             s_roof["launch_durations_from"] = "the timed proofs" if s_timed_stats else "one instrumented proof with nothing armed (per-round launches, no persistent tail): the class has armed launches"

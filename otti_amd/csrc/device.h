@@ -102,6 +102,7 @@ struct DevCtx {
     struct TailMail *h_tail = nullptr, *d_tail_alias = nullptr;   // per-workgroup mail lines of the persistent sum-check tail (snark_dev.h), pinned
     void ensure_tail_mail();
     void wait_tail(int n_groups, unsigned long long seq);     // spin until every line carries seq (same failure handling as wait_ticket)
+    void wait_tail_sums(int n_inst, int W, unsigned long long seq, Fr *sums);   // the same for a round's mails, summing the W partials of every instance as they arrive
     Armed arm_many(int count);                                // reserves `count` consecutive go() numbers for one persistent launch; .want = the first
     bool armed_ok() const;                                    // off under OTTI_ARMED=0, while kernel classes are being timed (a waiting kernel's duration includes the host), and
                                                               // while another proof is in flight in this process (a waiting grid holds wave slots the other proof's kernels could use: measured -15 % throughput with six in flight)

@@ -232,6 +232,23 @@ void DevCtx::wait_tail(int n_groups, unsigned long long want) {
         }
     }
 }
+// the same wait, adding up the W partial sums of every instance as its lines come in (lines a few ahead are prefetched: each is a fresh
+// cache line the device has just written, and 144 dependent misses in a row would cost more than the round's arithmetic)
+void DevCtx::wait_tail_sums(int n_inst, int W, unsigned long long want, Fr *sums /* [n_inst][3] */) {
+    const int n = n_inst * W;
+#if defined(__x86_64__)
+    for (int i = 0; i < n && i < 16; i++) { _mm_prefetch((const char *)&h_tail[i], _MM_HINT_T0); _mm_prefetch((const char *)&h_tail[i] + 64, _MM_HINT_T0); }
+#endif
+    for (int i = 0; i < n; i++) {
+#if defined(__x86_64__)
+        if (i + 16 < n) { _mm_prefetch((const char *)&h_tail[i + 16], _MM_HINT_T0); _mm_prefetch((const char *)&h_tail[i + 16] + 64, _MM_HINT_T0); }
+#endif
+        if (__atomic_load_n(&h_tail[i].seq, __ATOMIC_ACQUIRE) < want) { wait_tail(i + 1, want); }     // not in yet: the slow path (with its failure handling) up to this line
+        Fr *acc = sums + 3 * (i / W);
+        if (i % W == 0) { acc[0] = h_tail[i].s[0]; acc[1] = h_tail[i].s[1]; acc[2] = h_tail[i].s[2]; }
+        else { acc[0] = fr_add(acc[0], h_tail[i].s[0]); acc[1] = fr_add(acc[1], h_tail[i].s[1]); acc[2] = fr_add(acc[2], h_tail[i].s[2]); }
+    }
+}
 void DevCtx::wait_points(unsigned long long ticket) {
     if (!ticket) { sync(); return; }
     wait_ticket(ticket);

@@ -246,17 +246,16 @@ ProductCircuitEvalProofBatched pcbatch_prove(DevCtx &c, Circuits &C, const std::
                 // a round of the persistent launch: W partial sums per instance, in the workgroups' own mail lines; the eq table is a real
                 // third table there, so the sums already carry the bound variable's factor — only the factor of the rounds before k0 is missing
                 if (j == k0) cj_tail = cj;
+                Fr inst_sums[3 * kMaxInst];
                 {
                     const double tw = trace ? now_ms() : 0;
                     if (trace) { c.wait_tail(1, tail_seq + (j - k0)); tr_tail_first_ms += now_ms() - tw; }     // (trace only: when the first line is in)
-                    c.wait_tail(ni * tailW, tail_seq + (j - k0));
+                    c.wait_tail_sums(ni, tailW, tail_seq + (j - k0), inst_sums);
                     if (trace) tr_tail_wait_ms += now_ms() - tw;
                 }
                 Fr p0 = fr_zero(), p2 = fr_zero(), p3 = fr_zero();
                 for (int k = 0; k < ni; k++) {
-                    const TailMail *m = c.h_tail + (size_t)k * tailW;
-                    Fr s0 = m[0].s[0], s2 = m[0].s[1], s3 = m[0].s[2];
-                    for (int w = 1; w < tailW; w++) { s0 = fr_add(s0, m[w].s[0]); s2 = fr_add(s2, m[w].s[1]); s3 = fr_add(s3, m[w].s[2]); }
+                    const Fr &s0 = inst_sums[3 * k], &s2 = inst_sums[3 * k + 1], &s3 = inst_sums[3 * k + 2];
                     Fr &a0 = k < np ? p0 : c0, &a2 = k < np ? p2 : c2, &a3 = k < np ? p3 : c3;
                     a0 = fr_add(a0, fr_mul(s0, coeff[k])); a2 = fr_add(a2, fr_mul(s2, coeff[k])); a3 = fr_add(a3, fr_mul(s3, coeff[k]));
                 }

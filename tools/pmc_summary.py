@@ -8,7 +8,9 @@ import json
 import sys
 
 KERNELS = ("k_msm_rows<0>", "k_msm_small", "k_msm_rows<2>", "k_sc_cubic3_fold_eval", "k_sc_quad_fold_eval", "k_sc_cubic3_eval", "k_sc_quad_eval", "k_spmv3_light", "k_eq_expand",
-           "k_poly_bound_slab", "k_gather_strided")
+           "k_poly_bound_slab", "k_gather_strided",
+           # SNARK mode (k_snark.hip) and the verifier's kernels
+           "k_pc_round<true>", "k_pc_round<false>", "k_pc_tail", "k_prod_layer", "k_hash_ops", "k_hash_mem", "k_gather", "k_dot_many", "k_sum3", "k_msm_var", "k_decode_niels")
 
 
 def load(path, counter):
@@ -35,8 +37,8 @@ def main():
         if best:
             out[k] = {"largest_launch_FETCH_SIZE_KiB": best[0], "largest_launch_WRITE_SIZE_KiB": best[1],
                       "traffic_bytes_corrected": int((2 * best[0] + best[1]) * 1024)}
-    json.dump({"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python3 bench.py --steps 1 --warmup 1 --in-flight -1 --no-e2e "
-                       "--no-cpu-baseline` (2^20; window width in msm_window_bits). Unit of the counters: KiB. gfx950 correction (MI355X guide): FETCH_SIZE reports half of the "
+    json.dump({"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over the same command (tools/profile_round3.sh: bench.py for the NIZK kernels, "
+                       "tools/snark_probe.py for SNARK mode; 2^20; window width in msm_window_bits). Unit of the counters: KiB. gfx950 correction (MI355X guide): FETCH_SIZE reports half of the "
                        "bytes of wide coalesced 16-B-per-lane reads, so it is doubled; for the scattered 16-B loads of the window-table gathers that "
                        "factor is not calibrated and the corrected figure is an upper estimate.",
                "msm_window_bits": int(sys.argv[4]) if len(sys.argv) > 4 else 12, "log2_constraints": int(sys.argv[5]) if len(sys.argv) > 5 else 20,
