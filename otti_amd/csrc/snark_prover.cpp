@@ -409,14 +409,12 @@ std::vector<uint8_t> snark_prove_resident(Instance &I, CompComm &comm, DeviceWit
     tr.append_protocol_name("Spartan SNARK proof");
     snark_append_comm(tr, comm);
     { ProveTimings pt{}; r1cs_prove_device(I, wit, *g.sat, tr, tape, S.r1cs, pt, nullptr); for (int k = 0; k < 6; k++) T.ms[k] = pt.ms[k]; }
-    instance_evaluate_gpu(I, S.r1cs.rx, S.r1cs.ry, S.inst_evals);                // inst.evaluate(rx, ry)
-    lap("r1cs proof + inst.evaluate");
-    tr.append_scalar("Ar_claim", S.inst_evals[0]); tr.append_scalar("Br_claim", S.inst_evals[1]); tr.append_scalar("Cr_claim", S.inst_evals[2]);
-
-    // ---- R1CSEvalProof::prove -> SparseMatPolyEvalProof::prove
+    lap("r1cs proof");
+    // inst.evaluate(rx, ry) is not computed by a sparse product of its own: M(rx, ry) = sum_i val_i eq(rx)[row_i] eq(ry)[col_i] is exactly
+    // the dot product of the dereferenced vectors the evaluation proof needs anyway (its two halves are E.dotp_left / dotp_right below),
+    // so the eq tables, the gathers and one launch of six sums come first and serve both.
     EvalProof &E = S.eval;
     t0 = now_ms();
-    tr.append_protocol_name("Sparse polynomial evaluation proof");
     const std::vector<Fr> &rx = S.r1cs.rx, &ry = S.r1cs.ry;
     const size_t nm = std::max(rx.size(), ry.size());
     if (((size_t)1 << nm) != M) throw Error(OTTI_ERR_INTERNAL, "memory size does not match the evaluation point");
@@ -434,7 +432,19 @@ std::vector<uint8_t> snark_prove_resident(Instance &I, CompComm &comm, DeviceWit
     auto dcol = [&](int k) { return derefs.p + (size_t)(3 + k) * N; };
     lap("allocations, eq tables");
     for (int k = 0; k < 3; k++) { dev_gather(c, mem_rx.p, d.row_addr[k].p, drow(k), N); dev_gather(c, mem_ry.p, d.col_addr[k].p, dcol(k), N); }
-    lap("deref gathers");
+    std::vector<Fr> dotp_evals(6);
+    {
+        AbcList A; A.n = 6;
+        for (int k = 0; k < 3; k++) for (int half = 0; half < 2; half++) { A.A[2 * k + half] = drow(k) + half * H; A.B[2 * k + half] = dcol(k) + half * H; A.C[2 * k + half] = d.part(4, k) + half * H; }
+        dev_sum3(c, A, H, partials.p, kSumSlot + 40);
+        c.sync();
+        for (int i = 0; i < 6; i++) dotp_evals[i] = c.h_results[kSumSlot + 40 + i];
+        for (int k = 0; k < 3; k++) S.inst_evals[k] = fr_add(dotp_evals[2 * k], dotp_evals[2 * k + 1]);
+    }
+    lap("deref gathers, inst.evaluate");
+    tr.append_scalar("Ar_claim", S.inst_evals[0]); tr.append_scalar("Br_claim", S.inst_evals[1]); tr.append_scalar("Cr_claim", S.inst_evals[2]);
+    // ---- R1CSEvalProof::prove -> SparseMatPolyEvalProof::prove
+    tr.append_protocol_name("Sparse polynomial evaluation proof");
     E.comm_derefs = commit_poly(c, *g.eval, derefs.p, g.derefs, 0);      // values of eq tables: uniform field elements
     tr.append_message("derefs_commitment", "begin_derefs_commitment", 23);
     append_poly_commitment(tr, "comm_poly_row_col_ops_val", E.comm_derefs);
@@ -470,18 +480,15 @@ std::vector<uint8_t> snark_prove_resident(Instance &I, CompComm &comm, DeviceWit
     // PolyEvalNetworkProof::prove / ProductLayerProof::prove
     tr.append_protocol_name("Sparse polynomial evaluation proof");
     tr.append_protocol_name("Sparse polynomial product layer proof");
-    std::vector<Fr> ops_evals(12), mem_evals(4), dotp_evals(6);
-    {   // circuit outputs (left * right of the top layer) and the dot-product claims
+    std::vector<Fr> ops_evals(12), mem_evals(4);
+    {   // circuit outputs (left * right of the top layer); the dot-product claims were summed above
         PtrList pick; pick.n = 0;
         for (int i = 0; i < 12; i++) { pick.p[pick.n++] = ops.left(i, ops.nl - 1); pick.p[pick.n++] = ops.right(i, ops.nl - 1); }
         for (int i = 0; i < 4; i++) { pick.p[pick.n++] = mem.left(i, mem.nl - 1); pick.p[pick.n++] = mem.right(i, mem.nl - 1); }
         dev_pick0(c, pick, kSumSlot);
-        AbcList A; A.n = 6; for (int i = 0; i < 6; i++) { A.A[i] = D.l[i]; A.B[i] = D.r[i]; A.C[i] = D.w[i]; }
-        dev_sum3(c, A, H, partials.p, kSumSlot + 40);
         c.sync();
         for (int i = 0; i < 12; i++) ops_evals[i] = fr_mul(c.h_results[kSumSlot + 2 * i], c.h_results[kSumSlot + 2 * i + 1]);
         for (int i = 0; i < 4; i++) mem_evals[i] = fr_mul(c.h_results[kSumSlot + 24 + 2 * i], c.h_results[kSumSlot + 24 + 2 * i + 1]);
-        for (int i = 0; i < 6; i++) dotp_evals[i] = c.h_results[kSumSlot + 40 + i];
     }
     E.eval_row.init = mem_evals[0]; E.eval_row.audit = mem_evals[1]; E.eval_col.init = mem_evals[2]; E.eval_col.audit = mem_evals[3];
     for (int k = 0; k < 3; k++) { E.eval_row.read[k] = ops_evals[k]; E.eval_row.write[k] = ops_evals[3 + k]; E.eval_col.read[k] = ops_evals[6 + k]; E.eval_col.write[k] = ops_evals[9 + k]; }
