@@ -6,6 +6,15 @@
 // k_snark.hip; the R1CS satisfiability proof inside it is the same device code as NIZK mode (prover.cpp r1cs_prove_device).
 #pragma once
 #include "spartan.h"
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
+#include <algorithm>
+#include <vector>
+#include <system_error>
+#include <functional>
+#include <thread>
+#include <atomic>
 
 namespace otti {
 
@@ -74,7 +83,55 @@ struct RowSum {
     ~RowSum();
     Pt finish(const Fr *s);
 };
-void dotproductlog_verify(const DotProductProofLog &pf, size_t n, const Gens &g, const PcView &v, Transcript &tr, const Fr *a, const CPoint &Cx, const CPoint &Cy);
+// Group equations that do not feed the transcript — most of the verifier's arithmetic: per sum-check round two checks with a
+// variable-base scalar multiplication each — are handed to a few background threads AS THEY ARISE, while the calling thread walks on
+// through the rounds (whose hashed commitments are the sequential path); finish() drains what is left and reports the first failure.
+// Lock-free: the producer fills a slot and bumps `count`; workers claim slots with a compare-exchange on `next`.
+class Deferred {
+public:
+    Deferred() {
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        unsigned nw = hw >= 12 ? 6 : hw >= 6 ? hw - 3 : 0;                // beside the caller and its spinning helpers (pool.h)
+        if (const char *e = getenv("OTTI_VERIFY_THREADS")) { int v = atoi(e); if (v >= 0 && v <= 32) nw = (unsigned)v; }
+        try { for (unsigned i = 0; i < nw; i++) th_.emplace_back([this] { work(false); }); } catch (const std::system_error &) {}
+    }
+    Deferred(const Deferred &) = delete; Deferred &operator=(const Deferred &) = delete;
+    ~Deferred() { closing_.store(true, std::memory_order_release); for (auto &t : th_) t.join(); }
+    void push_back(std::function<void()> f) {
+        const size_t c = count_.load(std::memory_order_relaxed);
+        if (c >= kSlots) { run_one(f); return; }                          // (never in practice: two checks per round, at most 2 x 64 rounds + a few)
+        items_[c] = std::move(f);
+        count_.store(c + 1, std::memory_order_release);
+    }
+    void finish() {                                                       // throws VerifyFail
+        closing_.store(true, std::memory_order_release);
+        work(true);
+        for (auto &t : th_) t.join();
+        th_.clear();
+        if (const int c = code_.load()) throw VerifyFail{c};
+    }
+private:
+    static constexpr size_t kSlots = 512;
+    std::function<void()> items_[kSlots];
+    std::atomic<size_t> count_{0}, next_{0};
+    std::atomic<bool> closing_{false};
+    std::atomic<int> code_{0};
+    std::vector<std::thread> th_;
+    void run_one(const std::function<void()> &f) {
+        try { f(); } catch (const VerifyFail &e) { int z = 0; code_.compare_exchange_strong(z, e.code); } catch (...) { int z = 0; code_.compare_exchange_strong(z, (int)OTTI_ERR_VERIFY_INTERNAL); }
+    }
+    void work(bool until_empty) {
+        for (;;) {
+            size_t i = next_.load(std::memory_order_relaxed);
+            if (i < count_.load(std::memory_order_acquire)) { if (next_.compare_exchange_weak(i, i + 1, std::memory_order_acq_rel)) run_one(items_[i]); continue; }
+            if (until_empty || closing_.load(std::memory_order_acquire)) { if (next_.load() >= count_.load(std::memory_order_acquire)) return; continue; }
+#if defined(__x86_64__)
+            _mm_pause();
+#endif
+        }
+    }
+};
+void dotproductlog_verify(const DotProductProofLog &pf, size_t n, const Gens &g, const PcView &v, Transcript &tr, const Fr *a, const CPoint &Cx, const CPoint &Cy, Deferred *later = nullptr);
 
 // GPU (snark_prover.cpp)
 struct SnarkTimings { double ms[10]; };                      // the six R1CSProof stages, [6] derefs commitment, [7] product circuits, [8] hash layer, [9] total

@@ -228,7 +228,8 @@ void pcbatch_verify(const ProductCircuitEvalProofBatched &pf, const std::vector<
     claims_out = claims;
 }
 // PolyEvalProof::verify_plain: the commitment opens to Zr (blind zero) at r
-void polyeval_verify_plain(const DotProductProofLog &pf, const PcSet &s, const Gens &g, const std::vector<Fr> &r, const Fr &Zr, const std::vector<CPoint> &comm, RowSum &rows, Transcript &tr) {
+void polyeval_verify_plain(const DotProductProofLog &pf, const PcSet &s, const Gens &g, const std::vector<Fr> &r, const Fr &Zr, const std::vector<CPoint> &comm, RowSum &rows, Transcript &tr,
+                           Deferred &later) {
     require(r.size() == s.num_vars && comm.size() == s.L && rows.n == s.L && rows.C == comm.data() && pf.L_vec.size() == ilog2(s.R));
     const auto t_b = std::chrono::steady_clock::now();
     CPoint C_Zr; { Term t = {s.g1, Zr}; g.commit_terms_c(C_Zr.b, &t, 1); }
@@ -240,7 +241,7 @@ void polyeval_verify_plain(const DotProductProofLog &pf, const PcSet &s, const G
     CPoint C_LZ; pt_encode(C_LZ.b, rows.finish(Lv.data()));
     if (trace) fprintf(stderr, "[otti]   polyeval_verify_plain: C_Zr + eq tables + row sum %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_a).count());
     const PcView pv = {s.h_n, s.g1, s.h1, s.R};
-    dotproductlog_verify(pf, s.R, g, pv, tr, Rv.data(), C_LZ, C_Zr);
+    dotproductlog_verify(pf, s.R, g, pv, tr, Rv.data(), C_LZ, C_Zr, &later);
 }
 // HashLayerProof::verify_helper
 void hash_verify_helper(const std::vector<Fr> &rand_mem, const Evals4 &claims, const Fr ops_val[3], const Fr ops_addr[3], const Fr read_ts[3], const Fr &audit_ts,
@@ -266,6 +267,7 @@ void evalproof_verify(const EvalProof &E, const CompComm &c, const std::vector<F
     // the three polynomial commitments whose rows the closing evaluation proofs sum are known now: with a device they decompress while
     // the host verifies the layered sum-checks
     RowSum rows_derefs(E.comm_derefs.data(), E.comm_derefs.size()), rows_ops(c.comm_ops.data(), c.comm_ops.size()), rows_mem(c.comm_mem.data(), c.comm_mem.size());
+    Deferred later;                                                   // the closing group equations of the three evaluation proofs run beside the rest
     const size_t nm = std::max(rx.size(), ry.size()), N = c.num_ops, M = c.num_mem_cells;
     std::vector<Fr> rxe(nm - rx.size(), fr_zero()), rye(nm - ry.size(), fr_zero());     // equalize: zeros in FRONT of the shorter point
     rxe.insert(rxe.end(), rx.begin(), rx.end()); rye.insert(rye.end(), ry.begin(), ry.end());
@@ -313,7 +315,7 @@ void evalproof_verify(const EvalProof &E, const CompComm &c, const std::vector<F
         std::vector<Fr> ev(8, fr_zero()), rj;
         for (int k = 0; k < 3; k++) { ev[k] = E.h_deref_row[k]; ev[3 + k] = E.h_deref_col[k]; }
         const Fr j = joint(ev, "evals_ops_val", "challenge_combine_n_to_one", "joint_claim_eval", rand_ops, rj);
-        polyeval_verify_plain(E.pe_derefs, g.derefs, *g.eval, rj, j, E.comm_derefs, rows_derefs, tr);
+        polyeval_verify_plain(E.pe_derefs, g.derefs, *g.eval, rj, j, E.comm_derefs, rows_derefs, tr, later);
         lap("polyeval derefs");
     }
     for (int k = 0; k < 3; k++) require(fr_eq(claims_dotp[3 * k], E.h_deref_row[k]) && fr_eq(claims_dotp[3 * k + 1], E.h_deref_col[k]) && fr_eq(claims_dotp[3 * k + 2], E.h_val[k]));
@@ -321,13 +323,13 @@ void evalproof_verify(const EvalProof &E, const CompComm &c, const std::vector<F
         std::vector<Fr> ev(16, fr_zero()), rj;
         for (int k = 0; k < 3; k++) { ev[k] = E.h_row_addr[k]; ev[3 + k] = E.h_row_read_ts[k]; ev[6 + k] = E.h_col_addr[k]; ev[9 + k] = E.h_col_read_ts[k]; ev[12 + k] = E.h_val[k]; }
         const Fr j = joint(ev, "claim_evals_ops", "challenge_combine_n_to_one", "joint_claim_eval_ops", rand_ops, rj);
-        polyeval_verify_plain(E.pe_ops, g.ops, *g.eval, rj, j, c.comm_ops, rows_ops, tr);
+        polyeval_verify_plain(E.pe_ops, g.ops, *g.eval, rj, j, c.comm_ops, rows_ops, tr, later);
         lap("polyeval ops");
     }
     {
         std::vector<Fr> rj;
         const Fr j = joint({E.h_row_audit, E.h_col_audit}, "claim_evals_mem", "challenge_combine_two_to_one", "joint_claim_eval_mem", rand_mem, rj);
-        polyeval_verify_plain(E.pe_mem, g.mem, *g.eval, rj, j, c.comm_mem, rows_mem, tr);
+        polyeval_verify_plain(E.pe_mem, g.mem, *g.eval, rj, j, c.comm_mem, rows_mem, tr, later);
         lap("polyeval mem");
     }
     Evals4 crow, ccol;                                                // the product layer's claims at (rand_mem, rand_ops)
@@ -335,6 +337,7 @@ void evalproof_verify(const EvalProof &E, const CompComm &c, const std::vector<F
     for (int k = 0; k < 3; k++) { crow.read[k] = claims_ops[k]; crow.write[k] = claims_ops[3 + k]; ccol.read[k] = claims_ops[6 + k]; ccol.write[k] = claims_ops[9 + k]; }
     hash_verify_helper(rand_mem, crow, E.h_deref_row, E.h_row_addr, E.h_row_read_ts, E.h_row_audit, rxe, r_mem_check[0], r_mem_check[1]);
     hash_verify_helper(rand_mem, ccol, E.h_deref_col, E.h_col_addr, E.h_col_read_ts, E.h_col_audit, rye, r_mem_check[0], r_mem_check[1]);
+    later.finish();
 }
 }  // namespace
 

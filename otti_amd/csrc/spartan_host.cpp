@@ -422,54 +422,6 @@ Pt RowSum::finish(const Fr *s) {
     }
     return host_msm_wide(s, Cs.data(), n);
 }
-// Group equations that do not feed the transcript — most of the verifier's arithmetic: per sum-check round two checks with a
-// variable-base scalar multiplication each — are handed to a few background threads AS THEY ARISE, while the calling thread walks on
-// through the rounds (whose hashed commitments are the sequential path); finish() drains what is left and reports the first failure.
-// Lock-free: the producer fills a slot and bumps `count`; workers claim slots with a compare-exchange on `next`.
-class Deferred {
-public:
-    Deferred() {
-        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-        unsigned nw = hw >= 12 ? 6 : hw >= 6 ? hw - 3 : 0;                // beside the caller and its spinning helpers (pool.h)
-        if (const char *e = getenv("OTTI_VERIFY_THREADS")) { int v = atoi(e); if (v >= 0 && v <= 32) nw = (unsigned)v; }
-        try { for (unsigned i = 0; i < nw; i++) th_.emplace_back([this] { work(false); }); } catch (const std::system_error &) {}
-    }
-    Deferred(const Deferred &) = delete; Deferred &operator=(const Deferred &) = delete;
-    ~Deferred() { closing_.store(true, std::memory_order_release); for (auto &t : th_) t.join(); }
-    void push_back(std::function<void()> f) {
-        const size_t c = count_.load(std::memory_order_relaxed);
-        if (c >= kSlots) { run_one(f); return; }                          // (never in practice: two checks per round, at most 2 x 64 rounds + a few)
-        items_[c] = std::move(f);
-        count_.store(c + 1, std::memory_order_release);
-    }
-    void finish() {                                                       // throws VerifyFail
-        closing_.store(true, std::memory_order_release);
-        work(true);
-        for (auto &t : th_) t.join();
-        th_.clear();
-        if (const int c = code_.load()) throw VerifyFail{c};
-    }
-private:
-    static constexpr size_t kSlots = 512;
-    std::function<void()> items_[kSlots];
-    std::atomic<size_t> count_{0}, next_{0};
-    std::atomic<bool> closing_{false};
-    std::atomic<int> code_{0};
-    std::vector<std::thread> th_;
-    void run_one(const std::function<void()> &f) {
-        try { f(); } catch (const VerifyFail &e) { int z = 0; code_.compare_exchange_strong(z, e.code); } catch (...) { int z = 0; code_.compare_exchange_strong(z, (int)OTTI_ERR_VERIFY_INTERNAL); }
-    }
-    void work(bool until_empty) {
-        for (;;) {
-            size_t i = next_.load(std::memory_order_relaxed);
-            if (i < count_.load(std::memory_order_acquire)) { if (next_.compare_exchange_weak(i, i + 1, std::memory_order_acq_rel)) run_one(items_[i]); continue; }
-            if (until_empty || closing_.load(std::memory_order_acquire)) { if (next_.load() >= count_.load(std::memory_order_acquire)) return; continue; }
-#if defined(__x86_64__)
-            _mm_pause();
-#endif
-        }
-    }
-};
 void run_deferred(Deferred &d) { d.finish(); }
 
 void knowledge_verify(const KnowledgeProof &pf, const Gens &g, Transcript &tr, const CPoint &C, Deferred &later) {
@@ -514,9 +466,27 @@ void dotproduct_verify(const DotProductProof &pf, const Gens &g, const GensView 
     later.push_back([=] { require(pt_eq(pt_add(host_scalarmul(dec(Cx), c), dec(p->delta)), gp->commit_generic(p->z.data(), n, p->z_delta, *gv))); });
     later.push_back([=] { require(pt_eq(pt_add(host_scalarmul(dec(Cy), c), dec(p->beta)), commit_scalar_pt(*gp, gp->sc_1, za, p->z_beta))); });
 }
+// The commitments a sum-check's rounds decompress ON the sequential path (comm_evals: each one is combined with a challenge and the
+// result is hashed before the next round can start) are decompressed ahead of it by the background threads, a few per task; the round
+// takes the point if it is there and decompresses it itself if not.  State: 0 pending, 1 a point, 2 not an encoding.
+struct PreDecoded {
+    const std::vector<CPoint> *src = nullptr; std::vector<Pt> pts; std::unique_ptr<std::atomic<int>[]> state;
+    void start(const std::vector<CPoint> &v, Deferred &later) {
+        src = &v; pts.resize(v.size()); state.reset(new std::atomic<int>[v.size()]);
+        for (size_t i = 0; i < v.size(); i++) state[i].store(0, std::memory_order_relaxed);
+        for (size_t i0 = 0; i0 < v.size(); i0 += 4)
+            later.push_back([this, i0] { for (size_t i = i0; i < std::min(src->size(), i0 + 4); i++) { Pt p; const bool ok = pt_decode_fast(p, (*src)[i].b); pts[i] = p; state[i].store(ok ? 1 : 2, std::memory_order_release); } });
+    }
+    Pt get(size_t i) const {
+        const int st = state ? state[i].load(std::memory_order_acquire) : 0;
+        if (st == 1) return pts[i];
+        if (st == 2) throw VerifyFail{OTTI_ERR_VERIFY_DECOMPRESS};
+        return dec((*src)[i]);
+    }
+};
 // ZKSumcheckInstanceProof::verify
 CPoint sumcheck_verify(const ZKSumcheckProof &pf, const CPoint &comm_claim, size_t num_rounds, size_t degree, const Gens &g,
-                       const GensView &gn, Transcript &tr, std::vector<Fr> &r, Deferred &later) {
+                       const GensView &gn, Transcript &tr, std::vector<Fr> &r, Deferred &later, const PreDecoded *pre = nullptr) {
     require(gn.G.size() == degree + 1 && pf.comm_polys.size() == num_rounds && pf.comm_evals.size() == num_rounds &&
             pf.proofs.size() == num_rounds);
     size_t ne = degree + 1; r.clear();
@@ -529,8 +499,8 @@ CPoint sumcheck_verify(const ZKSumcheckProof &pf, const CPoint &comm_claim, size
         // the combined claim's commitment is hashed ("Cy" below), so it stays on the sequential path: its two halves on two threads
         Pt half[2]; int bad[2] = {0, 0};
         std::function<void()> halves[2] = {
-            [&] { try { half[0] = host_scalarmul(dec(ccpr), w[0]); } catch (const VerifyFail &f) { bad[0] = f.code; } },
-            [&] { try { half[1] = host_scalarmul(dec(pf.comm_evals[i]), w[1]); } catch (const VerifyFail &f) { bad[1] = f.code; } }};
+            [&] { try { half[0] = host_scalarmul((pre && i) ? pre->get(i - 1) : dec(ccpr), w[0]); } catch (const VerifyFail &f) { bad[0] = f.code; } },
+            [&] { try { half[1] = host_scalarmul(pre ? pre->get(i) : dec(pf.comm_evals[i]), w[1]); } catch (const VerifyFail &f) { bad[1] = f.code; } }};
         SpinPool::get().parallel(halves, 2);
         if (bad[0] || bad[1]) throw VerifyFail{bad[0] ? bad[0] : bad[1]};
         CPoint comm_target; pt_encode(comm_target.b, pt_add(half[0], half[1]));
@@ -545,41 +515,51 @@ CPoint sumcheck_verify(const ZKSumcheckProof &pf, const CPoint &comm_claim, size
 // already resident (prove and verify in one process, as `spzk verify` runs them), the device side registers this hook and the verifier
 // takes the sum from one small MSM launch instead of a host Pippenger over n points.  Without it (no device, no table) nothing changes.
 FixedBaseMsmHook g_fixed_base_msm_hook = nullptr;
-// BulletReductionProof::verify
-void bullet_verify(const DotProductProofLog &pf, size_t n, const Fr *a, Transcript &tr, const Pt &Gamma, const Gens &g, Pt &g_hat,
-                   Pt &Gamma_hat, Fr &a_hat) {                                    // gens_n.G = the first n points of g's stream
-    size_t lg = pf.L_vec.size();
+// BulletReductionProof::verify + the closing equation of DotProductProofLog::verify.  The transcript part (the round challenges, then c)
+// and the fixed-base sum g_hat (device, when the prover's table is resident) run on the calling thread; Gamma_hat — a variable-base sum
+// over the 2 log n proof points — and the closing group equation feed nothing that is hashed, so with `later` they become one more
+// deferred check (spartan.h verifiers: SNARK mode has three of these proofs in a row).
+void dotproductlog_verify(const DotProductProofLog &pf, size_t n, const Gens &g, const PcView &v, Transcript &tr, const Fr *a, const CPoint &Cx, const CPoint &Cy, Deferred *later) {
+    require(v.R == n && g.P.size() >= n + 2);
+    static const bool trace = getenv("OTTI_TRACE") != nullptr; auto t_lap = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) { if (!trace) return; const auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[otti]   dotproductlog_verify n=%zu %-22s %.3f ms\n", n, what, std::chrono::duration<double, std::milli>(t - t_lap).count()); t_lap = t; };
+    tr.append_protocol_name("dot product proof (log)");
+    tr.append_point("Cx", Cx.b); tr.append_point("Cy", Cy.b);
+    const size_t lg = pf.L_vec.size();
     require(pf.R_vec.size() == lg && lg < 32 && n == ((size_t)1 << lg));
     std::vector<Fr> ch(lg), chi(lg);
     for (size_t i = 0; i < lg; i++) { tr.append_point("L", pf.L_vec[i].b); tr.append_point("R", pf.R_vec[i].b); ch[i] = tr.challenge_scalar("u"); }
+    tr.append_point("delta", pf.delta.b); tr.append_point("beta", pf.beta.b);
+    const Fr c = tr.challenge_scalar("c");
+    // everything below is arithmetic on values the transcript has already absorbed
     Fr allinv = fr_one();
-    for (size_t i = 0; i < lg; i++) { chi[i] = fr_inv(ch[i]); allinv = fr_mul(allinv, chi[i]); }
+    {   // the lg inverses from ONE inversion (Montgomery's trick): allinv = 1 / prod ch[i], chi[i] = allinv * prod_{k != i} ch[k]
+        std::vector<Fr> pre(lg + 1); pre[0] = fr_one();
+        for (size_t i = 0; i < lg; i++) pre[i + 1] = fr_mul(pre[i], ch[i]);
+        allinv = fr_inv(pre[lg]);
+        Fr suf = allinv;                                                  // 1 / (ch[0] .. ch[i]) walking down
+        for (size_t i = lg; i-- > 0;) { chi[i] = fr_mul(suf, pre[i]); suf = fr_mul(suf, ch[i]); }
+    }
     for (size_t i = 0; i < lg; i++) { ch[i] = fr_sqr(ch[i]); chi[i] = fr_sqr(chi[i]); }
     std::vector<Fr> s(n); s[0] = allinv;
     for (size_t i = 1; i < n; i++) { size_t lg_i = ilog2(i + 1) - 1; size_t k = (size_t)1 << lg_i; s[i] = fr_mul(s[i - k], ch[(lg - 1) - lg_i]); }
+    Pt g_hat;
     if (!(g_fixed_base_msm_hook && g_fixed_base_msm_hook(g, s.data(), n, g_hat))) g_hat = host_msm_wide(s.data(), g.P.data(), n);
-    a_hat = fr_zero(); for (size_t i = 0; i < n; i++) a_hat = fr_add(a_hat, fr_mul(a[i], s[i]));
-    std::vector<Fr> sc; std::vector<Pt> pts;
-    for (size_t i = 0; i < lg; i++) { sc.push_back(ch[i]); pts.push_back(dec(pf.L_vec[i])); }
-    for (size_t i = 0; i < lg; i++) { sc.push_back(chi[i]); pts.push_back(dec(pf.R_vec[i])); }
-    sc.push_back(fr_one()); pts.push_back(Gamma);
-    Gamma_hat = host_msm(sc.data(), pts.data(), sc.size());
-}
-void dotproductlog_verify(const DotProductProofLog &pf, size_t n, const Gens &g, const PcView &v, Transcript &tr, const Fr *a, const CPoint &Cx, const CPoint &Cy) {
-    require(v.R == n && g.P.size() >= n + 2);
-    tr.append_protocol_name("dot product proof (log)");
-    tr.append_point("Cx", Cx.b); tr.append_point("Cy", Cy.b);
-    static const bool trace = getenv("OTTI_TRACE") != nullptr; auto t_lap = std::chrono::steady_clock::now();
-    auto lap = [&](const char *what) { if (!trace) return; const auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[otti]   dotproductlog_verify n=%zu %-22s %.3f ms\n", n, what, std::chrono::duration<double, std::milli>(t - t_lap).count()); t_lap = t; };
-    Pt Gamma = pt_add(dec(Cx), dec(Cy)), g_hat, Gamma_hat; Fr a_hat;
-    bullet_verify(pf, n, a, tr, Gamma, g, g_hat, Gamma_hat, a_hat);
-    lap("bullet_verify");
-    tr.append_point("delta", pf.delta.b); tr.append_point("beta", pf.beta.b);
-    Fr c = tr.challenge_scalar("c");
-    Pt lhs = pt_add(host_scalarmul(pt_add(host_scalarmul(Gamma_hat, c), dec(pf.beta)), a_hat), dec(pf.delta));
-    Pt rhs = pt_add(host_scalarmul(pt_add(g_hat, host_scalarmul(g.P[v.g1], a_hat)), pf.z1), host_scalarmul(g.P[v.h1], pf.z2));
-    require(pt_eq(lhs, rhs));
-    lap("closing equation");
+    Fr a_hat = fr_zero(); for (size_t i = 0; i < n; i++) a_hat = fr_add(a_hat, fr_mul(a[i], s[i]));
+    lap("challenges, s, g_hat");
+    const DotProductProofLog *p = &pf; const Gens *gp = &g;
+    auto closing = [=] {
+        std::vector<Fr> sc; std::vector<Pt> pts;
+        for (size_t i = 0; i < lg; i++) { sc.push_back(ch[i]); pts.push_back(dec(p->L_vec[i])); }
+        for (size_t i = 0; i < lg; i++) { sc.push_back(chi[i]); pts.push_back(dec(p->R_vec[i])); }
+        sc.push_back(fr_one()); pts.push_back(pt_add(dec(Cx), dec(Cy)));
+        const Pt Gamma_hat = host_msm(sc.data(), pts.data(), sc.size());
+        Pt lhs = pt_add(host_scalarmul(pt_add(host_scalarmul(Gamma_hat, c), dec(p->beta)), a_hat), dec(p->delta));
+        Pt rhs = pt_add(host_scalarmul(pt_add(g_hat, host_scalarmul(gp->P[v.g1], a_hat)), p->z1), host_scalarmul(gp->P[v.h1], p->z2));
+        require(pt_eq(lhs, rhs));
+    };
+    if (later) later->push_back(closing); else closing();
+    lap(later ? "closing equation (deferred)" : "Gamma_hat, closing equation");
 }
 // R1CSProof::verify: `tr` already carries the caller's protocol name (NIZK / SNARK); returns the challenges the transcript produced
 int r1cs_verify_host(const NizkProof &P, size_t N, size_t V, const std::vector<Fr> &inputs, const Fr inst_evals[3], const Gens &g, Transcript &tr,
@@ -597,11 +577,13 @@ int r1cs_verify_host(const NizkProof &P, size_t N, size_t V, const std::vector<F
         std::vector<Fr> tau = tr.challenge_vector("challenge_tau", nrx);
         CPoint claim_phase1; pt_encode(claim_phase1.b, commit_scalar_pt(g, g.sc_1, fr_zero(), fr_zero()));
         RowSum rows(P.comm_vars.data(), Lsz);                             // with a device: the row commitments start decompressing now
+        PreDecoded pre1, pre2;                                            // declared before `later`: its workers fill them, so they must be destroyed after it
         Deferred later;                                                   // P, g and the CPoints it captures live until run_deferred below
         SpinPool::Session pool_session;
         const bool trace = getenv("OTTI_TRACE") != nullptr; auto t_lap = std::chrono::steady_clock::now();
         auto lap = [&](const char *what) { if (!trace) return; const auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[otti] r1cs_verify %-28s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t_lap).count()); t_lap = t; };
-        CPoint comm_post1 = sumcheck_verify(P.sc1, claim_phase1, nrx, 3, g, g.sc_4, tr, rx, later);
+        if (P.sc1.comm_evals.size() == nrx && P.sc2.comm_evals.size() == nry) { pre1.start(P.sc1.comm_evals, later); pre2.start(P.sc2.comm_evals, later); }
+        CPoint comm_post1 = sumcheck_verify(P.sc1, claim_phase1, nrx, 3, g, g.sc_4, tr, rx, later, pre1.src ? &pre1 : nullptr);
         lap("sum-check one");
         const CPoint &cAz = P.claims_phase2[0], &cBz = P.claims_phase2[1], &cCz = P.claims_phase2[2], &cPr = P.claims_phase2[3];
         knowledge_verify(P.pok, g, tr, cCz, later);
@@ -616,7 +598,7 @@ int r1cs_verify_host(const NizkProof &P, size_t N, size_t V, const std::vector<F
         CPoint comm_claim2;
         pt_encode(comm_claim2.b, pt_add(pt_add(host_scalarmul(dec(cAz), rA), host_scalarmul(dec(cBz), rB)), host_scalarmul(dec(cCz), rC)));
         lap("sigma protocols");
-        CPoint comm_post2 = sumcheck_verify(P.sc2, comm_claim2, nry, 2, g, g.sc_3, tr, ry, later);
+        CPoint comm_post2 = sumcheck_verify(P.sc2, comm_claim2, nry, 2, g, g.sc_3, tr, ry, later, pre2.src ? &pre2 : nullptr);
         lap("sum-check two");
         // PolyEvalProof::verify
         {
@@ -627,7 +609,7 @@ int r1cs_verify_host(const NizkProof &P, size_t N, size_t V, const std::vector<F
             lap("C_LZ");
             require(P.polyeval.L_vec.size() == ilog2(Rsz));
             const PcView pv = {g.pc_n.h, g.pc_1.G[0], g.pc_1.h, Rsz};
-            dotproductlog_verify(P.polyeval, Rsz, g, pv, tr, Rv.data(), C_LZ, P.comm_vars_at_ry);
+            dotproductlog_verify(P.polyeval, Rsz, g, pv, tr, Rv.data(), C_LZ, P.comm_vars_at_ry, &later);
         }
         // SparsePolynomial over (1, inputs) evaluated at ry[1..], MSB-first index bits
         Fr poly_input_eval = fr_zero();
