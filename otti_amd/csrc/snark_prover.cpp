@@ -176,9 +176,15 @@ ProductCircuitEvalProofBatched pcbatch_prove(DevCtx &c, Circuits &C, const std::
     static const bool tail_env = [] { const char *e = getenv("OTTI_PC_TAIL"); return !(e && e[0] == '0'); }();
     static const size_t tail_cap = [] { const char *e = getenv("OTTI_PC_TAIL_CAP"); size_t v = e ? (size_t)atoi(e) : 0; return (v >= 2 && v <= (size_t)kTailCap && !(v & (v - 1))) ? v : (size_t)kTailCap; }();
     const bool tail_ok = arm_ok && tail_env;
+    static const size_t lgt_env_many = [] { const char *e = getenv("OTTI_PC_LGT_MANY"); return e ? (size_t)atoi(e) : (size_t)0; }();
+    static const size_t lgt_env_few = [] { const char *e = getenv("OTTI_PC_LGT_FEW"); return e ? (size_t)atoi(e) : (size_t)0; }();
     static const size_t pc_arm_max = [] { const char *e = getenv("OTTI_PC_ARM_MAX"); return e ? (size_t)atoll(e) : (size_t)1 << 22; }();     // (the sum-check kernels of the R1CS proof arm up to kArmMaxLen; here a round more or less ahead costs nothing else)
     SpinPool &pool = SpinPool::get();
     const int host_threads = std::min(8, pool.workers() + 1);
+    // the host plays the last 4 (18-instance batches: tables of 16) or 5 (4-instance batches: 32) rounds of every layer.  Larger host tails
+    // were measured with the rounds spread over the helper threads (5 / 7: 10.9-11.4 ms against 10.7; OTTI_PC_LGT_MANY / _FEW): a device round
+    // of that size costs less than the host's arithmetic plus its thread hand-offs
+    const size_t lgt_many = lgt_env_many ? lgt_env_many : 4, lgt_few = lgt_env_few ? lgt_env_few : 5;
     static const bool trace = getenv("OTTI_TRACE") != nullptr;
     double tr_tail_first_ms = 0, tr_tail_sum_ms = 0, tr_tail_wait_ms = 0, tr_tail_ms = 0, tr_launch_ms = 0, tr_host_ms = 0, tr_layer0_ms = 0; size_t tr_tail_rounds = 0, tr_launch_rounds = 0, tr_host_rounds = 0, tr_tail_layers = 0;
     for (size_t li = 0; li < nl; li++) {
@@ -190,9 +196,7 @@ ProductCircuitEvalProofBatched pcbatch_prove(DevCtx &c, Circuits &C, const std::
         for (int i = 0; i < np; i++) { P.A[P.n] = C.left(i, layer_id); P.B[P.n] = C.right(i, layer_id); P.C[P.n] = nullptr; P.n++; }
         if (with_dotp) for (int i = 0; i < D->n; i++) { P.A[P.n] = D->l[i]; P.B[P.n] = D->r[i]; P.C[P.n] = D->w[i]; P.n++; }
         const int ni = P.n;
-        // the host plays the last lgT rounds of every layer (and the small layers entirely): with its helper threads a round over tables of
-        // 32 (18-instance batches) or 128 (4-instance batches) elements costs it less than a device round's ~18 us of hand-overs
-        const size_t lgT = std::min<size_t>(nr, host_threads >= 4 ? (ni >= 8 ? 5 : 7) : (ni >= 8 ? 4 : 5)), T = (size_t)1 << lgT, ndev = nr - lgT;
+        const size_t lgT = std::min<size_t>(nr, ni >= 8 ? lgt_many : lgt_few), T = (size_t)1 << lgT, ndev = nr - lgT;
         // The persistent tail (k_pc_tail, snark_dev.h): from round k0 on — the first round whose tables fit the LDS of W workgroups per
         // instance — ONE launch plays every remaining device round.  Only while this is the process's single proof in flight (its grid
         // must be resident as a whole: the workgroups wait for the host, the host for all of them) and no kernel class it belongs to is
