@@ -176,7 +176,9 @@ def main():
     if rehearse:
         local_rank = 0
     os.environ.setdefault("OTTI_DEVICE", str(local_rank))
-    shard = world > 1 and not args.replicas
+    # OTTI_FORCE_SHARD (with OTTI_FORCE_DIST): the sharded code path — witness broadcast, exchange, transports, sharded sweep — with a world of
+    # ONE over the real RCCL backend: how the N > 1 path is exercised on a one-GPU box beyond the gloo rehearsal
+    shard = (world > 1 or bool(os.environ.get("OTTI_FORCE_SHARD"))) and not args.replicas
     lws = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
     cores_here = max(1, usable_cores() // lws)                  # host cores of this rank
     conc = 0 if args.in_flight < 0 else (args.in_flight if args.in_flight > 0 else max(1, min(6, cores_here // 2)))

@@ -42,3 +42,22 @@ def test_two_rank_rehearsal_of_the_drivers_command(tmp_path):
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1]
     _check_sharded_line(json.loads(line), 2)
+
+
+@pytest.mark.gpu
+def test_sharded_bench_path_over_the_real_rccl_backend_with_a_world_of_one(tmp_path):
+    """What a one-GPU box can run of the N > 1 path beyond the gloo rehearsal: `backend="nccl"` process group, witness broadcast, the exchange,
+    BOTH transports timed (RCCL accepts a communicator of one rank), the sharded sweep — OTTI_FORCE_DIST + OTTI_FORCE_SHARD."""
+    env = dict(os.environ)
+    env.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29547", "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0", "OTTI_FORCE_DIST": "1", "OTTI_FORCE_SHARD": "1"})
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--log2-constraints", "16", "--sweep", "14", "--in-flight", "-1",
+           "--no-e2e", "--no-snark"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), "rank 0 prints ONE line (RCCL's banner must not reach stdout): %r" % lines[:3]
+    d = json.loads(lines[0])
+    tr = d["transports"]
+    assert tr["mailbox"]["ms_per_proof"] > 0 and tr["rccl"].get("ms_per_proof", 0) > 0, tr
+    assert d["cpu_baseline"]["proof_equals_gpu_proof"] is True and d["sweep"]["2^14"]["equals_oracle_digest"] is True
