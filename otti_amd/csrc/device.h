@@ -4,6 +4,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <vector>
+#include <functional>
 #include <cstddef>
 #include "spartan.h"
 
@@ -98,6 +99,7 @@ struct DevCtx {
     bool host_coherent = false;                               // the words kernels spin on / mail to are fine-grained coherent host memory (else: no armed launches)
     void reset_arrival_counters();                            // after an aborted or timed-out launch: a grid may have left them non-zero (stream must be idle)
     hipEvent_t ev_order = nullptr;                            // orders a caller's stream (otti_kd_*) against this context's own
+    hipStream_t cu_masked_stream = nullptr; bool cu_mask_tried = false;   // a second stream confined to every CU but the first 32 (snark_prover.cpp RowsAhead), made on first use, kept
     std::vector<struct RowSumSlot *> row_slots;               // the verifier's variable-base sums in flight on this context (prover.cpp), buffers kept across proofs
     struct TailMail *h_tail = nullptr, *d_tail_alias = nullptr;   // per-workgroup mail lines of the persistent sum-check tail (snark_dev.h), pinned
     void ensure_tail_mail();
@@ -169,7 +171,11 @@ void instance_evaluate_gpu(Instance &I, const std::vector<Fr> &rx, const std::ve
 class ShardComm;
 std::vector<uint8_t> nizk_prove_resident(Instance &I, DeviceWitness &wit, Gens &g, const void *tlabel, size_t tlabel_len, const uint8_t *seed32,
                                          ProveTimings *tm, ShardComm *sh = nullptr);
-void r1cs_prove_device(Instance &I, DeviceWitness &wit, Gens &g, Transcript &tr, RandomTape &tape, NizkProof &P, ProveTimings &T, ShardComm *sh);
+// hooks: called on the proving thread the moment the first (rx) / second (ry) sum-check's challenges are complete — SNARK mode starts the
+// work that depends on them alone (the two halves of the dereferenced polynomial and their commitment rows) on another stream while the
+// R1CS proof goes on through its latency-bound rounds
+struct R1csHooks { std::function<void(const std::vector<Fr> &)> on_rx, on_ry; std::function<void()> on_idle; };   // on_idle: from here on the proof is short rounds only (the chip is idle between them)
+void r1cs_prove_device(Instance &I, DeviceWitness &wit, Gens &g, Transcript &tr, RandomTape &tape, NizkProof &P, ProveTimings &T, ShardComm *sh, const R1csHooks *hooks = nullptr);
 std::shared_ptr<DeviceShard> upload_instance_shard(const Instance &I, int rank, int world);
 // DotProductProofLog::prove on the device (prover.cpp): generator stream indices of (gens_n.h, gens_1.G[0], gens_1.h) and the row length
 struct PeBufs { Fr *LZ, *Rv, *a, *s, *b2, *s2, *rows, *extras; };      // R elements each (rows: 2 R, extras: 4 (log2 R + 1))

@@ -357,7 +357,7 @@ static void host_fold_top(std::vector<Fr> &t, const Fr &r) {
 
 // R1CSProof::prove on the device.  The transcript already carries the caller's protocol name (NIZK / SNARK) and whatever that caller
 // appends before the satisfiability proof; P receives the proof and the challenges (rx, ry); T.ms[0..5] the stage times.
-void r1cs_prove_device(Instance &I, DeviceWitness &wit, Gens &g, Transcript &tr, RandomTape &tape, NizkProof &P, ProveTimings &T, ShardComm *sh) {
+void r1cs_prove_device(Instance &I, DeviceWitness &wit, Gens &g, Transcript &tr, RandomTape &tape, NizkProof &P, ProveTimings &T, ShardComm *sh, const R1csHooks *hooks) {
     DevCtx &c = DevCtx::get();
     ensure_device_objects(I, g);
     const DeviceInstance &DI = *I.dev; const DeviceGens &DG = *g.dev;
@@ -543,6 +543,7 @@ void r1cs_prove_device(Instance &I, DeviceWitness &wit, Gens &g, Transcript &tr,
     else OTTI_HIP(hipMemcpyAsync(S.zw.p, wit.z.p, 2 * V * sizeof(Fr), hipMemcpyDeviceToDevice, c.stream));
     const Fr tau_claim = c.h_results[8], Az_claim = c.h_results[9], Bz_claim = c.h_results[10], Cz_claim = c.h_results[11];
     T.ms[2] = now_ms() - t0;
+    if (hooks && hooks->on_rx) hooks->on_rx(P.rx);
 
     // ---- claims about Az, Bz, Cz at rx (nizk/mod.rs sigma protocols; host)
     Fr Az_blind = tape.random_scalar("Az_blind"), Bz_blind = tape.random_scalar("Bz_blind"), Cz_blind = tape.random_scalar("Cz_blind"),
@@ -607,6 +608,7 @@ void r1cs_prove_device(Instance &I, DeviceWitness &wit, Gens &g, Transcript &tr,
         };
         tk[0] = dev_sc_quad_eval(c, S.zw.p, S.ABC.p, V2l, 0);
         if (ndev == 0) fetch_tail(); else if (armed(1)) fold_launch(1, nullptr);
+        bool idle_told = false;
         for (size_t j = 0; j < nry; j++) {
             Fr e[2];
             if (j >= dsum && !tail_built) build_tail();
@@ -622,6 +624,7 @@ void r1cs_prove_device(Instance &I, DeviceWitness &wit, Gens &g, Transcript &tr,
                 if (armed(j + 1)) c.go(&p1.r_j, 1); else fold_launch(j + 1, &p1.r_j);
                 if (armed(j + 2)) fold_launch(j + 2, nullptr);
             }
+            if (hooks && hooks->on_idle && !idle_told && (j >= ndev || (V2l >> (j + 1)) <= kArmMaxLen)) { idle_told = true; hooks->on_idle(); }   // the bandwidth-bound rounds are behind us
             sumcheck_round_finish(P.sc2, j, p1, st, g, g.sc_3, tr);
             if (j >= ndev && !tail_built) build_tail();
             if (j >= ndev) for (auto &t : tail2) host_fold_top(t, p1.r_j);
@@ -630,6 +633,7 @@ void r1cs_prove_device(Instance &I, DeviceWitness &wit, Gens &g, Transcript &tr,
         claims_phase2[0] = tail2[0][0]; claims_phase2[1] = tail2[1][0];
     }
     T.ms[4] = now_ms() - t0;
+    if (hooks && hooks->on_ry) hooks->on_ry(P.ry);
 
     // ---- polyeval: poly_vars.evaluate(ry[1..]) + PolyEvalProof::prove (K9, K10)
     t0 = now_ms();

@@ -15,6 +15,8 @@
 #include <chrono>
 #include <functional>
 #include <thread>
+#include <condition_variable>
+#include <mutex>
 
 namespace otti {
 
@@ -387,6 +389,65 @@ DotProductProofLog polyeval_prove_plain(DevCtx &c, Gens &gens, const PcSet &s, c
 }
 }  // namespace
 
+// ---- the row half of the derefs commitment, ahead of time.  The dereferenced polynomial is [eq(rx) at the row addresses of A, B, C |
+// eq(ry) at the column addresses | zeros]: its first 3 N / R commitment rows depend on rx alone, which the R1CS proof fixes at the end
+// of its FIRST sum-check — and everything the proof does after that (sigma protocols, second sum-check, evaluation proof: ~2 ms at 2^20)
+// is a chain of latency-bound rounds that leaves the chip idle.  A helper thread with a device context of its own therefore sums those
+// rows meanwhile (3.2 ms of the chip's multiplier), on a stream confined to 192 of the 256 CUs (hipExtStreamCreateWithCUMask) so that the rounds keep
+// CUs to themselves — a fixed-base MSM workgroup holds its CU for ~2 ms, and without the mask a round's kernel waits for one to end;
+// the column half is committed by the proving thread once ry is known, both launches sharing the chip.
+struct RowsAhead {
+    Gens &gens; const Fr *Z; size_t R, rows;
+    std::thread th; std::mutex mu; std::condition_variable cv; int stage = 0;      // 1: the rows' scalars are on their way (ev recorded), -1: cancelled
+    hipEvent_t ev = nullptr; std::vector<CPoint> C; std::exception_ptr err; bool done = false;
+    RowsAhead(Gens &g, const Fr *Z_, size_t R_, size_t rows_) : gens(g), Z(Z_), R(R_), rows(rows_) {
+        OTTI_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        th = std::thread([this] { run(); });
+    }
+    ~RowsAhead() { { std::lock_guard<std::mutex> lk(mu); if (stage == 0) stage = -1; } cv.notify_all(); if (th.joinable()) th.join(); if (ev) (void)hipEventDestroy(ev); }
+    bool recorded = false;
+    void record(hipStream_t producer) { OTTI_HIP(hipEventRecord(ev, producer)); recorded = true; }   // the scalars are complete once `producer` reaches this point
+    void release() {                                              // start summing (after record)
+        if (!recorded) return;
+        { std::lock_guard<std::mutex> lk(mu); if (stage == 0) stage = 1; }
+        cv.notify_all();
+    }
+    std::vector<CPoint> take() {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return done; });
+        if (err) std::rethrow_exception(err);
+        return std::move(C);
+    }
+    static hipStream_t masked_stream(DevCtx &hc) {              // kept with the (pooled) context: every CU but the first 32
+        if (!hc.cu_mask_tried) {
+            hc.cu_mask_tried = true;
+            const char *e = getenv("OTTI_DEREFS_CUMASK"), *f = getenv("OTTI_DEREFS_FREE_CUS");
+            const int free_words = f ? std::max(1, std::min(6, atoi(f) / 32)) : 2;              // CUs left to the proving thread's stream, in units of 32 (measured 32 ... 128: 64 is best)
+            uint32_t mask[8]; for (int i = 0; i < 8; i++) mask[i] = i < free_words ? 0u : 0xffffffffu;
+            if (!(e && e[0] == '0') && hipExtStreamCreateWithCUMask(&hc.cu_masked_stream, 8, mask) != hipSuccess) { (void)hipGetLastError(); hc.cu_masked_stream = nullptr; }
+        }
+        return hc.cu_masked_stream;
+    }
+    void run() {
+        try {
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return stage != 0; }); if (stage < 0) { done = true; cv.notify_all(); return; } }
+            DevCtx &hc = DevCtx::get();                           // this thread's own context: its own MSM partials, point buffers, stream
+            hipStream_t own = hc.stream, ms = masked_stream(hc);
+            struct Restore { DevCtx &c; hipStream_t s; ~Restore() { c.stream = s; } } restore{hc, own};
+            if (ms) hc.stream = ms;
+            if (getenv("OTTI_TRACE")) fprintf(stderr, "[otti] rows ahead: %zu rows on %s\n", rows, ms ? "a CU-masked stream" : "an ordinary second stream (no CU mask)");
+            OTTI_HIP(hipStreamWaitEvent(hc.stream, ev, 0));
+            dev_msm_rows(hc, *gens.dev, Z, R, R, rows, nullptr, nullptr, 0, MSM_COMPRESSED, nullptr, false);
+            // (polled, not hipStreamSynchronize: a blocking wait in this thread was seen to hold up the proving thread's launches for as long as it lasted)
+            if (!getenv("OTTI_DEREFS_SYNC")) while (hipStreamQuery(hc.stream) == hipErrorNotReady) std::this_thread::sleep_for(std::chrono::microseconds(50));
+            hc.sync();
+            std::vector<CPoint> out(rows); memcpy(out.data(), hc.h_points, 32 * rows);
+            std::lock_guard<std::mutex> lk(mu); C = std::move(out); done = true;
+        } catch (...) { std::lock_guard<std::mutex> lk(mu); err = std::current_exception(); done = true; }
+        cv.notify_all();
+    }
+};
+
 // ================================================================================================ SNARK::prove
 std::vector<uint8_t> snark_prove_gpu(Instance &I, CompComm &comm, const uint8_t *vars32, size_t nvars, const std::vector<Fr> &inputs, SnarkGens &g,
                                      const void *tlabel, size_t tlabel_len, const uint8_t *seed32, SnarkTimings *tm) {
@@ -412,7 +473,36 @@ std::vector<uint8_t> snark_prove_resident(Instance &I, CompComm &comm, DeviceWit
     SnarkProof S;
     tr.append_protocol_name("Spartan SNARK proof");
     snark_append_comm(tr, comm);
-    { ProveTimings pt{}; r1cs_prove_device(I, wit, *g.sat, tr, tape, S.r1cs, pt, nullptr); for (int k = 0; k < 6; k++) T.ms[k] = pt.ms[k]; }
+    SnarkScratch &W = snark_workspace(c);
+    struct Ptr { Fr *p; };                                    // (the buffers below used to be DevBufs of this proof; the code keeps reading x.p)
+    const Ptr mem_rx{W.get(SS_MEM_RX, M)}, mem_ry{W.get(SS_MEM_RY, M)}, eqs{W.get(SS_EQS, 5 * 4096)}, derefs{W.get(SS_DEREFS, (size_t)8 * N)},
+              partials{W.get(SS_PARTIALS, (size_t)3 * 2048 + 64)};             // 3 sums x at most 2048 workgroups per launch (k_snark.hip many_grid)
+    auto drow = [&](int k) { return derefs.p + (size_t)k * N; };
+    auto dcol = [&](int k) { return derefs.p + (size_t)(3 + k) * N; };
+    const size_t nm = ilog2(M);
+    auto equalized = [&](const std::vector<Fr> &r) {          // zeros in FRONT of the shorter point
+        if (r.size() > nm) throw Error(OTTI_ERR_INTERNAL, "memory size does not match the evaluation point");
+        std::vector<Fr> e(nm - r.size(), fr_zero()); e.insert(e.end(), r.begin(), r.end()); return e;
+    };
+    // dense.deref, row side: row_ops_val[k][i] = eq(rx)[row_addr[k][i]] — queued the moment rx is final (R1csHooks), and with it the row half
+    // of the derefs commitment on the helper's stream (RowsAhead above); the column side follows after the R1CS proof
+    const size_t rows_half = g.derefs.R ? 3 * N / g.derefs.R : 0;
+    static const bool ahead_env = [] { const char *e = getenv("OTTI_DEREFS_AHEAD"); return !(e && e[0] == '0'); }();
+    const bool ahead = ahead_env && c.armed_ok() && N >= ((size_t)1 << 14) && rows_half >= 64 && rows_half * g.derefs.R == 3 * N && 2 * rows_half <= g.derefs.L;
+    std::unique_ptr<RowsAhead> rows_job;
+    if (ahead) rows_job.reset(new RowsAhead(*g.eval, derefs.p, g.derefs.R, rows_half));
+    bool rows_queued = false;
+    auto queue_rows = [&](const std::vector<Fr> &rx_) {
+        const std::vector<Fr> rxe_ = equalized(rx_);
+        dev_eq_evals(c, rxe_.data(), nm, mem_rx.p, eqs.p);
+        for (int k = 0; k < 3; k++) dev_gather(c, mem_rx.p, d.row_addr[k].p, drow(k), N);
+        if (rows_job) rows_job->record(c.stream);
+        rows_queued = true;
+    };
+    // the helper starts once the second sum-check is past its bandwidth-bound rounds: those want the whole chip (confined to the CUs the
+    // helper leaves free they took 3.2 ms instead of 0.75), the short rounds after them and the evaluation proof do not
+    R1csHooks hooks; hooks.on_rx = queue_rows; hooks.on_idle = [&] { if (rows_job) rows_job->release(); };
+    { ProveTimings pt{}; r1cs_prove_device(I, wit, *g.sat, tr, tape, S.r1cs, pt, nullptr, ahead ? &hooks : nullptr); for (int k = 0; k < 6; k++) T.ms[k] = pt.ms[k]; }
     lap("r1cs proof");
     // inst.evaluate(rx, ry) is not computed by a sparse product of its own: M(rx, ry) = sum_i val_i eq(rx)[row_i] eq(ry)[col_i] is exactly
     // the dot product of the dereferenced vectors the evaluation proof needs anyway (its two halves are E.dotp_left / dotp_right below),
@@ -420,22 +510,15 @@ std::vector<uint8_t> snark_prove_resident(Instance &I, CompComm &comm, DeviceWit
     EvalProof &E = S.eval;
     t0 = now_ms();
     const std::vector<Fr> &rx = S.r1cs.rx, &ry = S.r1cs.ry;
-    const size_t nm = std::max(rx.size(), ry.size());
-    if (((size_t)1 << nm) != M) throw Error(OTTI_ERR_INTERNAL, "memory size does not match the evaluation point");
-    std::vector<Fr> rxe(nm - rx.size(), fr_zero()), rye(nm - ry.size(), fr_zero());     // equalize: zeros in FRONT of the shorter point
-    rxe.insert(rxe.end(), rx.begin(), rx.end()); rye.insert(rye.end(), ry.begin(), ry.end());
-    SnarkScratch &W = snark_workspace(c);
-    struct Ptr { Fr *p; };                                    // (the buffers below used to be DevBufs of this proof; the code keeps reading x.p)
-    const Ptr mem_rx{W.get(SS_MEM_RX, M)}, mem_ry{W.get(SS_MEM_RY, M)}, eqs{W.get(SS_EQS, 5 * 4096)}, derefs{W.get(SS_DEREFS, (size_t)8 * N)},
-              partials{W.get(SS_PARTIALS, (size_t)3 * 2048 + 64)};             // 3 sums x at most 2048 workgroups per launch (k_snark.hip many_grid)
-    dev_eq_evals(c, rxe.data(), nm, mem_rx.p, eqs.p);
+    if (((size_t)1 << std::max(rx.size(), ry.size())) != M) throw Error(OTTI_ERR_INTERNAL, "memory size does not match the evaluation point");
+    const std::vector<Fr> rxe = equalized(rx), rye = equalized(ry);
+    if (!rows_queued) queue_rows(rx);
+    if (rows_job) rows_job->release();
     dev_eq_evals(c, rye.data(), nm, mem_ry.p, eqs.p);
-    // dense.deref: row_ops_val[k][i] = mem_rx[row_addr[k][i]], col likewise; comb = merge(rows, cols), zero-padded to 8 N
+    // comb = merge(rows, cols), zero-padded to 8 N
     OTTI_HIP(hipMemsetAsync(derefs.p + 6 * N, 0, 2 * N * sizeof(Fr), c.stream));
-    auto drow = [&](int k) { return derefs.p + (size_t)k * N; };
-    auto dcol = [&](int k) { return derefs.p + (size_t)(3 + k) * N; };
     lap("allocations, eq tables");
-    for (int k = 0; k < 3; k++) { dev_gather(c, mem_rx.p, d.row_addr[k].p, drow(k), N); dev_gather(c, mem_ry.p, d.col_addr[k].p, dcol(k), N); }
+    for (int k = 0; k < 3; k++) dev_gather(c, mem_ry.p, d.col_addr[k].p, dcol(k), N);
     std::vector<Fr> dotp_evals(6);
     {
         AbcList A; A.n = 6;
@@ -449,7 +532,17 @@ std::vector<uint8_t> snark_prove_resident(Instance &I, CompComm &comm, DeviceWit
     tr.append_scalar("Ar_claim", S.inst_evals[0]); tr.append_scalar("Br_claim", S.inst_evals[1]); tr.append_scalar("Cr_claim", S.inst_evals[2]);
     // ---- R1CSEvalProof::prove -> SparseMatPolyEvalProof::prove
     tr.append_protocol_name("Sparse polynomial evaluation proof");
-    E.comm_derefs = commit_poly(c, *g.eval, derefs.p, g.derefs, 0);      // values of eq tables: uniform field elements
+    if (rows_job) {
+        // the column half (and nothing for the zero rows: the identity compresses to 32 zero bytes) on this stream, beside what is left of the helper's row half
+        dev_msm_rows(c, *g.eval->dev, derefs.p + (size_t)3 * N, g.derefs.R, g.derefs.R, rows_half, nullptr, nullptr, 0, MSM_COMPRESSED, nullptr, false);
+        c.sync();
+        E.comm_derefs.assign(g.derefs.L, CPoint{});
+        for (auto &z : E.comm_derefs) memset(z.b, 0, 32);
+        memcpy(E.comm_derefs[rows_half].b, c.h_points, 32 * rows_half);
+        const std::vector<CPoint> head = rows_job->take();
+        memcpy(E.comm_derefs[0].b, head[0].b, 32 * rows_half);
+        rows_job.reset();
+    } else E.comm_derefs = commit_poly(c, *g.eval, derefs.p, g.derefs, 0);      // values of eq tables: uniform field elements
     tr.append_message("derefs_commitment", "begin_derefs_commitment", 23);
     append_poly_commitment(tr, "comm_poly_row_col_ops_val", E.comm_derefs);
     tr.append_message("derefs_commitment", "end_derefs_commitment", 21);
