@@ -120,15 +120,18 @@ def test_snark_sweep_sizes_match_committed_oracle_digests(lg):
         oa.SNARK(bytes(bad)).verify(vc, inputs, gens, label)
 
 
-@pytest.mark.parametrize("env", [{"OTTI_PC_TAIL": "0"}, {"OTTI_PC_TAIL_CAP": "16"}, {"OTTI_PC_TAIL_CAP": "128"}, {"OTTI_ARMED": "0"}, {}])
-def test_persistent_tail_variants_give_the_oracles_proof(env):
+@pytest.mark.parametrize("lg,env", [(12, {"OTTI_PC_TAIL": "0"}), (12, {"OTTI_PC_TAIL_CAP": "16"}), (12, {"OTTI_PC_TAIL_CAP": "128"}), (12, {"OTTI_ARMED": "0"}), (12, {}),
+                                    (16, {"OTTI_DEREFS_AHEAD": "0"}), (16, {"OTTI_DEREFS_CUMASK": "0"}), (16, {"OTTI_DEREFS_FREE_CUS": "128"}), (16, {"OTTI_PC_LGT_MANY": "5", "OTTI_PC_LGT_FEW": "7"})])
+def test_persistent_tail_variants_give_the_oracles_proof(lg, env):
     """The layered sum-checks of R1CSEvalProof three ways — a launch per round (tail off / nothing armed), the persistent tail with
     its full LDS capacity (small instances: whole layers in one launch), and with a shrunken capacity (the tail then takes over tables
-    that earlier launches folded in HBM, as it does at 2^16 and beyond) — must all produce the oracle's bytes (committed digest, 2^12)."""
+    that earlier launches folded in HBM, as it does at 2^16 and beyond) — must all produce the oracle's bytes (committed digests, 2^12 and
+    2^16).  Likewise the row half of the derefs commitment running ahead on the helper's CU-masked stream (2^16: on by default there),
+    switched off, without the mask, with another split of the CUs, and the host tail of the sum-checks at another length."""
     import os, subprocess, sys
-    g = _golden_snark()[1 << 12]
+    g = _golden_snark()[1 << lg]
     e = dict(os.environ); e.update(env)
-    res = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "snark_tail_worker.py"), "12"], env=e,
+    res = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "snark_tail_worker.py"), str(lg)], env=e,
                          capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout + res.stderr
     line = [ln for ln in res.stdout.splitlines() if ln.startswith("DIGEST")][-1].split()
