@@ -99,7 +99,6 @@ struct DevCtx {
     bool host_coherent = false;                               // the words kernels spin on / mail to are fine-grained coherent host memory (else: no armed launches)
     void reset_arrival_counters();                            // after an aborted or timed-out launch: a grid may have left them non-zero (stream must be idle)
     hipEvent_t ev_order = nullptr;                            // orders a caller's stream (otti_kd_*) against this context's own
-    hipStream_t cu_masked_stream = nullptr; bool cu_mask_tried = false;   // a second stream confined to every CU but the first 32 (snark_prover.cpp RowsAhead), made on first use, kept
     std::vector<struct RowSumSlot *> row_slots;               // the verifier's variable-base sums in flight on this context (prover.cpp), buffers kept across proofs
     struct TailMail *h_tail = nullptr, *d_tail_alias = nullptr;   // per-workgroup mail lines of the persistent sum-check tail (snark_dev.h), pinned
     void ensure_tail_mail();

@@ -418,29 +418,35 @@ struct RowsAhead {
         if (err) std::rethrow_exception(err);
         return std::move(C);
     }
-    static hipStream_t masked_stream(DevCtx &hc) {              // kept with the (pooled) context: every CU but the first 32
-        if (!hc.cu_mask_tried) {
-            hc.cu_mask_tried = true;
-            const char *e = getenv("OTTI_DEREFS_CUMASK"), *f = getenv("OTTI_DEREFS_FREE_CUS");
-            const int free_words = f ? std::max(1, std::min(6, atoi(f) / 32)) : 2;              // CUs left to the proving thread's stream, in units of 32 (measured 32 ... 128: 64 is best)
+    static int masked_free_cus() {                              // CUs left to the proving thread's stream, in units of 32 (measured 32 ... 128: 64 is best)
+        static const int n = [] { const char *f = getenv("OTTI_DEREFS_FREE_CUS"); return 32 * (f ? std::max(1, std::min(6, atoi(f) / 32)) : 2); }();
+        return n;
+    }
+    static hipStream_t masked_stream() {                        // ONE for the process (made on first use, kept): creating a stream while a proof is
+        static std::once_flag once; static hipStream_t ms = nullptr;   // running stalls the proving thread's launches, and helper threads lease a different pooled context each time
+        std::call_once(once, [] {
+            const char *e = getenv("OTTI_DEREFS_CUMASK");
+            const int free_words = masked_free_cus() / 32;
             uint32_t mask[8]; for (int i = 0; i < 8; i++) mask[i] = i < free_words ? 0u : 0xffffffffu;
-            if (!(e && e[0] == '0') && hipExtStreamCreateWithCUMask(&hc.cu_masked_stream, 8, mask) != hipSuccess) { (void)hipGetLastError(); hc.cu_masked_stream = nullptr; }
-        }
-        return hc.cu_masked_stream;
+            if (!(e && e[0] == '0') && hipExtStreamCreateWithCUMask(&ms, 8, mask) != hipSuccess) { (void)hipGetLastError(); ms = nullptr; }
+        });
+        return ms;
     }
     void run() {
         try {
             { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return stage != 0; }); if (stage < 0) { done = true; cv.notify_all(); return; } }
             DevCtx &hc = DevCtx::get();                           // this thread's own context: its own MSM partials, point buffers, stream
-            hipStream_t own = hc.stream, ms = masked_stream(hc);
+            hipStream_t own = hc.stream, ms = masked_stream();
             struct Restore { DevCtx &c; hipStream_t s; ~Restore() { c.stream = s; } } restore{hc, own};
             if (ms) hc.stream = ms;
-            if (getenv("OTTI_TRACE")) fprintf(stderr, "[otti] rows ahead: %zu rows on %s\n", rows, ms ? "a CU-masked stream" : "an ordinary second stream (no CU mask)");
+            const bool trace = getenv("OTTI_TRACE") != nullptr; const double t_go = now_ms();
             OTTI_HIP(hipStreamWaitEvent(hc.stream, ev, 0));
             dev_msm_rows(hc, *gens.dev, Z, R, R, rows, nullptr, nullptr, 0, MSM_COMPRESSED, nullptr, false);
+            const double t_queued = now_ms();
             // (polled, not hipStreamSynchronize: a blocking wait in this thread was seen to hold up the proving thread's launches for as long as it lasted)
             if (!getenv("OTTI_DEREFS_SYNC")) while (hipStreamQuery(hc.stream) == hipErrorNotReady) std::this_thread::sleep_for(std::chrono::microseconds(50));
             hc.sync();
+            if (trace) fprintf(stderr, "[otti] rows ahead: %zu rows on %s: queued in %.3f ms, summed %.3f ms after the release\n", rows, ms ? "the CU-masked stream" : "an ordinary second stream (no CU mask)", t_queued - t_go, now_ms() - t_go);
             std::vector<CPoint> out(rows); memcpy(out.data(), hc.h_points, 32 * rows);
             std::lock_guard<std::mutex> lk(mu); C = std::move(out); done = true;
         } catch (...) { std::lock_guard<std::mutex> lk(mu); err = std::current_exception(); done = true; }

@@ -1,6 +1,7 @@
 """Randomised differential soak: proofs of random instance shapes / sizes / input counts / labels / seeds from the GPU prover
 against the CPU oracle, for a given number of seconds.  usage (GPU box): python3 tools/soak.py [seconds] [rng seed] [nizk|snark]
-(snark: computation commitment and SNARK proof bytes, sizes up to 2^11)"""
+(snark: computation commitment and SNARK proof bytes, sizes up to 2^11)  [lo:hi] as a fourth argument pins log2 of the uniform / compiler
+sizes to lo..hi-1 (e.g. snark 14:17 — the sizes at which SNARK::prove commits the dereferenced rows ahead of time on a helper thread)"""
 import os
 import sys
 import time
@@ -16,10 +17,13 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 mode = sys.argv[3] if len(sys.argv) > 3 else "nizk"
 orc.set_threads(min(16, os.cpu_count() or 1))
+lg_range = tuple(int(x) for x in sys.argv[4].split(":")) if len(sys.argv) > 4 else None
 t_end, n_ok, n_bad = time.time() + budget, 0, 0
 while time.time() < t_end:
-    dist = str(rng.choice(["uniform", "compiler", "many_cons", "many_vars", "odd"]))
+    dist = str(rng.choice(["uniform", "compiler"] if lg_range else ["uniform", "compiler", "many_cons", "many_vars", "odd"]))
     lg = int(rng.integers(3 if dist == "compiler" else 1, (12 if mode == "snark" else 14) if dist in ("uniform", "compiler") else 9))
+    if lg_range:
+        lg = int(rng.integers(lg_range[0], lg_range[1]))
     ni = int(rng.integers(0, min(12, (1 << lg) - 1) + 1))
     if dist == "odd":                                         # sizes that are not powers of two: exercises the padding rules
         n = int(rng.integers(2, 3000)); ni = int(rng.integers(0, min(12, n - 1) + 1))
