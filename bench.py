@@ -186,6 +186,10 @@ def main():
     os.environ.setdefault("OTTI_HOST_THREADS", str(max(1, min(4, cores_here))))
     if conc > 1:
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")         # one hardware queue per prover stream (HIP's default is 4)
+    # stdout carries ONE line, rank 0's JSON: native libraries print banners there (gloo's "Rank 0 is connected to ...", librccl's version
+    # line), so file descriptor 1 points at stderr for the whole run and the line goes out through the descriptor saved here
+    sys.stdout.flush()
+    line_fd = os.dup(1); os.dup2(2, 1)
     dist = None
     if world > 1 or os.environ.get("OTTI_FORCE_DIST"):      # OTTI_FORCE_DIST: exercise the RCCL path on a one-GPU box
         import torch
@@ -722,7 +726,8 @@ def main():
         "proof_bytes": len(final_proof), "proof_sha256": next(iter(digests)), "equals_oracle_digest": digest_ok, "oracle_parity_2^12": parity_ok,
         "wall_s": round(time.perf_counter() - t_start, 1),
     }
-    print(json.dumps(out))
+    sys.stdout.flush()
+    os.write(line_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()
 

@@ -307,14 +307,16 @@ int32_t otti_nizk_verify(const otti_instance *inst, const uint8_t *inputs32, siz
         std::vector<Fr> inputs = scalars_from_bytes(inputs32, ninputs);
         // The verifier is host code (as in the reference); only its O(nnz + N + V) step — evaluating A, B, C at (rx, ry) — goes to the
         // device when one is present.  (Verification is not the proving hot path: without a device it simply stays on the host.)
-        Fr evals[3]; const Fr *ev = nullptr;
+        // The evaluation is QUEUED here (its point is in the proof) and collected where the verifier needs it, after the sum-check rounds.
+        bool queued = false;
         if (inst->I->num_cons >= 4096 && otti_device_count() > 0) {
             try {
                 NizkProof P = NizkProof::parse(proof, proof_len);
-                instance_evaluate_gpu(*const_cast<Instance *>(inst->I.get()), P.rx, P.ry, evals); ev = evals;
-            } catch (const Error &) { ev = nullptr; }
+                instance_evaluate_begin(*const_cast<Instance *>(inst->I.get()), P.rx, P.ry); queued = true;
+            } catch (const Error &) { queued = false; }
         }
-        int rc = nizk_verify(*inst->I, inputs, *gens->g, tlabel, tlabel_len, proof, proof_len, ev);
+        const InstEvalFetch fetch = [](Fr out[3]) { instance_evaluate_finish(out); };
+        int rc = nizk_verify(*inst->I, inputs, *gens->g, tlabel, tlabel_len, proof, proof_len, nullptr, queued ? &fetch : nullptr);
         if (rc) g_last_error = "proof rejected";
         return rc;
     });

@@ -163,6 +163,9 @@ void ensure_instance_device(Instance &I);
 void ensure_gens_device(Gens &g);
 int device_window_bits(size_t nbases);                   // window width of the fixed-base table (prover.cpp)
 // R1CSInstance::evaluate on the device: (A,B,C)(rx,ry) = <eq(rx), M * eq(ry)> for M in {A,B,C}  (verifier's O(nnz + N + V) work)
+constexpr int kInstEvalSlot = 16;                            // result slots of the instance evaluation (nothing a verifier launches in between writes them)
+void instance_evaluate_begin(Instance &I, const std::vector<Fr> &rx, const std::vector<Fr> &ry);      // queued on the calling thread's stream
+void instance_evaluate_finish(Fr out[3]);                                                              // same thread: waits, reads
 void instance_evaluate_gpu(Instance &I, const std::vector<Fr> &rx, const std::vector<Fr> &ry, Fr out[3]);
 // sh == nullptr (or a world of one): the whole proof on this GPU.  Otherwise this process proves its shard of the SAME proof as the
 // other ranks of sh (collective call: same instance, witness, generators, label and seed on every rank); every rank returns the

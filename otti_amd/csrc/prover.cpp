@@ -228,7 +228,10 @@ inline CPoint point_at(const DevCtx &c, size_t i) { CPoint p; memcpy(p.b, c.h_po
 
 // R1CSInstance::evaluate on the device, in the calling thread's proof workspace (nothing of a proof is live when a verifier or the SNARK
 // prover's closing step calls this; allocating 160 MB for it per call cost more than the evaluation)
-void instance_evaluate_gpu(Instance &I, const std::vector<Fr> &rx, const std::vector<Fr> &ry, Fr out[3]) {
+// begin queues the kernels on the calling thread's stream and returns; finish waits for them.  A verifier begins before it walks the
+// sum-check rounds (the evaluation point is in the proof; the transcript's own challenges are compared with it at the end) and
+// collects the three values where the closing equality needs them, ~2 ms later.
+void instance_evaluate_begin(Instance &I, const std::vector<Fr> &rx, const std::vector<Fr> &ry) {
     DevCtx &c = DevCtx::get();
     ensure_instance_device(I);
     const size_t N = I.num_cons, V = I.num_vars, V2 = 2 * V;
@@ -239,9 +242,16 @@ void instance_evaluate_gpu(Instance &I, const std::vector<Fr> &rx, const std::ve
     dev_eq_evals(c, rx.data(), rx.size(), ex, S.eqs.p);
     dev_eq_evals(c, ry.data(), ry.size(), ey, S.eqs.p);
     dev_spmv3(c, I.dev->by_row, ey, Mz[0], Mz[1], Mz[2], false, nullptr);
-    for (int k = 0; k < 3; k++) dev_dot(c, ex, Mz[k], N, 16 + k);
+    for (int k = 0; k < 3; k++) dev_dot(c, ex, Mz[k], N, kInstEvalSlot + k);
+}
+void instance_evaluate_finish(Fr out[3]) {
+    DevCtx &c = DevCtx::get();
     c.sync();
-    for (int k = 0; k < 3; k++) out[k] = c.h_results[16 + k];
+    for (int k = 0; k < 3; k++) out[k] = c.h_results[kInstEvalSlot + k];
+}
+void instance_evaluate_gpu(Instance &I, const std::vector<Fr> &rx, const std::vector<Fr> &ry, Fr out[3]) {
+    instance_evaluate_begin(I, rx, ry);
+    instance_evaluate_finish(out);
 }
 
 

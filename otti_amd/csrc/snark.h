@@ -66,7 +66,7 @@ void snark_append_comm(Transcript &tr, const CompComm &c);  // R1CSCommitment::a
 int snark_verify(const CompComm &comm, const std::vector<Fr> &inputs, const SnarkGens &g, const void *tlabel, size_t tlabel_len, const uint8_t *proof, size_t proof_len);
 // R1CSProof::verify shared with NIZK mode (spartan_host.cpp): returns 0 and the challenges
 int r1cs_verify_host(const NizkProof &P, size_t N, size_t V, const std::vector<Fr> &inputs, const Fr inst_evals[3], const Gens &g, Transcript &tr,
-                     std::vector<Fr> &rx, std::vector<Fr> &ry);
+                     std::vector<Fr> &rx, std::vector<Fr> &ry, const InstEvalFetch *fetch = nullptr);
 
 // verifier building blocks shared with NIZK mode (spartan_host.cpp)
 struct VerifyFail { int code; };

@@ -3,6 +3,7 @@
 // Mirrors upstream libspartan's public API for this path [RECALL lib.rs: Instance, VarsAssignment, InputsAssignment,
 // NIZKGens, NIZK::{prove,verify}], reached from `spzk verify --nizk` [REF /root/reference/run.py:58, run.py:100].
 #pragma once
+#include <functional>
 #include <stdint.h>
 #include <stddef.h>
 #include <string>
@@ -141,8 +142,11 @@ void sumcheck_round_finish(ZKSumcheckProof &pf, size_t j, const RoundPart1 &p1, 
 
 // ---------------------------------------------------------------------------------------------- verifier (lib.rs NIZK::verify)
 // inst_evals: optional (A,B,C)(rx,ry) computed elsewhere (the device: the O(nnz + N + V) part of verification); NULL => host
+// fetch: the values are on their way (an evaluation begun on the device before the call: device.h instance_evaluate_begin) and are
+// collected through it at the point where the verifier first needs them, after both sum-checks
+typedef std::function<void(Fr out[3])> InstEvalFetch;
 int nizk_verify(const Instance &inst, const std::vector<Fr> &inputs, const Gens &g, const void *tlabel, size_t tlabel_len,
-                const uint8_t *proof, size_t proof_len, const Fr *inst_evals = nullptr);
+                const uint8_t *proof, size_t proof_len, const Fr *inst_evals = nullptr, const InstEvalFetch *fetch = nullptr);
 
 // ---------------------------------------------------------------------------------------------- prover (prover.cpp; GPU)
 struct ProveTimings { double ms[8]; };   // polycommit, multiply_vec, sc_phase_one, eval_table_sparse, sc_phase_two, polyeval, total, (spare)

@@ -10,6 +10,7 @@
 #include <functional>
 #include <atomic>
 #include <system_error>
+#include <memory>
 
 namespace otti {
 
@@ -548,22 +549,43 @@ void dotproductlog_verify(const DotProductProofLog &pf, size_t n, const Gens &g,
     Fr a_hat = fr_zero(); for (size_t i = 0; i < n; i++) a_hat = fr_add(a_hat, fr_mul(a[i], s[i]));
     lap("challenges, s, g_hat");
     const DotProductProofLog *p = &pf; const Gens *gp = &g;
-    auto closing = [=] {
-        std::vector<Fr> sc; std::vector<Pt> pts;
-        for (size_t i = 0; i < lg; i++) { sc.push_back(ch[i]); pts.push_back(dec(p->L_vec[i])); }
-        for (size_t i = 0; i < lg; i++) { sc.push_back(chi[i]); pts.push_back(dec(p->R_vec[i])); }
-        sc.push_back(fr_one()); pts.push_back(pt_add(dec(Cx), dec(Cy)));
-        const Pt Gamma_hat = host_msm(sc.data(), pts.data(), sc.size());
-        Pt lhs = pt_add(host_scalarmul(pt_add(host_scalarmul(Gamma_hat, c), dec(p->beta)), a_hat), dec(p->delta));
-        Pt rhs = pt_add(host_scalarmul(pt_add(g_hat, host_scalarmul(gp->P[v.g1], a_hat)), p->z1), host_scalarmul(gp->P[v.h1], p->z2));
-        require(pt_eq(lhs, rhs));
+    // the closing equation  ((Gamma_hat c + beta) a_hat + delta == (g_hat + a_hat G) z1 + z2 h)  as FOUR deferred jobs: the two halves of
+    // Gamma_hat (log n decompressions and a small variable-base sum each) and the right-hand side run side by side on the workers, the
+    // fourth job waits for them (jobs are claimed in order, so the three are under way or done when it starts) and finishes the chain.
+    struct Closing { Pt half[2], rhs; std::atomic<int> done{0}, ok{0}; };
+    struct Arrive { Closing &c; bool good = false; ~Arrive() { if (good) c.ok.fetch_add(1, std::memory_order_release); c.done.fetch_add(1, std::memory_order_release); } };
+    auto st = std::make_shared<Closing>();
+    auto half = [=](int which) {
+        Arrive arr{*st};
+        std::vector<Pt> pts(lg + 1); std::vector<Fr> sc(which ? chi : ch);
+        for (size_t i = 0; i < lg; i++) pts[i] = dec(which ? p->R_vec[i] : p->L_vec[i]);
+        if (which == 0) { sc.push_back(fr_one()); pts[lg] = pt_add(dec(Cx), dec(Cy)); }
+        st->half[which] = host_msm(sc.data(), pts.data(), sc.size());
+        arr.good = true;
     };
-    if (later) later->push_back(closing); else closing();
+    auto right = [=] {
+        Arrive arr{*st};
+        st->rhs = pt_add(host_scalarmul(pt_add(g_hat, host_scalarmul(gp->P[v.g1], a_hat)), p->z1), host_scalarmul(gp->P[v.h1], p->z2));
+        arr.good = true;
+    };
+    auto closing = [=] {
+        while (st->done.load(std::memory_order_acquire) < 3) {
+#if defined(__x86_64__)
+            _mm_pause();
+#endif
+        }
+        if (st->ok.load(std::memory_order_acquire) < 3) return;            // the job that failed has reported why
+        const Pt Gamma_hat = pt_add(st->half[0], st->half[1]);
+        const Pt lhs = pt_add(host_scalarmul(pt_add(host_scalarmul(Gamma_hat, c), dec(p->beta)), a_hat), dec(p->delta));
+        require(pt_eq(lhs, st->rhs));
+    };
+    if (later) { later->push_back([=] { half(0); }); later->push_back([=] { half(1); }); later->push_back(right); later->push_back(closing); }
+    else { half(0); half(1); right(); closing(); }
     lap(later ? "closing equation (deferred)" : "Gamma_hat, closing equation");
 }
 // R1CSProof::verify: `tr` already carries the caller's protocol name (NIZK / SNARK); returns the challenges the transcript produced
-int r1cs_verify_host(const NizkProof &P, size_t N, size_t V, const std::vector<Fr> &inputs, const Fr inst_evals[3], const Gens &g, Transcript &tr,
-                     std::vector<Fr> &rx, std::vector<Fr> &ry) {
+int r1cs_verify_host(const NizkProof &P, size_t N, size_t V, const std::vector<Fr> &inputs, const Fr inst_evals_given[3], const Gens &g, Transcript &tr,
+                     std::vector<Fr> &rx, std::vector<Fr> &ry, const InstEvalFetch *fetch) {
     try {
         const size_t nrx = ilog2(N), nry = ilog2(2 * V);
         size_t ell = ilog2(V), Lsz = (size_t)1 << (ell / 2), Rsz = (size_t)1 << (ell - ell / 2);
@@ -620,6 +642,8 @@ int r1cs_verify_host(const NizkProof &P, size_t N, size_t V, const std::vector<F
         }
         Pt comm_eval_Z = pt_add(host_scalarmul(dec(P.comm_vars_at_ry), fr_sub(one, ry[0])),
                                 host_scalarmul(commit_scalar_pt(g, g.pc_1, poly_input_eval, fr_zero()), ry[0]));
+        Fr inst_evals[3];                                                  // A, B, C at (rx, ry): given, or collected now from an evaluation begun before the rounds
+        if (fetch) (*fetch)(inst_evals); else for (int k = 0; k < 3; k++) inst_evals[k] = inst_evals_given[k];
         Fr comb = fr_add(fr_add(fr_mul(rA, inst_evals[0]), fr_mul(rB, inst_evals[1])), fr_mul(rC, inst_evals[2]));
         CPoint expected2; pt_encode(expected2.b, host_scalarmul(comm_eval_Z, comb));
         equality_verify(P.eq2, g, tr, expected2, comm_post2, later);
@@ -632,7 +656,7 @@ int r1cs_verify_host(const NizkProof &P, size_t N, size_t V, const std::vector<F
 }
 
 int nizk_verify(const Instance &I, const std::vector<Fr> &inputs, const Gens &g, const void *tlabel, size_t tlabel_len, const uint8_t *proof,
-                size_t proof_len, const Fr *inst_evals_opt) {
+                size_t proof_len, const Fr *inst_evals_opt, const InstEvalFetch *fetch) {
     try {
         if (inputs.size() != I.num_inputs) return OTTI_ERR_INVALID_NUM_INPUTS;
         NizkProof P = NizkProof::parse(proof, proof_len);
@@ -642,9 +666,9 @@ int nizk_verify(const Instance &I, const std::vector<Fr> &inputs, const Gens &g,
         tr.append_protocol_name("Spartan NIZK proof");
         Fr inst_evals[3];
         if (inst_evals_opt) { inst_evals[0] = inst_evals_opt[0]; inst_evals[1] = inst_evals_opt[1]; inst_evals[2] = inst_evals_opt[2]; }
-        else I.evaluate(P.rx, P.ry, inst_evals);
+        else if (!fetch) I.evaluate(P.rx, P.ry, inst_evals);
         std::vector<Fr> rx, ry;
-        if (int rc = r1cs_verify_host(P, N, V, inputs, inst_evals, g, tr, rx, ry)) return rc;
+        if (int rc = r1cs_verify_host(P, N, V, inputs, inst_evals, g, tr, rx, ry, inst_evals_opt ? nullptr : fetch)) return rc;
         for (size_t i = 0; i < nrx; i++) if (!fr_eq(rx[i], P.rx[i])) return OTTI_ERR_VERIFY_INTERNAL;
         for (size_t i = 0; i < nry; i++) if (!fr_eq(ry[i], P.ry[i])) return OTTI_ERR_VERIFY_INTERNAL;
         return OTTI_OK;
