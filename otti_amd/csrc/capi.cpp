@@ -80,6 +80,11 @@ int32_t otti_host_selftest(uint32_t iterations) {
             const Pt want = pt_add(rnd, host_scalarmul(g->P[base], s));
             pt_encode_ref(a, acc); pt_encode_ref(b, want);
             if (memcmp(a, b, 32)) throw Error(OTTI_ERR_INTERNAL, "fixed-base table result differs from the variable-base multiplication");
+            {   // the four-way split multiplication (verifier rounds) against the plain one
+                SplitTable st; split_table_build(st, rnd);
+                pt_encode_ref(a, split_table_mul(st, s)); pt_encode_ref(b, host_scalarmul(rnd, s));
+                if (memcmp(a, b, 32)) throw Error(OTTI_ERR_INTERNAL, "split_table_mul differs from host_scalarmul");
+            }
             {   // five-limb extended addition against the generic one
                 PtFe x = ptfe_from(rnd); ptfe_add(x, ptfe_from(want));
                 pt_encode_fe(a, x); pt_encode_ref(b, pt_add(rnd, want));

@@ -40,6 +40,28 @@ Pt host_scalarmul(const Pt &p, const Fr &s) {
     return ptfe_to(acc);
 }
 
+void split_table_build(SplitTable &T, const Pt &p) {
+    PtFe base = ptfe_from(p);
+    for (int q = 0; q < 4; q++) {
+        if (q) for (int k = 0; k < 64; k++) ptfe_dbl(base);
+        PtFe m = base; const CachedFe c1 = ptfe_cache(m);
+        T.tab[q][0] = c1;
+        for (int i = 1; i < 8; i++) { ptfe_add_cached(m, c1, false); T.tab[q][i] = ptfe_cache(m); }
+    }
+}
+Pt split_table_mul(const SplitTable &T, const Fr &s) {
+    int dig[64]; scalar_digits(s, 4, 64, dig);               // s = sum_q 2^(64 q) sum_{j < 16} dig[16 q + j] 16^j
+    PtFe acc = ptfe_identity();
+    for (int j = 15; j >= 0; j--) {
+        if (j != 15) for (int k = 0; k < 4; k++) ptfe_dbl(acc);
+        for (int q = 0; q < 4; q++) {
+            const int d = dig[16 * q + j];
+            if (d) ptfe_add_cached(acc, T.tab[q][(d > 0 ? d : -d) - 1], d < 0);
+        }
+    }
+    return ptfe_to(acc);
+}
+
 Pt host_msm(const Fr *s, const Pt *P, size_t n) {
     if (n == 0) return pt_identity();
     if (n < 24) {

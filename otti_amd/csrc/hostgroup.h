@@ -11,6 +11,13 @@ namespace otti {
 
 Pt host_scalarmul(const Pt &p, const Fr &s);
 Pt host_msm(const Fr *s, const Pt *P, size_t n);            // sum s[i] * P[i]
+// A point that will be multiplied by scalars not known yet (a verifier's sum-check commitments: in the proof from the start, their
+// scalars are transcript challenges): the multiples 1..8 of P, 2^64 P, 2^128 P, 2^192 P prepared ahead (192 doublings, off the
+// sequential path), so that the multiplication itself is a four-way Straus walk of 64 doublings and at most 64 additions — a third
+// of host_scalarmul's chain.
+struct SplitTable { CachedFe tab[4][8]; };
+void split_table_build(SplitTable &T, const Pt &p);
+Pt split_table_mul(const SplitTable &T, const Fr &s);
 void host_batch_invert(Fp *x, size_t n);                    // in place, no zeros allowed
 
 // signed radix-2^c digits (c <= 16) of a Montgomery-form scalar; nwin = floor(253/c) + 1

@@ -468,21 +468,22 @@ void dotproduct_verify(const DotProductProof &pf, const Gens &g, const GensView 
     later.push_back([=] { require(pt_eq(pt_add(host_scalarmul(dec(Cy), c), dec(p->beta)), commit_scalar_pt(*gp, gp->sc_1, za, p->z_beta))); });
 }
 // The commitments a sum-check's rounds decompress ON the sequential path (comm_evals: each one is combined with a challenge and the
-// result is hashed before the next round can start) are decompressed ahead of it by the background threads, a few per task; the round
-// takes the point if it is there and decompresses it itself if not.  State: 0 pending, 1 a point, 2 not an encoding.
+// result is hashed before the next round can start) are decompressed ahead of it by the background threads, one per task; the round
+// takes the prepared multiples if they are there and starts from the encoding itself if not.  State: 0 pending, 1 ready, 2 not an encoding.
 struct PreDecoded {
-    const std::vector<CPoint> *src = nullptr; std::vector<Pt> pts; std::unique_ptr<std::atomic<int>[]> state;
+    const std::vector<CPoint> *src = nullptr; std::vector<SplitTable> tabs; std::unique_ptr<std::atomic<int>[]> state;
     void start(const std::vector<CPoint> &v, Deferred &later) {
-        src = &v; pts.resize(v.size()); state.reset(new std::atomic<int>[v.size()]);
+        src = &v; tabs.resize(v.size()); state.reset(new std::atomic<int>[v.size()]);
         for (size_t i = 0; i < v.size(); i++) state[i].store(0, std::memory_order_relaxed);
-        for (size_t i0 = 0; i0 < v.size(); i0 += 4)
-            later.push_back([this, i0] { for (size_t i = i0; i < std::min(src->size(), i0 + 4); i++) { Pt p; const bool ok = pt_decode_fast(p, (*src)[i].b); pts[i] = p; state[i].store(ok ? 1 : 2, std::memory_order_release); } });
+        for (size_t i = 0; i < v.size(); i++)
+            later.push_back([this, i] { Pt p; const bool ok = pt_decode_fast(p, (*src)[i].b); if (ok) split_table_build(tabs[i], p); state[i].store(ok ? 1 : 2, std::memory_order_release); });
     }
-    Pt get(size_t i) const {
+    // s * (point i): from the prepared table when a worker has finished it (hostgroup.h SplitTable: a third of the chain), else from scratch
+    Pt mul(size_t i, const Fr &s) const {
         const int st = state ? state[i].load(std::memory_order_acquire) : 0;
-        if (st == 1) return pts[i];
+        if (st == 1) return split_table_mul(tabs[i], s);
         if (st == 2) throw VerifyFail{OTTI_ERR_VERIFY_DECOMPRESS};
-        return dec((*src)[i]);
+        return host_scalarmul(dec((*src)[i]), s);
     }
 };
 // ZKSumcheckInstanceProof::verify
@@ -500,8 +501,8 @@ CPoint sumcheck_verify(const ZKSumcheckProof &pf, const CPoint &comm_claim, size
         // the combined claim's commitment is hashed ("Cy" below), so it stays on the sequential path: its two halves on two threads
         Pt half[2]; int bad[2] = {0, 0};
         std::function<void()> halves[2] = {
-            [&] { try { half[0] = host_scalarmul((pre && i) ? pre->get(i - 1) : dec(ccpr), w[0]); } catch (const VerifyFail &f) { bad[0] = f.code; } },
-            [&] { try { half[1] = host_scalarmul(pre ? pre->get(i) : dec(pf.comm_evals[i]), w[1]); } catch (const VerifyFail &f) { bad[1] = f.code; } }};
+            [&] { try { half[0] = (pre && i) ? pre->mul(i - 1, w[0]) : host_scalarmul(dec(ccpr), w[0]); } catch (const VerifyFail &f) { bad[0] = f.code; } },
+            [&] { try { half[1] = pre ? pre->mul(i, w[1]) : host_scalarmul(dec(pf.comm_evals[i]), w[1]); } catch (const VerifyFail &f) { bad[1] = f.code; } }};
         SpinPool::get().parallel(halves, 2);
         if (bad[0] || bad[1]) throw VerifyFail{bad[0] ? bad[0] : bad[1]};
         CPoint comm_target; pt_encode(comm_target.b, pt_add(half[0], half[1]));
