@@ -199,7 +199,7 @@ int32_t otti_gens_table_info(const otti_gens *gens, uint32_t *window_bits, uint6
         if (!gens) throw Error(OTTI_ERR_BAD_ARG, "null argument");
         const DeviceGens *d = gens->g->dev.get();
         if (window_bits) *window_bits = d ? (uint32_t)d->c : 0;
-        if (table_bytes) *table_bytes = d ? (uint64_t)d->table.n * sizeof(Niels) : 0;
+        if (table_bytes) *table_bytes = d ? (uint64_t)d->table.n * sizeof(TabEntry) : 0;
         return OTTI_OK;
     });
 }

@@ -46,8 +46,8 @@ struct DeviceShard { int rank = 0, world = 1; DeviceCsrSet by_row, by_col; };
 
 // fixed-base window table: entry (base b, window w, digit d in 1..E) = d * 2^(c*w) * P[b] in affine Niels form
 struct DeviceGens {
-    DevBuf<Niels> table; int c = 0, W = 0; size_t E = 0, nbases = 0;
-    const Niels *entry0(size_t base) const { return table.p + base * (size_t)W * E; }
+    DevBuf<TabEntry> table; int c = 0, W = 0; size_t E = 0, nbases = 0;
+    const TabEntry *entry0(size_t base) const { return table.p + base * (size_t)W * E; }
 };
 
 // where a sum-check kernel's last workgroup delivers the round's totals (see finish_in_kernel)

@@ -23,7 +23,7 @@ static_assert(kMsmBulkChunk + 8 <= 2048, "work-list entries pack the term index 
 __device__ __attribute__((noinline)) Fr fr_mul_shared(Fr a, Fr b) { return fr_mul(a, b); }
 struct BulletArgs { int on, fold; uint32_t n; const Fr *a_in, *b_in, *s_in; Fr *a_out, *b_out, *s_out; Fr u, uinv, u_raw, uinv_raw; };
 struct MsmArgs {
-    const Niels *table; int c, W; uint32_t E; int lanes;            // lanes = 256 / W term lanes
+    const TabEntry *table; int c, W; uint32_t E; int lanes;            // lanes = 256 / W term lanes
     const Fr *dense; size_t stride, n_dense; uint32_t chunk, nchunks;
     const Fr *extra_s; uint32_t extra_base[8]; int n_extra;
     uint32_t K[9];                                                  // recoding constant (288 bits)
@@ -129,7 +129,7 @@ template <int kKind> __global__ __launch_bounds__(kBlock) void k_msm_rows(MsmArg
                 const int d = recoded_digit(s_raw + t * 9, (int)ww, A.c);
                 const size_t base = T < n_here ? j0 + T : (size_t)s_base[T - n_here];
                 const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
-                N10 e = n10_unpack(A.table[base * WE + (size_t)ww * A.E + (mag - 1)]);
+                N10 e = n10_unpack(A.table[base * WE + (size_t)ww * A.E + (mag - 1)].n);
                 if (d < 0) e = n10_negate(e);
                 acc = p10_madd(acc, e);
             }
@@ -153,7 +153,7 @@ template <int kKind> __global__ __launch_bounds__(kBlock) void k_msm_rows(MsmArg
                     const uint32_t T = sub0 + t;
                     size_t base = T < n_here ? j0 + T : (size_t)s_base[T - n_here];
                     uint32_t mag = (uint32_t)(d < 0 ? -d : d);
-                    N10 e = n10_unpack(A.table[base * WE + (size_t)w * A.E + (mag - 1)]);
+                    N10 e = n10_unpack(A.table[base * WE + (size_t)w * A.E + (mag - 1)].n);
                     if (d < 0) e = n10_negate(e);
                     acc = p10_madd(acc, e);
                 }
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(kBlock) void k_msm_small(MsmArgs A) {
             const int d = recoded_digit(s_raw + t * 9, (int)w, A.c);
             if (d == 0) return;
             const size_t base = t < n_here ? (bullet ? bullet_slot(U, row, j0 + t) : j0 + t) : (size_t)s_base[t - n_here];
-            const Niels *e = &A.table[base * WE + (size_t)w * A.E + ((uint32_t)(d < 0 ? -d : d) - 1)];
+            const Niels *e = &A.table[base * WE + (size_t)w * A.E + ((uint32_t)(d < 0 ? -d : d) - 1)].n;
             nxt_neg = d < 0; nxt_have = true;
             if (q < 3) nxt = reinterpret_cast<const Fp *>(e)[q == 2 ? 2 : (((q == 0) != nxt_neg) ? 1 : 0)];   // Niels = {yplusx, yminusx, xy2d}
         };
@@ -496,13 +496,13 @@ __global__ __launch_bounds__(kBlock) void k_table_starts(const Pt *bases, size_t
     row[0] = acc;
     for (size_t k = 1; k < nblk; k++) { acc = pt_add(acc, TB); row[k] = acc; }
 }
-__global__ __launch_bounds__(kBlock) void k_table_fill(const Pt *starts, size_t nrows, size_t nblk, size_t T, Pt *tmp, Niels *out) {
+__global__ __launch_bounds__(kBlock) void k_table_fill(const Pt *starts, size_t nrows, size_t nblk, size_t T, Pt *tmp, TabEntry *out) {
     size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (t >= nrows * nblk) return;
     const size_t r = t / nblk;
     const Pt B = starts[r * nblk];
     Pt acc = starts[t];
-    Pt *blk = tmp + t * T; Niels *oblk = out + t * T;                                      // row r, block k: entries r*E + k*T ..
+    Pt *blk = tmp + t * T; TabEntry *oblk = out + t * T;                                      // row r, block k: entries r*E + k*T ..
     Fp prod = fp_one();
     for (size_t d = 0; d < T; d++) {
         if (d) acc = pt_add(acc, B);
@@ -510,7 +510,7 @@ __global__ __launch_bounds__(kBlock) void k_table_fill(const Pt *starts, size_t 
         blk[d] = p; prod = fp_mul(prod, acc.Z);
     }
     Fp inv = fp_inv(prod);
-    for (size_t d = T; d-- > 0;) { Pt p = blk[d]; Fp zinv = fp_mul(inv, p.T); inv = fp_mul(inv, p.Z); oblk[d] = pt_to_niels(p, zinv); }
+    for (size_t d = T; d-- > 0;) { Pt p = blk[d]; Fp zinv = fp_mul(inv, p.T); inv = fp_mul(inv, p.Z); oblk[d].n = pt_to_niels(p, zinv); }
 }
 std::shared_ptr<DeviceGens> build_device_gens(const Gens &g, int c) {
     DevCtx &ctx = DevCtx::get();

@@ -8,6 +8,12 @@ namespace otti {
 
 struct Pt { Fp X, Y, Z, T; };                 // extended twisted Edwards, a = -1; 128 B
 struct Niels { Fp yplusx, yminusx, xy2d; };   // affine precomputed form for mixed addition; 96 B
+// one entry of the fixed-base window table (k_msm.hip).  OTTI_TABLE_ALIGN128 pads it to a 128-byte line of its own.
+#ifdef OTTI_TABLE_ALIGN128
+struct alignas(128) TabEntry { Niels n; uint32_t pad[8]; };
+#else
+struct TabEntry { Niels n; };
+#endif
 
 HD Pt pt_identity() { Pt p; p.X = fp_zero(); p.Y = fp_one(); p.Z = fp_one(); p.T = fp_zero(); return p; }
 HD Niels niels_identity() { Niels n; n.yplusx = fp_one(); n.yminusx = fp_one(); n.xy2d = fp_zero(); return n; }

@@ -31,7 +31,7 @@ int device_window_bits(size_t nbases) {
     int best = 8;
     const int widest = nbases < 256 ? 12 : 16;             // tiny instances (R < 256) are launch-bound whatever the window: keep their tables small
     for (int c = 8; c <= widest; c++) {
-        const double W = 253 / c + 1, bytes = (double)nbases * W * (double)((size_t)1 << (c - 1)) * sizeof(Niels);
+        const double W = 253 / c + 1, bytes = (double)nbases * W * (double)((size_t)1 << (c - 1)) * sizeof(TabEntry);
         if (bytes <= budget_gb * 1073741824.0) best = c;
     }
     return best;
