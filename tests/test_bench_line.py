@@ -36,12 +36,16 @@ def test_committed_two_rank_rehearsal_line_carries_cpu_baseline_transports_and_s
 @pytest.mark.gpu
 def test_two_rank_rehearsal_of_the_drivers_command(tmp_path):
     env = dict(os.environ); env["OTTI_BENCH_REHEARSE"] = "1"; env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["OTTI_BENCH_REHEARSE_SNARK"] = "1"; env["OTTI_MSM_TABLE_GB"] = "16"          # the SNARK replicas leg too; two ranks' window tables on ONE card
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29533",
            os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--log2-constraints", "18", "--sweep", "16", "--in-flight", "-1"]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1]
-    _check_sharded_line(json.loads(line), 2)
+    d = json.loads(line)
+    _check_sharded_line(d, 2)
+    sn = d["snark"]                                                      # SNARK mode at N > 1: one independent proof per rank, checked against the committed digest
+    assert sn and "error" not in sn and sn["value"] > 0 and sn["scaling"] == "weak" and sn["n_gpus"] == 2 and sn["equals_oracle_digest"] is True, sn
 
 
 @pytest.mark.gpu
