@@ -32,6 +32,7 @@ Extras in the same line (all measured in this run, none of them the headline):
   snark         SNARK mode on the same workload: SNARK::encode once (untimed: preprocessing of the circuit), then SNARK::prove = the
                 headline's R1CSProof + R1CSEvalProof; its own roofline (dominant class over SNARK::prove's kernels); commitment and
                 proof compared with the oracle digests committed in tests/golden/snark_proofs.json; CPU oracle on a bounded 2^16 sample
+                (N > 1: one independent SNARK::prove per GPU between barriers — SNARK mode is not sharded — aggregate over the ranks, "scaling": "weak")
   spzk_e2e      the path run.py actually executes: `spzk verify --nizk` on a zkInterface triple of the workload, one process
 Every timed proof is checked: identical bytes across steps (fixed seed), accepted by the verifier, equal to the oracle's committed
 digest for the size; rank 0 also compares a 2^12 proof with the CPU oracle (checker only, outside the timed region) and, when the CPU
