@@ -7,7 +7,7 @@ import csv
 import json
 import sys
 
-KERNELS = ("k_msm_rows<0>", "k_msm_small", "k_msm_rows<2>", "k_sc_cubic3_fold_eval", "k_sc_quad_fold_eval", "k_sc_cubic3_eval", "k_sc_quad_eval", "k_spmv3_light", "k_eq_expand",
+KERNELS = ("k_msm_rows<0>", "k_msm_small", "k_msm_rows<2>", "k_sc_cubic3_fold_eval", "k_sc_quad_fold_eval", "k_sc_cubic3_eval", "k_sc_quad_eval", "k_spmv3_light", "k_spmv3_light<true>", "k_spmv3_light<false>", "k_spmv3_quad<true>", "k_spmv3_quad<false>", "k_spmv3_heavy_seg<true>", "k_eq_expand",
            "k_poly_bound_slab", "k_gather_strided",
            # SNARK mode (k_snark.hip) and the verifier's kernels
            "k_pc_round<true>", "k_pc_round<false>", "k_pc_tail", "k_prod_layer", "k_hash_ops", "k_hash_mem", "k_gather", "k_dot_many", "k_sum3", "k_msm_var", "k_decode_niels")
