@@ -210,19 +210,20 @@ struct TailArgs {
     TailMail *mail; Fr *host_out; unsigned long long seq0; Armed go;        // go.want: the go() number of the first round's challenge
     unsigned long long *stamps;                                             // OTTI_TAIL_STAMPS: wall_clock64 (100 MHz) of workgroup (0,0) at the phase boundaries, 8 per round
 };
-// sums acc[0..3) over the waves [0, active_waves) of the workgroup into s_tot[0..3) (LDS); every thread of the workgroup calls it
-__device__ __forceinline__ void tail_reduce3(Fr (&acc)[3], uint32_t busy, Fr (*s_part)[16], Fr *s_tot) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, active_waves = (int)((busy + 63) / 64);
-    if (wave < active_waves) {
-        int top = 64; if (busy < 64) { top = 1; while ((uint32_t)top < busy) top <<= 1; }      // lanes at and beyond `busy` hold zero: only as many levels as there is data
+// A wave works on ONE evaluation point (wave % 3) and group g = wave / 3 takes the pairs g*64 + lane, + 64*groups, ...: no divergence over
+// the point inside a wave, and a wave's 64 partial sums of its one point fold by shuffles of ONE field element per level (the first
+// version gave every lane its own point and reduced three elements, two of them zero, over all lanes: 11 us at 1024 elements per table).
+// s_part[pt][g] <- the wave's sum; threads 0..2 add the groups that had pairs into s_tot[0..3).  Every thread of the workgroup calls it.
+__device__ __forceinline__ void tail_reduce1(Fr acc, int pt, int grp, int ngrp, uint32_t half, Fr (*s_part)[16], Fr *s_tot) {
+    const int lane = threadIdx.x & 63, groups = (int)min((uint32_t)ngrp, (half + 63) / 64);
+    if (grp < groups) {
+        int top = 64; if (half < 64) { top = 1; while ((uint32_t)top < half) top <<= 1; }          // lanes at and beyond `half` hold zero: only as many levels as there is data
 #pragma unroll 1
-        for (int off = top >> 1; off >= 1; off >>= 1)
-#pragma unroll
-            for (int k = 0; k < 3; k++) acc[k] = fr_add(acc[k], shfl_xor_fr(acc[k], off));
-        if (lane == 0) for (int k = 0; k < 3; k++) s_part[k][wave] = acc[k];
+        for (int off = top >> 1; off >= 1; off >>= 1) acc = fr_add(acc, shfl_xor_fr(acc, off));
+        if (lane == 0) s_part[pt][grp] = acc;
     }
     __syncthreads();
-    if (threadIdx.x < 3) { Fr t = s_part[threadIdx.x][0]; for (int w = 1; w < active_waves; w++) t = fr_add(t, s_part[threadIdx.x][w]); s_tot[threadIdx.x] = t; }
+    if (threadIdx.x < 3) { Fr t = s_part[threadIdx.x][0]; for (int g = 1; g < groups; g++) t = fr_add(t, s_part[threadIdx.x][g]); s_tot[threadIdx.x] = t; }
     __syncthreads();
 }
 __device__ __forceinline__ void tail_post(TailMail *m, const Fr *s_tot, bool with_sums, unsigned long long seq) {
@@ -253,13 +254,13 @@ __global__ __launch_bounds__(kTailThreads) void k_pc_tail(TailArgs a) {
     const uint32_t L_out = a.t_out / (uint32_t)W;
     unsigned long long *stamp = (a.stamps && tid == 0 && w == 0 && y == 0) ? a.stamps : nullptr; int rnd = 0;
     if (stamp) stamp[0] = wall_clock64();
-    const int pt = tid % 3, q0 = tid / 3, qn = nthr / 3;                // thread -> evaluation point (0, 2, 3) and first pair; the last thread of 1024 idles
+    const int wave = tid >> 6, lane = tid & 63, ngrp = (nthr >> 6) / 3, pt = wave % 3, grp = wave / 3;   // wave -> evaluation point (0, 2, 3) and group of pairs; the 16th wave of 1024 threads idles
     while (L > L_out) {
         const uint32_t half = L / 2;
         // ---- this round's sums: S_t = sum over pairs of (A_t B_t C_t), t in {0, 2, 3}
         Fr acc = fr_zero();
-        if (tid < 3 * qn)
-            for (uint32_t p = q0; p < half; p += qn) {
+        if (grp < ngrp)
+            for (uint32_t p = (uint32_t)grp * 64 + lane; p < half; p += (uint32_t)ngrp * 64) {
                 Fr x[3];
 #pragma unroll
                 for (int t = 0; t < 3; t++) {
@@ -269,12 +270,8 @@ __global__ __launch_bounds__(kTailThreads) void k_pc_tail(TailArgs a) {
                 }
                 acc = fr_add(acc, fr_mul(fr_mul(x[0], x[1]), x[2]));
             }
-        Fr acc3[3];
-#pragma unroll
-        for (int k = 0; k < 3; k++) acc3[k] = (k == pt && tid < 3 * qn) ? acc : fr_zero();
-        const uint32_t busy = min((uint32_t)(3 * qn), 3 * half);        // threads [0, busy) had a pair
         if (stamp) stamp[8 * rnd + 1] = wall_clock64();               // sums done
-        tail_reduce3(acc3, busy, s_part, s_tot);
+        tail_reduce1(acc, pt, grp, ngrp, half, s_part, s_tot);
         if (stamp) stamp[8 * rnd + 2] = wall_clock64();               // reduced
         tail_post(mail, s_tot, true, seq++);
         if (stamp) stamp[8 * rnd + 3] = wall_clock64();               // mailed
