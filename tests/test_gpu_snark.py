@@ -136,3 +136,51 @@ def test_persistent_tail_variants_give_the_oracles_proof(lg, env):
     assert res.returncode == 0, res.stdout + res.stderr
     line = [ln for ln in res.stdout.splitlines() if ln.startswith("DIGEST")][-1].split()
     assert line[1] == g["commitment_sha256"] and line[2] == g["proof_sha256"], (env, res.stderr)
+
+
+def test_concurrent_snark_and_nizk_provers_in_one_process_match_the_oracle():
+    """Three prover threads in one process — two in SNARK mode (2^14: the size from which a lone proof commits its dereferenced rows
+    ahead of time on a helper thread's CU-masked stream and arms its launches; with company it must do neither) and one in NIZK mode —
+    each proving several times while the others start and finish around it: every proof equals the oracle's, whatever the number of
+    proofs in flight was when it started."""
+    import threading
+    cases = []
+    for k, (n, kind) in enumerate([(1 << 14, "uniform"), (1 << 14, "compiler"), (1 << 13, "uniform")]):
+        r, nz = _case(n, 10, kind, seed=11 + k)
+        oi = orc.OInstance(r["num_cons"], r["num_vars"], r["num_inputs"], r["A"], r["B"], r["C"])
+        inst = oa.Instance.new(r["num_cons"], r["num_vars"], r["num_inputs"], r["A"], r["B"], r["C"])
+        if k < 2:
+            og, gens = orc.OSnarkGens(r["num_cons"], r["num_vars"], r["num_inputs"], nz), oa.SNARKGens.new(r["num_cons"], r["num_vars"], r["num_inputs"], nz)
+            oc, comm = orc.OSnarkComm.encode(oi, og), oa.ComputationCommitment.encode(inst, gens)
+            assert comm.bytes == oc.bytes
+            want = [orc.snark_prove(oi, oc, r["vars"], r["inputs"], og, LABEL, bytes([s]) * 32)[0] for s in (1, 2)]
+            cases.append(("snark", r, inst, gens, comm, want))
+        else:
+            og, gens = orc.OGens(r["num_cons"], r["num_vars"], r["num_inputs"]), oa.NIZKGens.new(r["num_cons"], r["num_vars"], r["num_inputs"])
+            want = [orc.nizk_prove(oi, r["vars"], r["inputs"], og, LABEL, bytes([s]) * 32)[0] for s in (1, 2)]
+            cases.append(("nizk", r, inst, gens, None, want))
+    bad, go = [], threading.Event()
+
+    def worker(idx):
+        mode, r, inst, gens, comm, want = cases[idx]
+        v, i = oa.VarsAssignment.new(r["vars"]), oa.InputsAssignment.new(r["inputs"])
+        go.wait()
+        try:
+            for rep in range(6):
+                s = 1 + rep % 2
+                p = (oa.SNARK.prove(inst, comm, v, i, gens, LABEL, bytes([s]) * 32) if mode == "snark" else oa.NIZK.prove(inst, v, i, gens, LABEL, bytes([s]) * 32))
+                if p.bytes != want[s - 1]:
+                    bad.append((idx, rep, "bytes differ"))
+        except Exception as ex:                                    # noqa: BLE001 — reported by the main thread
+            bad.append((idx, -1, repr(ex)))
+
+    ths = [threading.Thread(target=worker, args=(k,)) for k in range(3)]
+    for t in ths:
+        t.start()
+    go.set()
+    for t in ths:
+        t.join()
+    assert not bad, bad
+    # and alone again afterwards: the lone-proof path (ahead-of-time rows, armed launches, persistent tail) on the contexts the threads left behind
+    mode, r, inst, gens, comm, want = cases[0]
+    assert oa.SNARK.prove(inst, comm, oa.VarsAssignment.new(r["vars"]), oa.InputsAssignment.new(r["inputs"]), gens, LABEL, b"\x01" * 32).bytes == want[0]
