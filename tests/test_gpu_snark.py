@@ -184,3 +184,40 @@ def test_concurrent_snark_and_nizk_provers_in_one_process_match_the_oracle():
     # and alone again afterwards: the lone-proof path (ahead-of-time rows, armed launches, persistent tail) on the contexts the threads left behind
     mode, r, inst, gens, comm, want = cases[0]
     assert oa.SNARK.prove(inst, comm, oa.VarsAssignment.new(r["vars"]), oa.InputsAssignment.new(r["inputs"]), gens, LABEL, b"\x01" * 32).bytes == want[0]
+
+
+def _degenerate(name):
+    base = oa.synth_r1cs(64, 3, 5)
+    empty = base["A"][:0]
+    if name == "all matrices empty":
+        return dict(base, A=empty, B=empty, C=empty)
+    if name == "A and C empty":                                   # 0 * (B z) = 0
+        return dict(base, A=empty, C=empty)
+    if name == "B and C empty":
+        return dict(base, B=empty, C=empty)
+    if name == "one constraint, no inputs":
+        return oa.synth_r1cs(1, 0, 3)
+    if name == "three constraints":
+        return oa.synth_r1cs(3, 2, 3)
+    return oa.synth_r1cs(1 << 12, 0, 3)                           # "no inputs"
+
+
+@pytest.mark.parametrize("name", ["all matrices empty", "A and C empty", "B and C empty", "one constraint, no inputs", "three constraints", "no inputs"])
+def test_empty_and_degenerate_instances_in_both_modes(name):
+    """matrices without entries (SNARK mode pads each to two operations), a single constraint, no public inputs: commitment and proofs
+    of both modes against the oracle, both verifiers accept"""
+    r = _degenerate(name)
+    nz = int(max(r["A"].size, r["B"].size, r["C"].size, 1))
+    oi = orc.OInstance(r["num_cons"], r["num_vars"], r["num_inputs"], r["A"], r["B"], r["C"])
+    inst = oa.Instance.new(r["num_cons"], r["num_vars"], r["num_inputs"], r["A"], r["B"], r["C"])
+    v, i = oa.VarsAssignment.new(r["vars"]), oa.InputsAssignment.new(r["inputs"])
+    og, gens = orc.OSnarkGens(r["num_cons"], r["num_vars"], r["num_inputs"], nz), oa.SNARKGens.new(r["num_cons"], r["num_vars"], r["num_inputs"], nz)
+    oc, comm = orc.OSnarkComm.encode(oi, og), oa.ComputationCommitment.encode(inst, gens)
+    assert comm.bytes == oc.bytes
+    p = oa.SNARK.prove(inst, comm, v, i, gens, LABEL, SEED)
+    assert p.bytes == orc.snark_prove(oi, oc, r["vars"], r["inputs"], og, LABEL, SEED)[0]
+    p.verify(oa.ComputationCommitment.from_bytes(comm.bytes), i, gens, LABEL)
+    ng, ong = oa.NIZKGens.new(r["num_cons"], r["num_vars"], r["num_inputs"]), orc.OGens(r["num_cons"], r["num_vars"], r["num_inputs"])
+    pn = oa.NIZK.prove(inst, v, i, ng, LABEL, SEED)
+    assert pn.bytes == orc.nizk_prove(oi, r["vars"], r["inputs"], ong, LABEL, SEED)[0]
+    pn.verify(inst, i, ng, LABEL)
