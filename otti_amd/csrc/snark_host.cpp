@@ -82,7 +82,8 @@ struct Reader {
     }
     DotProductProofLog dplog() {
         DotProductProofLog d; d.L_vec = pts(64); d.R_vec = pts(64); d.delta = pt(); d.beta = pt(); d.z1 = fr(); d.z2 = fr();
-        if (d.L_vec.size() != d.R_vec.size()) throw Error(OTTI_ERR_MALFORMED_PROOF, "bullet reduction vectors"); return d;
+        if (d.L_vec.size() != d.R_vec.size()) throw Error(OTTI_ERR_MALFORMED_PROOF, "bullet reduction vectors");
+        return d;
     }
     ZKSumcheckProof sc() {
         ZKSumcheckProof s; s.comm_polys = pts(64); s.comm_evals = pts(64); size_t k = len(64); s.proofs.resize(k);
