@@ -118,6 +118,29 @@ int32_t otti_host_selftest(uint32_t iterations) {
             pt_encode_fast(a, pt_identity()); pt_encode_ref(b, pt_identity());
             if (memcmp(a, b, 32)) throw Error(OTTI_ERR_INTERNAL, "identity encodes differently");
         }
+        {   // the transcript's fused message operations (hash.h Strobe128::merlin_append / merlin_challenge) against the separate STROBE
+            // operations they stand for: random labels and messages of 0 .. 100 bytes, so that every position of the rate block, the
+            // block boundary and the long-message fallback are all crossed many times
+            Strobe128 fused("Merlin v1.0"), plain("Merlin v1.0");
+            for (uint32_t it = 0; it < 40 * iterations + 2000; it++) {
+                uint8_t rnd[8]; xof.squeeze(rnd, 8);
+                const size_t L = 1 + rnd[0] % 30, n = rnd[1] % 101; const bool chal = (rnd[2] & 3) == 0;
+                char label[32]; uint8_t msg[128], o1[128], o2[128];
+                xof.squeeze(label, L); xof.squeeze(msg, n ? n : 1);
+                const uint8_t len[4] = {(uint8_t)n, 0, 0, 0};
+                if (chal) {
+                    fused.merlin_challenge(label, L, o1, n);
+                    plain.meta_ad(label, L, false); plain.meta_ad(len, 4, true); plain.prf(o2, n, false);
+                    if (memcmp(o1, o2, n)) throw Error(OTTI_ERR_INTERNAL, "fused transcript challenge differs from the separate STROBE operations");
+                } else {
+                    fused.merlin_append(label, L, msg, n);
+                    plain.meta_ad(label, L, false); plain.meta_ad(len, 4, true); plain.ad(msg, n, false);
+                }
+            }
+            uint8_t o1[64], o2[64];
+            fused.prf(o1, 64, false); plain.prf(o2, 64, false);
+            if (memcmp(o1, o2, 64)) throw Error(OTTI_ERR_INTERNAL, "fused transcript operations left a different state");
+        }
         return OTTI_OK;
     });
 }

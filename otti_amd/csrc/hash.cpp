@@ -108,17 +108,46 @@ void Strobe128::ad(const void *d, size_t n, bool more) { begin_op(FA, more); abs
 void Strobe128::prf(void *out, size_t n, bool more) { begin_op(FI | FA | FC, more); squeeze((uint8_t *)out, n); }
 void Strobe128::key(const void *d, size_t n, bool more) { begin_op(FA | FC, more); overwrite((const uint8_t *)d, n); }
 
-static void le32(uint8_t b[4], size_t n) { b[0] = (uint8_t)n; b[1] = (uint8_t)(n >> 8); b[2] = (uint8_t)(n >> 16); b[3] = (uint8_t)(n >> 24); }
+// framing of one message: [old_begin, M|A] label len4 [begin of the first op, flags2]; returns its length.  p0 = position before the message.
+static inline size_t merlin_frame(uint8_t *b, uint8_t old_begin, uint8_t p0, const char *label, size_t L, size_t n, uint8_t flags2) {
+    b[0] = old_begin; b[1] = FM | FA;
+    memcpy(b + 2, label, L);
+    b[2 + L] = (uint8_t)n; b[3 + L] = (uint8_t)(n >> 8); b[4 + L] = (uint8_t)(n >> 16); b[5 + L] = (uint8_t)(n >> 24);
+    b[6 + L] = (uint8_t)(p0 + 1); b[7 + L] = flags2;
+    return 8 + L;
+}
+void Strobe128::merlin_append(const char *label, size_t L, const void *msg, size_t n) {
+    const size_t total = 8 + L + n;
+    if (L > 64 || n > 64 || (size_t)pos_ + total >= (size_t)kRate) {       // near the end of the block (or an unusually long message): the separate operations
+        uint8_t len[4] = {(uint8_t)n, (uint8_t)(n >> 8), (uint8_t)(n >> 16), (uint8_t)(n >> 24)};
+        meta_ad(label, L, false); meta_ad(len, 4, true); ad(msg, n, false);
+        return;
+    }
+    uint8_t b[8 + 64 + 64];
+    const uint8_t p0 = pos_;
+    const size_t f = merlin_frame(b, pos_begin_, p0, label, L, n, FA);
+    memcpy(b + f, msg, n);
+    xor_bytes(st_ + p0, b, total);
+    pos_ = (uint8_t)(p0 + total); pos_begin_ = (uint8_t)(p0 + 6 + L + 1); cur_flags_ = FA;     // the second operation began after header, label and length
+}
+void Strobe128::merlin_challenge(const char *label, size_t L, void *out, size_t n) {
+    if (L > 64 || (size_t)pos_ + 8 + L >= (size_t)kRate) {
+        uint8_t len[4] = {(uint8_t)n, (uint8_t)(n >> 8), (uint8_t)(n >> 16), (uint8_t)(n >> 24)};
+        meta_ad(label, L, false); meta_ad(len, 4, true); prf(out, n, false);
+        return;
+    }
+    uint8_t b[8 + 64];
+    const uint8_t p0 = pos_;
+    const size_t f = merlin_frame(b, pos_begin_, p0, label, L, n, FI | FA | FC);
+    xor_bytes(st_ + p0, b, f);
+    pos_ = (uint8_t)(p0 + f); pos_begin_ = (uint8_t)(p0 + 6 + L + 1); cur_flags_ = FI | FA | FC;
+    run_f();                                                                // a C operation starts on a fresh block (pos_ != 0 here)
+    squeeze((uint8_t *)out, n);
+}
 
 Transcript::Transcript(const void *label, size_t n) : s_("Merlin v1.0") { append_message("dom-sep", label, n); }
-void Transcript::append_message(const char *label, const void *msg, size_t n) {
-    uint8_t len[4]; le32(len, n);
-    s_.meta_ad(label, strlen(label), false); s_.meta_ad(len, 4, true); s_.ad(msg, n, false);
-}
-void Transcript::challenge_bytes(const char *label, void *out, size_t n) {
-    uint8_t len[4]; le32(len, n);
-    s_.meta_ad(label, strlen(label), false); s_.meta_ad(len, 4, true); s_.prf(out, n, false);
-}
+void Transcript::append_message(const char *label, const void *msg, size_t n) { s_.merlin_append(label, strlen(label), msg, n); }
+void Transcript::challenge_bytes(const char *label, void *out, size_t n) { s_.merlin_challenge(label, strlen(label), out, n); }
 void Transcript::append_scalars(const char *label, const Fr *s, size_t n) {
     append_message(label, "begin_append_vector", 19);
     for (size_t i = 0; i < n; i++) append_scalar(label, s[i]);

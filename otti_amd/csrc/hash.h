@@ -30,6 +30,12 @@ public:
     void ad(const void *d, size_t n, bool more);
     void prf(void *out, size_t n, bool more);
     void key(const void *d, size_t n, bool more);
+    // One whole Merlin message in a single pass over the state: meta_ad(label) ‖ meta_ad(len, more) ‖ ad(msg)  (append_message), or the
+    // same framing followed by prf(out)  (challenge_bytes).  A proof makes ~25 of these per sum-check round, each 40-60 bytes: as
+    // separate operations that is five small absorbs and two operation headers apiece, most of the transcript's time on the
+    // sequential path.  Same bytes into the same positions as the separate operations (falls back to them at a rate boundary).
+    void merlin_append(const char *label, size_t label_len, const void *msg, size_t n);
+    void merlin_challenge(const char *label, size_t label_len, void *out, size_t n);
 private:
     void run_f(); void absorb(const uint8_t *d, size_t n); void overwrite(const uint8_t *d, size_t n);
     void squeeze(uint8_t *d, size_t n); void begin_op(uint8_t flags, bool more);
