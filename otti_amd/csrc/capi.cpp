@@ -80,6 +80,16 @@ int32_t otti_host_selftest(uint32_t iterations) {
             const Pt want = pt_add(rnd, host_scalarmul(g->P[base], s));
             pt_encode_ref(a, acc); pt_encode_ref(b, want);
             if (memcmp(a, b, 32)) throw Error(OTTI_ERR_INTERNAL, "fixed-base table result differs from the variable-base multiplication");
+            if (host_ifma_available()) {   // the AVX-512 IFMA mixed addition (hostifma.h) against the scalar five-limb one, both signs, on a point with lazily reduced limbs
+                const NielsFe &ne = g->small_tables[slot].t[(it * 37) % g->small_tables[slot].t.size()];
+                const Niels4 n4 = niels4_from(ne);
+                for (int neg = 0; neg < 2; neg++) {
+                    PtFe x1 = ptfe_from(rnd), x2 = x1;
+                    for (int k = 0; k < 3; k++) { ptfe_madd(x1, ne, neg != 0); ifma_madd(x2, n4, neg != 0); }
+                    pt_encode_fe(a, x1); pt_encode_fe(b, x2);
+                    if (memcmp(a, b, 32)) throw Error(OTTI_ERR_INTERNAL, "IFMA mixed addition differs from the scalar one");
+                }
+            }
             {   // the four-way split multiplication (verifier rounds) against the plain one
                 SplitTable st; split_table_build(st, rnd);
                 pt_encode_ref(a, split_table_mul(st, s)); pt_encode_ref(b, host_scalarmul(rnd, s));

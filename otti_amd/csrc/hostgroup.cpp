@@ -125,10 +125,12 @@ void FixedBaseTable::build(const Pt &base) {
     host_batch_invert(z.data(), z.size());
     t.resize(ext.size());
     for (size_t i = 0; i < ext.size(); i++) t[i] = nielsfe_from(pt_to_niels(ext[i], z[i]));
+    if (host_ifma_available()) { t4.resize(t.size()); for (size_t i = 0; i < t.size(); i++) t4[i] = niels4_from(t[i]); }
 }
 
 void FixedBaseTable::accumulate(PtFe &acc, const Fr &s) const {
     int dig[kHostWindows]; scalar_digits(s, kHostWinBits, kHostWindows, dig);
+    if (!t4.empty()) { ifma_accumulate(acc, t4.data(), dig, 0, kHostWindows); return; }     // two 4-way products per addition instead of seven scalar ones
     for (int w = 0; w < kHostWindows; w++) {
         const int d = dig[w];
         if (d) ptfe_madd(acc, t[(size_t)w * kHostWinEntries + (d > 0 ? d : -d) - 1], d < 0);

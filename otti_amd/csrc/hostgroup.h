@@ -6,6 +6,7 @@
 #include <utility>
 #include "point.h"
 #include "hostfast.h"
+#include "hostifma.h"
 
 namespace otti {
 
@@ -26,6 +27,7 @@ void scalar_digits(const Fr &s, int c, int nwin, int *digits);
 constexpr int kHostWinBits = 8, kHostWindows = 32, kHostWinEntries = 128;   // 2^(c-1) entries per window
 struct FixedBaseTable {
     std::vector<NielsFe> t;                                 // [w * 128 + (|d| - 1)] = |d| * 2^(8w) * B, five 51-bit limbs per coordinate (hostfast.h)
+    std::vector<Niels4> t4;                                 // the same entries in four-lane layout when the CPU has AVX-512 IFMA (hostifma.h); empty otherwise
     void build(const Pt &base);
     void accumulate(Pt &acc, const Fr &s) const;            // acc += s * B  (32 mixed additions)
     void accumulate(PtFe &acc, const Fr &s) const;          // the same without converting the accumulator in and out

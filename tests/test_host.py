@@ -6,6 +6,7 @@ import json
 import os
 import re
 import subprocess
+import sys
 import numpy as np
 import pytest
 
@@ -295,8 +296,30 @@ def test_host_verifiers_under_thread_sanitizer(tmp_path):
 
 
 def test_host_fast_paths_agree_with_the_generic_field_code():
-    """five-limb GF(2^255-19) point compression and the fixed-base window tables of the prover's per-round host work (hostfast.h)"""
+    """five-limb GF(2^255-19) point compression, the fixed-base window tables of the prover's per-round host work (hostfast.h; with
+    AVX-512 IFMA where the CPU has it: hostifma.h), the verifier's split multiplication tables, the transcript's fused message operations"""
     oa.host_selftest(300)
+
+
+def test_host_paths_without_avx512_ifma():
+    """OTTI_HOST_IFMA=0 (what a CPU without the instructions runs): the same self-test, and the product's host verifiers on the oracle's
+    proofs of both modes — whichever of the two arithmetic paths the other tests took on this machine, this one takes the scalar one"""
+    import subprocess
+    code = """
+import sys, os
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'))
+import otti_amd as oa, orc
+oa.host_selftest(100)
+r = oa.synth_r1cs_compiler_like(100, 3, 4)
+oi, og = orc.OInstance(r['num_cons'], r['num_vars'], r['num_inputs'], r['A'], r['B'], r['C']), orc.OGens(r['num_cons'], r['num_vars'], r['num_inputs'])
+proof, _ = orc.nizk_prove(oi, r['vars'], r['inputs'], og, b'noifma', bytes([5]) * 32)
+inst = oa.Instance.new(r['num_cons'], r['num_vars'], r['num_inputs'], r['A'], r['B'], r['C'])
+gens = oa.NIZKGens.new(r['num_cons'], r['num_vars'], r['num_inputs'])
+oa.NIZK(proof).verify(inst, oa.InputsAssignment.new(r["inputs"]), gens, b"noifma")
+print('ok')
+""" % (ROOT, ROOT)
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, OTTI_HOST_IFMA="0"))
+    assert res.returncode == 0 and "ok" in res.stdout, res.stdout[-1000:] + res.stderr[-3000:]
 
 
 @pytest.mark.parametrize("n,ni,kind", [(16, 3, "uniform"), (200, 4, "compiler"), (1 << 10, 10, "uniform")])

@@ -39,7 +39,7 @@ with tempfile.TemporaryDirectory() as d:
     exe = os.path.join(d, "roundbench")
     cxx = "/opt/rocm/lib/llvm/bin/clang++" if os.path.exists("/opt/rocm/lib/llvm/bin/clang++") else "g++"
     subprocess.check_call([cxx, "-O3", "-std=c++17", "-march=x86-64-v3", "-I" + S, "-Wno-unused-result", os.path.join(ROOT, "tools", "roundbench", "main.cpp"), timed] +
-                          [os.path.join(S, f) for f in ("hash.cpp", "hostfast.cpp", "hostgroup.cpp", "snark_host.cpp")] + ["-o", exe, "-lpthread"])
+                          [os.path.join(S, f) for f in ("hash.cpp", "hostfast.cpp", "hostifma.cpp", "hostgroup.cpp", "snark_host.cpp")] + ["-o", exe, "-lpthread"])
     env = dict(os.environ); env["OTTI_HOST_THREADS"] = sys.argv[1] if len(sys.argv) > 1 else "4"
     for _ in range(3):
         subprocess.check_call([exe], env=env)
