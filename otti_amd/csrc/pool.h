@@ -3,6 +3,7 @@
 // spinning host threads halves the per-round latency.  Workers spin only while a proof is in flight (Session), otherwise they sleep.
 #pragma once
 #include <sched.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <string.h>
 #include <algorithm>
@@ -18,6 +19,50 @@
 #endif
 
 namespace otti {
+
+// ---- where helper threads run.  A prover thread hands its helpers a few microseconds of work dozens of times per proof; on a
+// two-socket, many-CCX host (the GPU boxes: 2 x 64 cores, 16 L3 groups) the scheduler is free to put a helper on the other socket,
+// where every hand-over and every table lookup crosses the fabric (measured: a 1.3 us task taking 7 us).  Helpers are therefore
+// kept on cores that share the last-level cache with the thread they serve, one core each, never that thread's own core
+// (OTTI_PIN_HELPERS=0: leave them to the scheduler).  Linux sysfs; anything missing or refused leaves the affinity alone.
+namespace cpu_place {
+inline bool read_cpu_list(const char *path, std::vector<int> &out) {
+    out.clear();
+    FILE *f = fopen(path, "r"); if (!f) return false;
+    char buf[512] = {0}; const bool ok = fgets(buf, sizeof buf, f) != nullptr; fclose(f);
+    if (!ok) return false;
+    for (char *p = buf; *p;) {
+        if (*p < '0' || *p > '9') { p++; continue; }
+        const long a = strtol(p, &p, 10); long b = a;
+        if (*p == '-') b = strtol(p + 1, &p, 10);
+        for (long x = a; x <= b && out.size() < 4096; x++) out.push_back((int)x);
+    }
+    return !out.empty();
+}
+inline std::vector<int> siblings_of(int cpu) {
+    char path[128]; snprintf(path, sizeof path, "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", cpu);
+    std::vector<int> v; if (!read_cpu_list(path, v)) v = {cpu};
+    return v;
+}
+// one entry per physical core that shares the L3 with `cpu`, the core of `cpu` itself excluded: each entry = that core's logical CPUs
+inline std::vector<std::vector<int>> neighbour_cores(int cpu) {
+    std::vector<std::vector<int>> cores;
+    char path[128]; snprintf(path, sizeof path, "/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", cpu);
+    std::vector<int> l3; if (!read_cpu_list(path, l3)) return cores;
+    const std::vector<int> mine = siblings_of(cpu);
+    std::vector<char> seen(4096, 0);
+    for (int m : mine) if (m >= 0 && m < 4096) seen[m] = 1;
+    for (int x : l3) {
+        if (x < 0 || x >= 4096 || seen[x]) continue;
+        std::vector<int> sib = siblings_of(x);
+        for (int y : sib) if (y >= 0 && y < 4096) seen[y] = 1;
+        cores.push_back(sib);
+    }
+    return cores;
+}
+inline std::atomic<int> &sessions() { static std::atomic<int> n{0}; return n; }       // prover threads with a Session open, process-wide
+inline bool enabled() { static const bool on = [] { const char *e = getenv("OTTI_PIN_HELPERS"); return !(e && e[0] == '0'); }(); return on; }
+}  // namespace cpu_place
 
 class SpinPool {
 public:
@@ -87,9 +132,35 @@ private:
         for (auto &t : th_) t.join();
     }
     void set_active(bool on) {
-        if (on) { active_.fetch_add(1); std::lock_guard<std::mutex> lk(mu_); cv_.notify_all(); }
-        else active_.fetch_sub(1);
+        if (on) {
+            // one prover at work in the process: its helpers go next to it.  Several (proofs in flight on their own threads): the
+            // scheduler spreads the threads better than a rule that would put every prover's helpers on the first cores of its L3 group
+            if (cpu_place::sessions().fetch_add(1) == 0) place_helpers(); else release_helpers();
+            active_.fetch_add(1); std::lock_guard<std::mutex> lk(mu_); cv_.notify_all();
+        } else { active_.fetch_sub(1); cpu_place::sessions().fetch_sub(1); }
     }
+    void release_helpers() {
+        if (placed_for_ < 0) return;
+        placed_for_ = -1;
+        cpu_set_t all; CPU_ZERO(&all);
+        if (sched_getaffinity(0, sizeof all, &all) != 0) return;         // the calling thread's own mask: what the helpers were created with
+        for (auto &t : th_) (void)pthread_setaffinity_np(t.native_handle(), sizeof all, &all);
+    }
+    // helper i on the i-th core that shares the L3 with the calling thread's current CPU; redone only when that thread has moved to another core
+    void place_helpers() {
+        if (th_.empty() || !cpu_place::enabled()) return;
+        const int cpu = sched_getcpu();
+        if (cpu < 0 || cpu == placed_for_) return;
+        placed_for_ = cpu;
+        const std::vector<std::vector<int>> cores = cpu_place::neighbour_cores(cpu);
+        if (cores.size() < th_.size()) return;                   // fewer neighbour cores than helpers (or no topology information): leave them alone
+        for (size_t i = 0; i < th_.size(); i++) {
+            cpu_set_t set; CPU_ZERO(&set);
+            for (int x : cores[i]) if (x < CPU_SETSIZE) CPU_SET(x, &set);
+            (void)pthread_setaffinity_np(th_[i].native_handle(), sizeof set, &set);
+        }
+    }
+    int placed_for_ = -1;
     void run(int i) {
         Slot &s = slots_[i];
         for (;;) {
