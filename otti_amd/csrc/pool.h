@@ -135,13 +135,24 @@ private:
         if (on) {
             // one prover at work in the process: its helpers go next to it.  Several (proofs in flight on their own threads): the
             // scheduler spreads the threads better than a rule that would put every prover's helpers on the first cores of its L3 group
-            if (cpu_place::sessions().fetch_add(1) == 0) place_helpers(); else release_helpers();
+            if (cpu_place::sessions().fetch_add(1) == 0) { place_helpers(); hold_caller(); } else release_helpers();
             active_.fetch_add(1); std::lock_guard<std::mutex> lk(mu_); cv_.notify_all();
-        } else { active_.fetch_sub(1); cpu_place::sessions().fetch_sub(1); }
+        } else { active_.fetch_sub(1); cpu_place::sessions().fetch_sub(1); free_caller(); }
     }
+    // for the length of the session the calling thread stays on the free cores of the group its helpers were placed in (it would
+    // otherwise wander — onto a helper's core, or to another group and away from its helpers and its warm tables); its own mask comes back after
+    void hold_caller() {
+        if (placed_for_ < 0 || group_.empty() || caller_held_) return;
+        if (sched_getaffinity(0, sizeof saved_mask_, &saved_mask_) != 0) return;
+        cpu_set_t set; CPU_ZERO(&set); int n = 0;
+        for (int x = 0; x < (int)group_.size() && x < CPU_SETSIZE; x++) if (group_[x] == 1 && CPU_ISSET(x, &saved_mask_)) { CPU_SET(x, &set); n++; }
+        if (n && sched_setaffinity(0, sizeof set, &set) == 0) caller_held_ = true;
+    }
+    void free_caller() { if (caller_held_) { (void)sched_setaffinity(0, sizeof saved_mask_, &saved_mask_); caller_held_ = false; } }
+    cpu_set_t saved_mask_; bool caller_held_ = false;
     void release_helpers() {
         if (placed_for_ < 0) return;
-        placed_for_ = -1;
+        placed_for_ = -1; group_.clear();
         cpu_set_t all; CPU_ZERO(&all);
         if (sched_getaffinity(0, sizeof all, &all) != 0) return;         // the calling thread's own mask: what the helpers were created with
         for (auto &t : th_) (void)pthread_setaffinity_np(t.native_handle(), sizeof all, &all);
@@ -151,9 +162,15 @@ private:
         if (th_.empty() || !cpu_place::enabled()) return;
         const int cpu = sched_getcpu();
         if (cpu < 0 || cpu == placed_for_) return;
+        // still in the L3 group the helpers were placed for, and not on a core one of them holds: nothing to do (the calling thread is
+        // not pinned and wanders between the cores of a group; re-reading sysfs per proof would cost more than it saves)
+        if (placed_for_ >= 0 && cpu < (int)group_.size() && group_[cpu] == 1) { return; }
         placed_for_ = cpu;
         const std::vector<std::vector<int>> cores = cpu_place::neighbour_cores(cpu);
+        group_.assign(4096, 0);
         if (cores.size() < th_.size()) return;                   // fewer neighbour cores than helpers (or no topology information): leave them alone
+        for (int x : cpu_place::siblings_of(cpu)) if (x >= 0 && x < 4096) group_[x] = 1;
+        for (size_t i = 0; i < cores.size(); i++) for (int x : cores[i]) if (x >= 0 && x < 4096) group_[x] = i < th_.size() ? 2 : 1;   // 2: a helper's core
         for (size_t i = 0; i < th_.size(); i++) {
             cpu_set_t set; CPU_ZERO(&set);
             for (int x : cores[i]) if (x < CPU_SETSIZE) CPU_SET(x, &set);
@@ -161,6 +178,7 @@ private:
         }
     }
     int placed_for_ = -1;
+    std::vector<char> group_;                                     // per logical CPU: 1 = in the L3 group the helpers were placed for and free, 2 = a helper's core
     void run(int i) {
         Slot &s = slots_[i];
         for (;;) {
