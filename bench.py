@@ -134,6 +134,34 @@ def usable_cores():
     return n
 
 
+def bind_rank_to_l3_groups(local_rank, local_world):
+    """N > 1: every rank process on L3 groups of its own (the launcher's job where there is one — mpirun --bind-to l3cache; torch.distributed.run
+    has no such option).  The library keeps a prover thread's spinning helper threads on cores that share the L3 with it (pool.h); two
+    ranks whose prover threads the scheduler happened to put into one group would put their helpers on the same cores.  Returns the
+    CPUs bound to, or None when the topology cannot be read or the mask cannot be set."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0)); groups, seen = [], set()
+        for cpu in allowed:
+            if cpu in seen:
+                continue
+            txt = open("/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list" % cpu).read().strip()
+            members = set()
+            for part in txt.split(","):
+                lo, _, hi = part.partition("-")
+                members.update(range(int(lo), int(hi or lo) + 1))
+            members &= set(allowed); seen |= members
+            if members:
+                groups.append(sorted(members))
+        per = len(groups) // local_world
+        if per < 1:
+            return None
+        mine = sorted(c for g in groups[local_rank * per:(local_rank + 1) * per] for c in g)
+        os.sched_setaffinity(0, mine)
+        return mine
+    except Exception:                                          # noqa: BLE001 — no topology files, a cpuset that refuses: leave the process where it is
+        return None
+
+
 def golden_digest(kind, n):
     """committed oracle digests (tests/golden/): kind 'nizk' -> proofs.json, 'snark' -> snark_proofs.json; None when the size is not there"""
     try:
@@ -181,7 +209,8 @@ def main():
     # ONE over the real RCCL backend: how the N > 1 path is exercised on a one-GPU box beyond the gloo rehearsal
     shard = (world > 1 or bool(os.environ.get("OTTI_FORCE_SHARD"))) and not args.replicas
     lws = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
-    cores_here = max(1, usable_cores() // lws)                  # host cores of this rank
+    bound_cpus = bind_rank_to_l3_groups(local_rank, lws) if (lws > 1 and os.environ.get("OTTI_BENCH_BIND", "1") != "0") else None
+    cores_here = max(1, usable_cores() if bound_cpus else usable_cores() // lws)   # host cores of this rank (a bound rank's mask is already its share)
     conc = 0 if args.in_flight < 0 else (args.in_flight if args.in_flight > 0 else max(1, min(6, cores_here // 2)))
     # host threads of the single-proof prover (itself + spinning helpers for the per-round sigma-protocol work)
     os.environ.setdefault("OTTI_HOST_THREADS", str(max(1, min(4, cores_here))))
@@ -747,7 +776,8 @@ def main():
                                + "(SURVEY 8d); witness/instance/generators resident in HBM; one step = one NIZK::prove, one proof at a time",
                    "parallelism": ("1 proof sharded over %d GPUs (%s exchange of the per-round sums)" % (world, transport)) if shard else
                                   ("1 independent proof per GPU" if world > 1 else "single GPU"),
-                   "msm_window_bits": cbits, "msm_table_GB": round(table_bytes / 1e9, 2), "armed_launches": armed_on},
+                   "msm_window_bits": cbits, "msm_table_GB": round(table_bytes / 1e9, 2), "armed_launches": armed_on,
+                   "rank_cpu_binding": ("each rank on %d L3 groups of its own (rank 0: %d logical CPUs)" % (len(bound_cpus) // 16 or 1, len(bound_cpus))) if bound_cpus else None},
         "roofline": roofline,
         "field_mul": field_mul,
         "cpu_baseline": cpu_baseline,
