@@ -166,7 +166,15 @@ private:
         // not pinned and wanders between the cores of a group; re-reading sysfs per proof would cost more than it saves)
         if (placed_for_ >= 0 && cpu < (int)group_.size() && group_[cpu] == 1) { return; }
         placed_for_ = cpu;
-        const std::vector<std::vector<int>> cores = cpu_place::neighbour_cores(cpu);
+        std::vector<std::vector<int>> cores = cpu_place::neighbour_cores(cpu);
+        {   // only cores the calling thread itself may run on (a caller confined by taskset / a cpuset keeps its helpers inside that set)
+            cpu_set_t mine; CPU_ZERO(&mine);
+            if (sched_getaffinity(0, sizeof mine, &mine) == 0) {
+                std::vector<std::vector<int>> ok;
+                for (auto &c : cores) { bool in = !c.empty(); for (int x : c) in = in && x < CPU_SETSIZE && CPU_ISSET(x, &mine); if (in) ok.push_back(c); }
+                cores.swap(ok);
+            }
+        }
         group_.assign(4096, 0);
         if (cores.size() < th_.size()) return;                   // fewer neighbour cores than helpers (or no topology information): leave them alone
         for (int x : cpu_place::siblings_of(cpu)) if (x >= 0 && x < 4096) group_[x] = 1;
