@@ -115,6 +115,7 @@ struct DevCtx {
     DevBuf<Pt> msm_partial, msm_final;                        // [rows][chunks] partial sums, [rows] row sums
     Pt *h_pts = nullptr; size_t pending_host_encode = 0;      // pinned: row sums of small launches, compressed on the host in sync()
     uint8_t *h_points = nullptr;                              // pinned: compressed points coming back
+    uint8_t *d_points_host = nullptr;                         // the device's address of h_points: the encode kernel writes there as well (no copy engine round trip)
     DevBuf<uint8_t> d_points;
     size_t msm_partial_cap = 0, points_cap = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;

@@ -115,6 +115,7 @@ void DevCtx::ensure_points(size_t rows, size_t splits) {
         if (stream) OTTI_HIP(hipStreamSynchronize(stream));
         if (h_points) (void)hipHostFree(h_points);
         OTTI_HIP(hipHostMalloc((void **)&h_points, want_rows * 32, hipHostMallocDefault));
+        if (hipHostGetDevicePointer((void **)&d_points_host, h_points, 0) != hipSuccess) { (void)hipGetLastError(); d_points_host = nullptr; }
         d_points.alloc(want_rows * 32); msm_final.alloc(want_rows); points_cap = want_rows;
     }
     if (!h_pts) {
