@@ -90,6 +90,18 @@ int32_t otti_host_selftest(uint32_t iterations) {
                     if (memcmp(a, b, 32)) throw Error(OTTI_ERR_INTERNAL, "IFMA mixed addition differs from the scalar one");
                 }
             }
+            {   // host_scalarmul (windowed; AVX-512 IFMA doublings and additions where the CPU has them) against plain double-and-add in the generic
+                // 4 x u64 code of point.h, and a small multi-scalar sum against the sum of the single products
+                const Fr raw = fr_to_raw(s);
+                Pt ref = pt_identity();
+                for (int bit = 255; bit >= 0; bit--) { ref = pt_dbl(ref); if ((raw.v[bit / 32] >> (bit % 32)) & 1) ref = pt_add(ref, rnd); }
+                pt_encode_ref(a, host_scalarmul(rnd, s)); pt_encode_ref(b, ref);
+                if (memcmp(a, b, 32)) throw Error(OTTI_ERR_INTERNAL, "host_scalarmul differs from double-and-add");
+                const Fr s3[3] = {s, fr_neg(s), fr_add(s, fr_one())}; const Pt p3[3] = {rnd, g->P[1], g->P[2]};
+                Pt sum = pt_add(pt_add(host_scalarmul(p3[0], s3[0]), host_scalarmul(p3[1], s3[1])), host_scalarmul(p3[2], s3[2]));
+                pt_encode_ref(a, host_msm(s3, p3, 3)); pt_encode_ref(b, sum);
+                if (memcmp(a, b, 32)) throw Error(OTTI_ERR_INTERNAL, "host_msm differs from the sum of its terms");
+            }
             {   // the four-way split multiplication (verifier rounds) against the plain one
                 SplitTable st; split_table_build(st, rnd);
                 pt_encode_ref(a, split_table_mul(st, s)); pt_encode_ref(b, host_scalarmul(rnd, s));

@@ -26,12 +26,23 @@ void scalar_digits(const Fr &s, int c, int nwin, int *digits) {
 
 // Variable-base work of the verifiers, in the five-limb field of hostfast.h (the generic 4 x u64 code is ~3x slower per point operation;
 // a NIZK verification makes 82 scalar multiplications of proof points on its sequential path, a SNARK verification six MSMs of 2-4 k points)
+// the multiples 1 .. 8 of a point in cached form, four-lane layout (hostifma.h)
+static void multiples8_ifma(Niels4 *out, PtFe m) {
+    const CachedFe c1 = ptfe_cache(m);
+    out[0] = cached4_from(c1);
+    for (int i = 1; i < 8; i++) { ptfe_add_cached(m, c1, false); out[i] = cached4_from(ptfe_cache(m)); }
+}
 Pt host_scalarmul(const Pt &p, const Fr &s) {
     // signed 4-bit windows, table of 1..8 multiples in cached form
+    int dig[64]; scalar_digits(s, 4, 64, dig);
+    if (host_ifma_available()) {                                // doublings and additions as two 4-way products each (hostifma.h)
+        Niels4 tab4[8]; multiples8_ifma(tab4, ptfe_from(p));
+        PtFe acc; ifma_straus(acc, tab4, 1, dig, 64);
+        return ptfe_to(acc);
+    }
     CachedFe tab[8]; PtFe m = ptfe_from(p); const CachedFe c1 = ptfe_cache(m);
     tab[0] = c1;
     for (int i = 1; i < 8; i++) { ptfe_add_cached(m, c1, false); tab[i] = ptfe_cache(m); }
-    int dig[64]; scalar_digits(s, 4, 64, dig);
     PtFe acc = ptfe_identity();
     for (int w = 63; w >= 0; w--) {
         for (int k = 0; k < 4; k++) ptfe_dbl(acc);
@@ -42,6 +53,11 @@ Pt host_scalarmul(const Pt &p, const Fr &s) {
 
 void split_table_build(SplitTable &T, const Pt &p) {
     PtFe base = ptfe_from(p);
+    T.ifma = host_ifma_available();
+    if (T.ifma) {
+        for (int q = 0; q < 4; q++) { if (q) ifma_dbl_n(base, 64); multiples8_ifma(T.tab4[q], base); }
+        return;
+    }
     for (int q = 0; q < 4; q++) {
         if (q) for (int k = 0; k < 64; k++) ptfe_dbl(base);
         PtFe m = base; const CachedFe c1 = ptfe_cache(m);
@@ -51,6 +67,7 @@ void split_table_build(SplitTable &T, const Pt &p) {
 }
 Pt split_table_mul(const SplitTable &T, const Fr &s) {
     int dig[64]; scalar_digits(s, 4, 64, dig);               // s = sum_q 2^(64 q) sum_{j < 16} dig[16 q + j] 16^j
+    if (T.ifma) { PtFe acc; ifma_straus(acc, &T.tab4[0][0], 4, dig, 16); return ptfe_to(acc); }   // table q, window j: digit dig[16 q + j]
     PtFe acc = ptfe_identity();
     for (int j = 15; j >= 0; j--) {
         if (j != 15) for (int k = 0; k < 4; k++) ptfe_dbl(acc);
@@ -64,6 +81,12 @@ Pt split_table_mul(const SplitTable &T, const Fr &s) {
 
 Pt host_msm(const Fr *s, const Pt *P, size_t n) {
     if (n == 0) return pt_identity();
+    if (n < 24 && host_ifma_available()) {
+        std::vector<Niels4> tab4(n * 8); std::vector<int> dig(n * 64);
+        for (size_t i = 0; i < n; i++) { multiples8_ifma(&tab4[8 * i], ptfe_from(P[i])); scalar_digits(s[i], 4, 64, &dig[64 * i]); }
+        PtFe acc; ifma_straus(acc, tab4.data(), (int)n, dig.data(), 64);
+        return ptfe_to(acc);
+    }
     if (n < 24) {
         // Straus: shared doublings, per-point 4-bit signed tables
         std::vector<CachedFe> tab(n * 8); std::vector<int> dig(n * 64);

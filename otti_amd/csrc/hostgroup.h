@@ -16,7 +16,7 @@ Pt host_msm(const Fr *s, const Pt *P, size_t n);            // sum s[i] * P[i]
 // scalars are transcript challenges): the multiples 1..8 of P, 2^64 P, 2^128 P, 2^192 P prepared ahead (192 doublings, off the
 // sequential path), so that the multiplication itself is a four-way Straus walk of 64 doublings and at most 64 additions — a third
 // of host_scalarmul's chain.
-struct SplitTable { CachedFe tab[4][8]; };
+struct SplitTable { CachedFe tab[4][8]; Niels4 tab4[4][8]; bool ifma = false; };   // tab4: the same multiples in four-lane layout when the CPU has AVX-512 IFMA (then tab is not filled)
 void split_table_build(SplitTable &T, const Pt &p);
 Pt split_table_mul(const SplitTable &T, const Fr &s);
 void host_batch_invert(Fp *x, size_t n);                    // in place, no zeros allowed

@@ -33,6 +33,12 @@ static inline void canon(Fe &a) {                            // every limb below
         c = a.v[0] >> 51; a.v[0] &= M; a.v[1] += c;
     }
 }
+Niels4 cached4_from(const CachedFe &c0) {
+    CachedFe c = c0; canon(c.yplusx); canon(c.yminusx); canon(c.z2); canon(c.t2d);
+    Niels4 r;
+    for (int k = 0; k < 5; k++) { r.v[k][0] = c.yminusx.v[k]; r.v[k][1] = c.yplusx.v[k]; r.v[k][2] = c.t2d.v[k]; r.v[k][3] = c.z2.v[k]; }
+    return r;
+}
 Niels4 niels4_from(const NielsFe &n0) {
     NielsFe n = n0; canon(n.yplusx); canon(n.yminusx); canon(n.xy2d);
     Niels4 r;
@@ -125,7 +131,62 @@ OTTI_IFMA V5 vmadd(const V5 &P, const Niels4 &q, bool negate) {
     }
     return vmul(vreduce(M1), vreduce(M2));                                // (E F, G H, E H, F G) = (X3, Y3, T3, Z3)
 }
+// 4p - b per limb (b below 2^53 - 76)
+OTTI_IFMA V5 vneg4p(const V5 &b) {
+    V5 r;
+    r.l[0] = _mm256_sub_epi64(_mm256_set1_epi64x(0x1FFFFFFFFFFFB4LL), b.l[0]);
+    const __m256i p = _mm256_set1_epi64x(0x1FFFFFFFFFFFFCLL);
+    for (int k = 1; k < 5; k++) r.l[k] = _mm256_sub_epi64(p, b.l[k]);
+    return r;
+}
+// dbl-2008-hwcd (a = -1) as a 4-way squaring and a 4-way product (lanes X, Y, T, Z in and out)
+OTTI_IFMA V5 vdbl(const V5 &P) {
+    const __m256i z = _mm256_setzero_si256();
+    V5 S;
+    for (int k = 0; k < 5; k++) {
+        const __m256i a = _mm256_permute4x64_epi64(P.l[k], 0x34);                     // (X, Y, Z, X): 00 01 11 00 -> imm 0b00_11_01_00
+        const __m256i b = _mm256_blend_epi32(z, _mm256_permute4x64_epi64(P.l[k], 0x55), 0xC0);   // (0, 0, 0, Y)
+        S.l[k] = _mm256_add_epi64(a, b);                                              // (X, Y, Z, X + Y)
+    }
+    S = vreduce(S);
+    const V5 Q = vmul(S, S);                                                          // (A, B, ZZ, W) = (X^2, Y^2, Z^2, (X + Y)^2)
+    V5 a4, b4, zz4, w4;
+    for (int k = 0; k < 5; k++) {
+        a4.l[k] = _mm256_permute4x64_epi64(Q.l[k], 0x00); b4.l[k] = _mm256_permute4x64_epi64(Q.l[k], 0x55);
+        zz4.l[k] = _mm256_permute4x64_epi64(Q.l[k], 0xAA); w4.l[k] = _mm256_permute4x64_epi64(Q.l[k], 0xFF);
+    }
+    const V5 na = vneg2p(a4), nb = vneg2p(b4);
+    const V5 G = vadd(b4, na), H = vadd(na, nb);                                      // G = B - A, H = -A - B  (D = -A)
+    const V5 E = vadd(w4, H);                                                         // (X + Y)^2 - A - B
+    const V5 F = vadd(G, vneg4p(vadd(zz4, zz4)));                                     // G - 2 ZZ
+    V5 M1, M2;
+    for (int k = 0; k < 5; k++) {
+        M1.l[k] = _mm256_blend_epi32(_mm256_blend_epi32(E.l[k], G.l[k], 0x0C), F.l[k], 0xC0);        // (E, G, E, F)
+        M2.l[k] = _mm256_blend_epi32(_mm256_blend_epi32(H.l[k], F.l[k], 0x03), G.l[k], 0xC0);        // (F, H, H, G)
+    }
+    return vmul(vreduce(M1), vreduce(M2));                                            // (E F, G H, E H, F G) = (X3, Y3, T3, Z3)
+}
+OTTI_IFMA V5 videntity() {
+    V5 r;
+    r.l[0] = _mm256_set_epi64x(1, 0, 1, 0);                                           // lanes X, Y, T, Z = 0, 1, 0, 1
+    for (int k = 1; k < 5; k++) r.l[k] = _mm256_setzero_si256();
+    return r;
+}
 }  // namespace
+
+OTTI_IFMA_FN void ifma_dbl_n(PtFe &p, int n) { V5 P = vload_point(p); for (int i = 0; i < n; i++) P = vdbl(P); vstore_point(p, P); }
+
+OTTI_IFMA_FN void ifma_straus(PtFe &acc, const Niels4 *tabs, int ntabs, const int *digs, int nwin) {
+    V5 P = videntity();
+    for (int w = nwin - 1; w >= 0; w--) {
+        if (w != nwin - 1) { P = vdbl(P); P = vdbl(P); P = vdbl(P); P = vdbl(P); }
+        for (int i = 0; i < ntabs; i++) {
+            const int d = digs[(size_t)i * nwin + w];
+            if (d) P = vmadd(P, tabs[(size_t)8 * i + (size_t)((d > 0 ? d : -d) - 1)], d < 0);
+        }
+    }
+    vstore_point(acc, P);
+}
 
 OTTI_IFMA_FN void ifma_madd(PtFe &p, const Niels4 &q, bool negate) { vstore_point(p, vmadd(vload_point(p), q, negate)); }
 

@@ -19,4 +19,13 @@ void ifma_accumulate(PtFe &acc, const Niels4 *table, const int *digits, int w0, 
 // one mixed addition (selftest)
 void ifma_madd(PtFe &p, const Niels4 &q, bool negate);
 
+// ---- the verifiers' variable-base work in the same form: a doubling is a 4-way squaring of (X, Y, Z, X+Y) and the same second
+// product; an addition of a point kept in cached form (Y-X, Y+X, 2dT, 2Z — the layout of Niels4, fourth lane 2Z) is the mixed addition
+// above with that lane in place of the constant.
+Niels4 cached4_from(const CachedFe &c);
+void ifma_dbl_n(PtFe &p, int n);                             // p = 2^n p
+// Straus: acc = sum_i s_i P_i, where tabs[8 i + m - 1] = m P_i (m = 1 .. 8, cached form) and digs[i * nwin + w] is signed radix-16
+// digit w of s_i (|digit| <= 8); four doublings per window, windows from nwin - 1 down to 0
+void ifma_straus(PtFe &acc, const Niels4 *tabs, int ntabs, const int *digs, int nwin);
+
 }  // namespace otti
