@@ -79,8 +79,9 @@ template <int kKind> __global__ __launch_bounds__(kBlock) void k_msm_rows(MsmArg
     // in pieces that fit the LDS and keeps its accumulators across them, so there is ONE reduction tree and one partial per chunk
     if (threadIdx.x < 8) s_base[threadIdx.x] = A.extra_base[threadIdx.x];
     __syncthreads();
-    // ---- phase 2: one mixed addition per (term, window) pair, in 26/25-bit limbs (fp10.h)
-    P10 acc = p10_identity();
+    // ---- phase 2: one mixed addition per (term, window) pair, in nine 29-bit limbs (fp9.h: 90 multiply-adds per product instead of
+    // fp10.h's 100 + the 19-folds, one asm block each; the tree below and everything latency-bound stay in fp10.h's form)
+    P9 acc9 = p9_identity();
     const int w = threadIdx.x % A.W, tl = threadIdx.x / A.W;
     if constexpr (kKind == MSM_BULK_SPARSE) {
         // First compact the pairs whose digit is non-zero into an LDS work list (wave-aggregated append), then every thread takes
@@ -129,9 +130,9 @@ template <int kKind> __global__ __launch_bounds__(kBlock) void k_msm_rows(MsmArg
                 const int d = recoded_digit(s_raw + t * 9, (int)ww, A.c);
                 const size_t base = T < n_here ? j0 + T : (size_t)s_base[T - n_here];
                 const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
-                N10 e = n10_unpack(A.table[base * WE + (size_t)ww * A.E + (mag - 1)].n);
-                if (d < 0) e = n10_negate(e);
-                acc = p10_madd(acc, e);
+                N9 e = n9_unpack(A.table[base * WE + (size_t)ww * A.E + (mag - 1)].n);
+                if (d < 0) e = n9_negate(e);
+                acc9 = p9_madd(acc9, e);
             }
         }
     } else {
@@ -153,14 +154,15 @@ template <int kKind> __global__ __launch_bounds__(kBlock) void k_msm_rows(MsmArg
                     const uint32_t T = sub0 + t;
                     size_t base = T < n_here ? j0 + T : (size_t)s_base[T - n_here];
                     uint32_t mag = (uint32_t)(d < 0 ? -d : d);
-                    N10 e = n10_unpack(A.table[base * WE + (size_t)w * A.E + (mag - 1)].n);
-                    if (d < 0) e = n10_negate(e);
-                    acc = p10_madd(acc, e);
+                    N9 e = n9_unpack(A.table[base * WE + (size_t)w * A.E + (mag - 1)].n);
+                    if (d < 0) e = n9_negate(e);
+                    acc9 = p9_madd(acc9, e);
                 }
         }
     }
     // ---- phase 3: LDS tree (reuses the scalar region: everyone must be done reading it)
     __syncthreads();
+    P10 acc = p10_unpack(p9_pack(acc9));
     const F10 d2 = f10_const(fp_2D());
     for (int sft = kBlock / 2; sft >= 1; sft >>= 1) {
         if ((int)threadIdx.x >= sft && (int)threadIdx.x < 2 * sft) sm[threadIdx.x - sft] = acc;
@@ -653,14 +655,14 @@ void dev_decode_niels(DevCtx &c, const uint8_t *compressed_dev, size_t n, Niels 
 }
 
 // ------------------------------------------------------------------------------------------------ the ALU roof of the MSM, measured
-// Whole-chip throughput of the mixed point addition the bulk MSM is made of (p10_madd, operands in registers, every CU busy): what
+// Whole-chip throughput of the mixed point addition the bulk MSM is made of (p9_madd of fp9.h — the form the bulk kernel uses —, operands in registers, every CU busy): what
 // bench.py prices k_msm_rows<0> against (roofline.alu.peak), measured in the run that reports it.  tools/mulbench.hip is the same loop.
 __global__ __launch_bounds__(kBlock) void k_madd_peak(Fp *io, int iters) {
     const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    P10 p; p.X = f10_unpack(io[2 * i]); p.Y = f10_unpack(io[2 * i + 1]); p.Z = f10_one(); p.T = f10_mul(p.X, p.Y);
-    N10 n; n.yplusx = p.X; n.yminusx = p.Y; n.xy2d = p.T;
-    for (int k = 0; k < iters; k++) p = p10_madd(p, n);
-    io[2 * i] = f10_pack(p.X);
+    P9 p; p.X = f9_unpack(io[2 * i]); p.Y = f9_unpack(io[2 * i + 1]); p.Z = f9_one(); p.T = f9_mul(p.X, p.Y);
+    N9 n; n.yplusx = p.X; n.yminusx = p.Y; n.xy2d = p.T;
+    for (int k = 0; k < iters; k++) p = p9_madd(p, n);
+    io[2 * i] = f9_pack(p.X);
 }
 double dev_madd_peak(DevCtx &c) {
     const int blocks = 1024, iters = 200; const size_t n = (size_t)blocks * kBlock;

@@ -3,6 +3,8 @@
 #pragma once
 #include "device.h"
 #include "fp10.h"
+#include "fp9.h"
+#include "fr9.h"
 #include "pool.h"
 #include <stdio.h>
 #include <stdlib.h>
