@@ -114,20 +114,36 @@ HD Fr fr9_pack_lt3l(const Fr9 &a) {
 }
 
 HD Fr9 fr9_add(const Fr9 &a, const Fr9 &b) { Fr9 r; for (int i = 0; i < 9; i++) r.v[i] = a.v[i] + b.v[i]; return r; }
-// a - b + 2l with every limb non-negative: b NORMALISED with value < 2l - 2^233 (limb 8 <= 2^21 - 1).  Result limbs < a_i + 2^30.
-//   2l = sum o_i 2^(29 i) with o_0 = L0' + 2^29, o_i = Li' + 2^29 - 1 (0 < i < 8), o_8 = 2^21 - 1   (Li' the limbs of 2l)
-HD Fr9 fr9_sub2l(const Fr9 &a, const Fr9 &b) {
+// limb i of K * l in "borrow-proof" form: K l = sum o_i 2^(29 i) with o_0 = t_0 + 2^29, o_i = t_i + 2^29 - 1 (0 < i < 8), o_8 = t_8 - 1
+// (t the ordinary limbs of K l): every o_i >= 2^29 - 1, so a_i + o_i - b_i never goes negative for a normalised b below K l - 2^232.
+constexpr uint32_t fr9_kl_limb(uint32_t K, int i) {
+    const uint32_t L[9] = {FR9_L0, FR9_L1, FR9_L2, FR9_L3, FR9_L4, 0, 0, 0, FR9_L8};
+    uint64_t c = 0; uint32_t t = 0;
+    for (int j = 0; j <= i; j++) { c += (uint64_t)K * L[j]; t = (uint32_t)(j < 8 ? (c & FR9_M) : c); c >>= 29; }
+    return i == 0 ? t + 0x20000000u : (i < 8 ? t + 0x1fffffffu : t - 1u);
+}
+// a - b + K l with every limb non-negative: b NORMALISED with value < K l - 2^232 (K a power of two <= 128).  Result limbs < a_i + 2^30.
+template <uint32_t K> HD Fr9 fr9_sub_kl(const Fr9 &a, const Fr9 &b) {
     Fr9 r;
-    r.v[0] = a.v[0] + (0x19eba7dau + 0x20000000u) - b.v[0];
-    r.v[1] = a.v[1] + (0x012631a5u + 0x1fffffffu) - b.v[1];
-    r.v[2] = a.v[2] + (0x1bce6b2cu + 0x1fffffffu) - b.v[2];
-    r.v[3] = a.v[3] + (0x1be77a8bu + 0x1fffffffu) - b.v[3];
-    r.v[4] = a.v[4] + (0x0000029bu + 0x1fffffffu) - b.v[4];
-    r.v[5] = a.v[5] + 0x1fffffffu - b.v[5];
-    r.v[6] = a.v[6] + 0x1fffffffu - b.v[6];
-    r.v[7] = a.v[7] + 0x1fffffffu - b.v[7];
-    r.v[8] = a.v[8] + 0x001fffffu - b.v[8];
+    r.v[0] = a.v[0] + fr9_kl_limb(K, 0) - b.v[0]; r.v[1] = a.v[1] + fr9_kl_limb(K, 1) - b.v[1]; r.v[2] = a.v[2] + fr9_kl_limb(K, 2) - b.v[2];
+    r.v[3] = a.v[3] + fr9_kl_limb(K, 3) - b.v[3]; r.v[4] = a.v[4] + fr9_kl_limb(K, 4) - b.v[4]; r.v[5] = a.v[5] + fr9_kl_limb(K, 5) - b.v[5];
+    r.v[6] = a.v[6] + fr9_kl_limb(K, 6) - b.v[6]; r.v[7] = a.v[7] + fr9_kl_limb(K, 7) - b.v[7]; r.v[8] = a.v[8] + fr9_kl_limb(K, 8) - b.v[8];
     return r;
+}
+HD Fr9 fr9_sub2l(const Fr9 &a, const Fr9 &b) { return fr9_sub_kl<2>(a, b); }
+// any normalised value below 2^261 (limb 8 < 2^29)  ->  canonical memory word:  v = low252 + q 2^252 = low252 - q delta (mod l), q < 2^9
+HD Fr fr9_canon(const Fr9 &a) {
+    const uint32_t q = a.v[8] >> 20;
+    const uint32_t L[5] = {FR9_L0, FR9_L1, FR9_L2, FR9_L3, FR9_L4};
+    uint32_t d[6]; uint64_t acc = 0;
+#pragma unroll
+    for (int j = 0; j < 5; j++) { acc += (uint64_t)q * L[j]; d[j] = (uint32_t)acc & FR9_M; acc >>= 29; }
+    d[5] = (uint32_t)acc;
+    Fr9 r;                                                           // low252 + l - q delta, limb by limb, in (0, 2l)
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.v[i] = a.v[i] + fr9_kl_limb(1, i) - (i < 6 ? d[i] : 0u);
+    r.v[8] = (a.v[8] & 0xfffffu) + fr9_kl_limb(1, 8);
+    return fr9_pack_lt2l(fr9_norm(r));
 }
 // limbs of 32 x, normalised (x normalised, x < 2^256)
 HD Fr9 fr9_shl5(const Fr9 &a) {

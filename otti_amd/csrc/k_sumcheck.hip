@@ -69,7 +69,24 @@ template <int K> __device__ __forceinline__ void store_partials(Fr (&acc)[K], Fr
 // Round sums without a second launch or a stream synchronise: every workgroup publishes its partial sums, the last one to arrive
 // (agent-scope counter; release/acquire per the gfx950 inter-workgroup recipe) adds them up, writes the K totals straight into
 // pinned host memory and then stores the launch's sequence number into a host-visible flag the prover thread is spinning on.
-template <int K> __device__ __forceinline__ void finish_in_kernel(Fr (&acc)[K], const Mailbox &mb) {
+// What the LAST thread does to the launch's totals before they go to the host (the nine-limb kernels below sum other quantities than
+// the transcript wants, in a Montgomery radix of their own; both corrections are linear, so they are applied once per launch, not per item):
+//   POST_CUBIC3: (Q(0), Q(1), leading coefficient) of a quadratic  ->  its values at 0, 2, 3;   POST_X32: every total times 32
+enum { POST_NONE = 0, POST_CUBIC3 = 1, POST_X32 = 2 };
+__device__ __forceinline__ Fr fr_const_32() {                 // 32 in the memory format (32 * 2^256 mod l)
+    Fr r; r.v[0] = 0x714df9edu; r.v[1] = 0x334c2e60u; r.v[2] = 0xb3bdf026u; r.v[3] = 0x56eb3c98u; r.v[4] = 0xffffffd6u; r.v[5] = 0xffffffffu; r.v[6] = 0xffffffffu; r.v[7] = 0x0fffffffu; return r;
+}
+__device__ __forceinline__ Fr fr_const_1024() {               // 1024 in the memory format
+    Fr r; r.v[0] = 0xe7fa93edu; r.v[1] = 0xbf4bcbdcu; r.v[2] = 0xbbc206d1u; r.v[3] = 0x56675120u; r.v[4] = 0xfffffac8u; r.v[5] = 0xffffffffu; r.v[6] = 0xffffffffu; r.v[7] = 0x0fffffffu; return r;
+}
+// q = (Q(0), Q(1), Q_inf) of Q(t) = Q(0) + c t + Q_inf t^2  ->  (Q(0), Q(2), Q(3)):  Q(2) = 2 (Q(1) + Q_inf) - Q(0),  Q(3) = 3 Q(1) + 6 Q_inf - 2 Q(0)
+__device__ __forceinline__ void quadratic_to_023(Fr (&q)[3]) {
+    const Fr t = fr_add(q[1], q[2]), t2 = fr_dbl(t);
+    const Fr s2 = fr_sub(t2, q[0]);
+    const Fr s3 = fr_sub(fr_add(fr_add(t2, t), fr_add(fr_dbl(q[2]), q[2])), fr_dbl(q[0]));
+    q[1] = s2; q[2] = s3;
+}
+template <int K, int kPost = POST_NONE> __device__ __forceinline__ void finish_in_kernel(Fr (&acc)[K], const Mailbox &mb) {
     block_reduce<K>(acc);
     if (gridDim.x > 1) {
         if (threadIdx.x == 0) for (int k = 0; k < K; k++) store_words_sc1(&mb.partials[(size_t)blockIdx.x * K + k], acc[k].v, 8);
@@ -80,6 +97,12 @@ template <int K> __device__ __forceinline__ void finish_in_kernel(Fr (&acc)[K], 
         block_reduce<K>(acc);
     }
     if (threadIdx.x == 0) {
+        if constexpr (kPost == POST_CUBIC3) { static_assert(K == 3, "three totals"); quadratic_to_023(acc); }
+        if constexpr (kPost == POST_X32) {
+            const Fr c32 = fr_const_32();
+#pragma unroll
+            for (int k = 0; k < K; k++) acc[k] = fr_mul(acc[k], c32);
+        }
         for (int k = 0; k < K; k++) mb.host_results[mb.slot + k] = acc[k];
         __threadfence_system();
         __hip_atomic_store(mb.host_flag, mb.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -120,41 +143,76 @@ __global__ __launch_bounds__(kBlock) void k_sc_cubic_fold_eval(Fr *A, Fr *B, Fr 
 // S_t = sum_i E_j[i] * (A_t[i] B_t[i] - C_t[i]); the kernels below return S_t (three tables instead of four: a quarter less HBM
 // traffic and register pressure), the host applies the two scalar factors.  E_j[i] itself is hi[i >> lo_bits] * lo[i & mask] from the
 // two small "pyramids" of k_eq_pyramid (L2-resident), or lo[i] once at most lo_bits variables are left.
-__device__ __forceinline__ void cubic3_accum(Fr (&acc)[3], const Fr &e, const Pair &b, const Pair &c, const Pair &d) {
-    acc[0] = fr_add(acc[0], fr_mul(e, fr_sub(fr_mul(b.lo, c.lo), d.lo)));
-    Fr db = fr_sub(b.hi, b.lo), dc = fr_sub(c.hi, c.lo), dd = fr_sub(d.hi, d.lo);
-    Fr b2 = fr_add(b.hi, db), c2 = fr_add(c.hi, dc), d2 = fr_add(d.hi, dd);
-    acc[1] = fr_add(acc[1], fr_mul(e, fr_sub(fr_mul(b2, c2), d2)));
-    Fr b3 = fr_add(b2, db), c3 = fr_add(c2, dc), d3 = fr_add(d2, dd);
-    acc[2] = fr_add(acc[2], fr_mul(e, fr_sub(fr_mul(b3, c3), d3)));
+// ---- the same two kernels in nine 29-bit limbs (fr9.h): operands stay unpacked from load to store.  Per item they sum
+//   Q(0) += E (B_lo C_lo - D_lo),   Q(1) += E (B_hi C_hi - D_hi),   Q_inf += E (B_hi - B_lo)(C_hi - C_lo)
+// — S_t's values at 0 and 1 and its leading coefficient: every operand is a table element or a single difference, so no product needs an
+// operand carried down beyond one normalisation (the points 2 and 3 would want 2 X_hi - X_lo and 3 X_hi - 2 X_lo: limbs of 31 bits on both
+// sides of a product) — and the launch's last thread turns the totals into S_0, S_2, S_3 (POST_CUBIC3).  Montgomery radix 2^261: C and E go
+// in times 32 (shifted unpack / fr9_shl5), everything else as it is, and every product comes out in the memory format.
+__device__ __forceinline__ Fr9 eq5_at(const EqSrc &e, size_t i) {                 // 32 E[i] (mod l): < 3 l from two factors, < 32 l from one table
+    if (!e.hi) return fr9_unpack5(e.lo[i]);
+    return fr9_mul(fr9_unpack5(e.hi[i >> e.lo_bits]), fr9_unpack5(e.lo[i & (((size_t)1 << e.lo_bits) - 1)]));
 }
-__global__ __launch_bounds__(kBlock, 4) void k_sc_cubic3_eval(const Fr *B, const Fr *C, const Fr *D, size_t half, EqSrc E, Mailbox mb) {
-    Fr acc[3] = {fr_zero(), fr_zero(), fr_zero()};
+// b_*, d_* normalised below 2.2 l; c_*5 normalised below 71 l (32 times an element below 2.2 l); e5 normalised below 32 l.
+// Products: (norm x norm), (norm x limbs < 2^30.6): column sums < 2^63; values: P < 1.4 l, X < 5.4 l, E X / 2^261 + l < 1.4 l.
+__device__ __forceinline__ void cubic3_accum9(Fr9 (&acc)[3], const Fr9 &e5, const Fr9 &b_lo, const Fr9 &b_hi, const Fr9 &c_lo5, const Fr9 &c_hi5, const Fr9 &d_lo, const Fr9 &d_hi) {
+    const Fr9 db = fr9_norm(fr9_sub_kl<4>(b_hi, b_lo));
+    const Fr9 dc5 = fr9_sub_kl<128>(c_hi5, c_lo5);
+    const Fr9 x0 = fr9_sub_kl<4>(fr9_mul(b_lo, c_lo5), d_lo);
+    const Fr9 x1 = fr9_sub_kl<4>(fr9_mul(b_hi, c_hi5), d_hi);
+    const Fr9 xi = fr9_mul(db, dc5);
+    acc[0] = fr9_add(acc[0], fr9_mul(e5, x0));
+    acc[1] = fr9_add(acc[1], fr9_mul(e5, x1));
+    acc[2] = fr9_add(acc[2], fr9_mul(e5, xi));
+}
+// a thread's three running sums (limbs grow by < 2^29 per item: carried down every fourth item) -> canonical words
+__device__ __forceinline__ void acc9_carry(Fr9 (&acc)[3]) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) acc[k] = fr9_norm(acc[k]);
+}
+template <int K> __device__ __forceinline__ void acc9_canon(Fr (&out)[K], const Fr9 (&acc)[K]) {
+#pragma unroll
+    for (int k = 0; k < K; k++) out[k] = fr9_canon(fr9_norm(acc[k]));
+}
+// bound_poly_var_top of (x0, x2) by r (r5 = 32 r): the folded element, normalised and below 2.2 l, and its canonical word for the table
+__device__ __forceinline__ Fr9 fold9(const Fr &x0, const Fr &x2, const Fr9 &r5, Fr &word) {
+    const Fr9 a = fr9_unpack(x0);
+    const Fr9 s = fr9_norm(fr9_add(a, fr9_mul(r5, fr9_sub_kl<2>(fr9_unpack(x2), a))));   // r5 (x2 - x0 + 2l) / 2^261 + l < 1.2 l
+    word = fr9_pack_lt3l(s);
+    return s;
+}
+__global__ __launch_bounds__(kBlock) void k_sc_cubic3_eval(const Fr *B, const Fr *C, const Fr *D, size_t half, EqSrc E, Mailbox mb) {
+    Fr9 acc[3] = {fr9_zero(), fr9_zero(), fr9_zero()}; unsigned n = 0;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x) {
-        Pair b, c, d;
-        b.lo = B[i]; b.hi = B[i + half]; c.lo = C[i]; c.hi = C[i + half]; d.lo = D[i]; d.hi = D[i + half];
-        Fr e = eq_at(E, i);
+        const Fr b0 = B[i], b1 = B[i + half], c0 = C[i], c1 = C[i + half], d0 = D[i], d1 = D[i + half];
+        const Fr9 e5 = eq5_at(E, i);
         __builtin_amdgcn_sched_barrier(0);
-        cubic3_accum(acc, e, b, c, d);
+        cubic3_accum9(acc, e5, fr9_unpack(b0), fr9_unpack(b1), fr9_unpack5(c0), fr9_unpack5(c1), fr9_unpack(d0), fr9_unpack(d1));
+        if ((++n & 3u) == 0) acc9_carry(acc);
     }
-    finish_in_kernel<3>(acc, mb);
+    Fr tot[3]; acc9_canon<3>(tot, acc);
+    finish_in_kernel<3, POST_CUBIC3>(tot, mb);
 }
 __global__ __launch_bounds__(kBlock) void k_sc_cubic3_fold_eval(Fr *B, Fr *C, Fr *D, size_t q, Fr r, EqSrc E, Mailbox mb, Armed go) {
     if (go.want) { Fr v[1]; if (!armed_fetch<1>(go, v)) return; r = v[0]; }
-    Fr acc[3] = {fr_zero(), fr_zero(), fr_zero()};
+    const Fr9 r5 = fr9_unpack5(r);
+    Fr9 acc[3] = {fr9_zero(), fr9_zero(), fr9_zero()}; unsigned n = 0;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < q; i += (size_t)gridDim.x * blockDim.x) {
-        Fr b0 = B[i], b1 = B[i + q], b2 = B[i + 2 * q], b3 = B[i + 3 * q];
-        Fr c0 = C[i], c1 = C[i + q], c2 = C[i + 2 * q], c3 = C[i + 3 * q];
+        const Fr b0 = B[i], b1 = B[i + q], b2 = B[i + 2 * q], b3 = B[i + 3 * q];
+        const Fr c0 = C[i], c1 = C[i + q], c2 = C[i + 2 * q], c3 = C[i + 3 * q];
         __builtin_amdgcn_sched_barrier(0);
-        Pair b = fold_regs(b0, b1, b2, b3, r); B[i] = b.lo; B[i + q] = b.hi;
-        Fr d0 = D[i], d1 = D[i + q], d2 = D[i + 2 * q], d3 = D[i + 3 * q];
-        Fr e = eq_at(E, i);
+        Fr w0, w1;
+        const Fr9 b_lo = fold9(b0, b2, r5, w0), b_hi = fold9(b1, b3, r5, w1); B[i] = w0; B[i + q] = w1;
+        const Fr d0 = D[i], d1 = D[i + q], d2 = D[i + 2 * q], d3 = D[i + 3 * q];
+        const Fr9 e5 = eq5_at(E, i);
         __builtin_amdgcn_sched_barrier(0);
-        Pair c = fold_regs(c0, c1, c2, c3, r); C[i] = c.lo; C[i + q] = c.hi;
-        Pair d = fold_regs(d0, d1, d2, d3, r); D[i] = d.lo; D[i + q] = d.hi;
-        cubic3_accum(acc, e, b, c, d);
+        const Fr9 c_lo = fold9(c0, c2, r5, w0), c_hi = fold9(c1, c3, r5, w1); C[i] = w0; C[i + q] = w1;
+        const Fr9 d_lo = fold9(d0, d2, r5, w0), d_hi = fold9(d1, d3, r5, w1); D[i] = w0; D[i + q] = w1;
+        cubic3_accum9(acc, e5, b_lo, b_hi, fr9_shl5(c_lo), fr9_shl5(c_hi), d_lo, d_hi);
+        if ((++n & 3u) == 0) acc9_carry(acc);
     }
-    finish_in_kernel<3>(acc, mb);
+    Fr tot[3]; acc9_canon<3>(tot, acc);
+    finish_in_kernel<3, POST_CUBIC3>(tot, mb);
 }
 // "Pyramid" of eq tables over the LAST k of n variables, k = 0..n: level k (2^k entries) sits at out + 2^k - 1.  Level k prepends
 // variable v = r[n-k] as the new most significant index bit: new[i] = old[i] * (1 - v), new[2^(k-1) + i] = old[i] * v.
@@ -170,28 +228,42 @@ __global__ __launch_bounds__(1024) void k_eq_pyramid(FrArgs r0, int n0, Fr *out0
         __syncthreads();
     }
 }
+// ---- phase two in nine limbs: e_0 = sum A_lo B_lo and e_2 = sum (2 A_hi - A_lo)(2 B_hi - B_lo) as they stand (a third sum for the point 1
+// would cost a product; one carried-down operand costs 24 light instructions).  Nothing goes in times 32 here: both totals come out divided
+// by 32 and the launch's last thread multiplies them back (POST_X32).  a_*, b_* normalised below 2.2 l.
+__device__ __forceinline__ void quad_accum9(Fr9 (&acc)[2], const Fr9 &a_lo, const Fr9 &a_hi, const Fr9 &b_lo, const Fr9 &b_hi) {
+    acc[0] = fr9_add(acc[0], fr9_mul(a_lo, b_lo));
+    const Fr9 u = fr9_norm(fr9_sub_kl<4>(fr9_add(a_hi, a_hi), a_lo));             // limbs < 2^31 before the sweep; value < 8.4 l
+    const Fr9 v = fr9_sub_kl<4>(fr9_add(b_hi, b_hi), b_lo);                       // limbs < 2^31: 9 * 2^29 * 2^31 + 6 * 2^58 < 2^63.4
+    acc[1] = fr9_add(acc[1], fr9_mul(u, v));
+}
 __global__ __launch_bounds__(kBlock) void k_sc_quad_eval(const Fr *A, const Fr *B, size_t half, Mailbox mb) {
-    Fr acc[2] = {fr_zero(), fr_zero()};
+    Fr9 acc[2] = {fr9_zero(), fr9_zero()}; unsigned n = 0;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x) {
-        Pair a, b;
-        a.lo = A[i]; a.hi = A[i + half]; b.lo = B[i]; b.hi = B[i + half];
+        const Fr a0 = A[i], a1 = A[i + half], b0 = B[i], b1 = B[i + half];
         __builtin_amdgcn_sched_barrier(0);
-        quad_accum(acc, a, b);
+        quad_accum9(acc, fr9_unpack(a0), fr9_unpack(a1), fr9_unpack(b0), fr9_unpack(b1));
+        if ((++n & 3u) == 0) { acc[0] = fr9_norm(acc[0]); acc[1] = fr9_norm(acc[1]); }
     }
-    finish_in_kernel<2>(acc, mb);
+    Fr tot[2]; acc9_canon<2>(tot, acc);
+    finish_in_kernel<2, POST_X32>(tot, mb);
 }
 __global__ __launch_bounds__(kBlock) void k_sc_quad_fold_eval(Fr *A, Fr *B, size_t q, Fr r, Mailbox mb, Armed go) {
     if (go.want) { Fr v[1]; if (!armed_fetch<1>(go, v)) return; r = v[0]; }
-    Fr acc[2] = {fr_zero(), fr_zero()};
+    const Fr9 r5 = fr9_unpack5(r);
+    Fr9 acc[2] = {fr9_zero(), fr9_zero()}; unsigned n = 0;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < q; i += (size_t)gridDim.x * blockDim.x) {
-        Fr a0 = A[i], a1 = A[i + q], a2 = A[i + 2 * q], a3 = A[i + 3 * q];
-        Fr b0 = B[i], b1 = B[i + q], b2 = B[i + 2 * q], b3 = B[i + 3 * q];
+        const Fr a0 = A[i], a1 = A[i + q], a2 = A[i + 2 * q], a3 = A[i + 3 * q];
+        const Fr b0 = B[i], b1 = B[i + q], b2 = B[i + 2 * q], b3 = B[i + 3 * q];
         __builtin_amdgcn_sched_barrier(0);
-        Pair a = fold_regs(a0, a1, a2, a3, r); A[i] = a.lo; A[i + q] = a.hi;
-        Pair b = fold_regs(b0, b1, b2, b3, r); B[i] = b.lo; B[i + q] = b.hi;
-        quad_accum(acc, a, b);
+        Fr w0, w1;
+        const Fr9 a_lo = fold9(a0, a2, r5, w0), a_hi = fold9(a1, a3, r5, w1); A[i] = w0; A[i + q] = w1;
+        const Fr9 b_lo = fold9(b0, b2, r5, w0), b_hi = fold9(b1, b3, r5, w1); B[i] = w0; B[i + q] = w1;
+        quad_accum9(acc, a_lo, a_hi, b_lo, b_hi);
+        if ((++n & 3u) == 0) { acc[0] = fr9_norm(acc[0]); acc[1] = fr9_norm(acc[1]); }
     }
-    finish_in_kernel<2>(acc, mb);
+    Fr tot[2]; acc9_canon<2>(tot, acc);
+    finish_in_kernel<2, POST_X32>(tot, mb);
 }
 __global__ __launch_bounds__(kBlock) void k_fold_top(Fr *Z, size_t half, Fr r) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x) {
