@@ -619,9 +619,10 @@ def main():
     # products one per non-zero entry (+ 3 per output row for the fused combination); eq tables one per element written
     products = {"sc_cubic": 10 * N, "sc_quad": 8 * (2 * V) // 2, "spmv": 2 * nnz + 3 * 2 * V, "eq": N + 2 * V}
     field_mul = {"peak": round(frmul_peak / 1e9, 2), "unit": "G Montgomery products/s", "classes": {},
-                 "note": "peak = otti_bench_fr_mul_peak measured in this run (fr_mul chains in registers, every CU busy): 104 v_mad_u64_u32 + 104 carry adds + ~55 moves, "
-                         "shifts and the conditional subtraction = ~265 issue slots per product at ~4.8 cycles each — the instruction count binds, not the multiplier "
-                         "alone (its 32.6 T lane-ops/s would allow 313 G products/s); classes: products per proof / summed device time of the class in one instrumented proof "
+                 "note": "peak = otti_bench_fr_mul_peak measured in this run: the nine-limb product of fr9.h (round 4; operands unpacked in registers, two chains per lane, every CU "
+                         "busy): 135 v_mad_u64_u32 + 17 64-bit shifts + 9 v_mul_lo_u32 ('heavy': ~4.3 nominal cycles per wave instruction each) + ~27 masks and moves (~2.4) in one asm block; "
+                         "the 8 x u32 form it replaces (104 multiply-adds + 104 carry adds, 143-147 G/s) is timed beside it by tools/limbbench (profiles/r4_limbbench.txt); "
+                         "classes: products per proof / summed device time of the class in one instrumented proof "
                          "(most launches of a sum-check are rounds too short to fill the chip, so the whole-proof rate sits far below the roof; profiles/*kbw* has the rates at size)"}
     for cls, nprod in products.items():
         if breakdown.get(cls, (0, 0))[0]:

@@ -11,7 +11,7 @@
 // limb 8 of either operand below 2^26.  f9_sub(a, b) needs b reduced.
 //
 // Restates, for this path, curve25519-dalek's FieldElement arithmetic under libspartan's `group.rs` [RECALL; Cargo dependency of the
-// empty submodule /root/reference/Spartan, .gitmodules:4-6]; oracle: oracle/fp.c.
+// empty submodule /root/reference/Spartan, .gitmodules:4-6]; checked against the CPU oracle (fp.c) by the parity tests.
 #pragma once
 #include "field.h"
 #include "point.h"

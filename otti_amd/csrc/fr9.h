@@ -18,7 +18,7 @@
 // other with limbs < 2^31.9, or both < 2^30.3.  Value bound of a product: a * b / 2^261 + l; every caller states what it relies on.
 //
 // Restates, for this path, upstream libspartan `src/scalar/ristretto255.rs::Scalar::{mul, add, sub}` (montgomery_reduce is its
-// reduction; /root/reference/Spartan is an empty submodule: .gitmodules:4-6); oracle: oracle/fr.c.
+// reduction; /root/reference/Spartan is an empty submodule: .gitmodules:4-6); checked against the CPU oracle (fr.c) by the parity tests.
 #pragma once
 #include "field.h"
 
@@ -54,34 +54,29 @@ HD Fr fr9_cond_sub_l(const uint32_t w[8]) {
 
 HD Fr9 fr9_zero() { Fr9 r; for (int i = 0; i < 9; i++) r.v[i] = 0; return r; }
 
-// limbs of the 256-bit word x (any value below 2^256)
-HD Fr9 fr9_unpack(const Fr &a) {
+// limbs of x << S for a 256-bit word x: limb i = bits [29 i - S, 29 i - S + 29) of x, limb 8 everything from bit 232 - S up (so the
+// value must stay below 2^264: any x for S <= 5 — limb 8 < 2^29 —, a canonical x < 2^253 for S = 10 — limb 8 < 2^31).  S = 0: the plain
+// unpack; S = 5, 10: the same instructions with other shift counts, for the operand that carries the radix correction(s) of a product.
+template <int S> HD Fr9 fr9_unpack_s(const Fr &a) {
+    static_assert(S >= 0 && S <= 10, "shifted unpack");
     const uint32_t *w = a.v; Fr9 r;
-    r.v[0] = w[0] & FR9_M;
-    r.v[1] = fr9_alignbit(w[1], w[0], 29) & FR9_M;
-    r.v[2] = fr9_alignbit(w[2], w[1], 26) & FR9_M;
-    r.v[3] = fr9_alignbit(w[3], w[2], 23) & FR9_M;
-    r.v[4] = fr9_alignbit(w[4], w[3], 20) & FR9_M;
-    r.v[5] = fr9_alignbit(w[5], w[4], 17) & FR9_M;
-    r.v[6] = fr9_alignbit(w[6], w[5], 14) & FR9_M;
-    r.v[7] = fr9_alignbit(w[7], w[6], 11) & FR9_M;
-    r.v[8] = w[7] >> 8;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        const int lo = 29 * i - S;                                   // first bit of x in this limb
+        uint32_t v;
+        if (lo < 0) v = w[0] << (-lo);
+        else {
+            const int word = lo >> 5, off = lo & 31;
+            if (off == 0) v = w[word];
+            else if (word == 7 || off + 29 <= 32) v = w[word] >> off;
+            else v = fr9_alignbit(w[word + 1], w[word], off);
+        }
+        r.v[i] = i < 8 ? (v & FR9_M) : v;
+    }
     return r;
 }
-// limbs of x << 5 (x < 2^256: limb 8 < 2^29)
-HD Fr9 fr9_unpack5(const Fr &a) {
-    const uint32_t *w = a.v; Fr9 r;
-    r.v[0] = (w[0] << 5) & FR9_M;
-    r.v[1] = (w[0] >> 24) | ((w[1] << 8) & FR9_M);
-    r.v[2] = fr9_alignbit(w[2], w[1], 21) & FR9_M;
-    r.v[3] = fr9_alignbit(w[3], w[2], 18) & FR9_M;
-    r.v[4] = fr9_alignbit(w[4], w[3], 15) & FR9_M;
-    r.v[5] = fr9_alignbit(w[5], w[4], 12) & FR9_M;
-    r.v[6] = fr9_alignbit(w[6], w[5], 9) & FR9_M;
-    r.v[7] = fr9_alignbit(w[7], w[6], 6) & FR9_M;
-    r.v[8] = w[7] >> 3;
-    return r;
-}
+HD Fr9 fr9_unpack(const Fr &a) { return fr9_unpack_s<0>(a); }
+HD Fr9 fr9_unpack5(const Fr &a) { return fr9_unpack_s<5>(a); }
 // normalised limbs, value < 2^256  ->  the 256-bit word
 HD void fr9_pack_words(uint32_t w[8], const Fr9 &a) {
     const uint32_t *t = a.v;

@@ -52,9 +52,11 @@ size_t dev_witness_ingest(DevCtx &c, Fr *z, size_t n, size_t *n_small) {
 // and eq kernels are priced against beside the HBM roof — at 7-13 products per 192 bytes they are bounded by the multiplier first.
 __global__ __launch_bounds__(kBlock) void k_fr_mul_peak(Fr *io, int iters) {
     const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    Fr x = io[2 * i], y = io[2 * i + 1];
-    for (int k = 0; k < iters; k++) { x = fr_mul(x, y); y = fr_mul(y, x); }
-    io[2 * i] = fr_add(x, y);
+    // the form the streaming kernels use since round 4: nine 29-bit limbs kept unpacked (fr9.h), two chains per lane; x <- x * y in the memory
+    // format is mont261(x, 32 y) (every product below 1.1 l: no normalisation between them)
+    const Fr9 y5 = fr9_unpack5(io[2 * i + 1]); Fr9 x = fr9_unpack(io[2 * i]), z = fr9_unpack(io[2 * i + 1]);
+    for (int k = 0; k < iters; k++) { x = fr9_mul(x, y5); z = fr9_mul(z, y5); }
+    io[2 * i] = fr_add(fr9_pack_lt2l(x), fr9_pack_lt2l(z));
 }
 double dev_fr_mul_peak(DevCtx &c) {
     const int blocks = 2048, iters = 250; const size_t n = (size_t)blocks * kBlock;

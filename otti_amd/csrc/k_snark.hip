@@ -86,17 +86,21 @@ static inline int many_grid(size_t n, int ninst) { return (int)std::max<size_t>(
 // ---- a round of the batched cubic sum-check as ONE launch (fold by the previous challenge + the sums of this round at the points 0, 2, 3
 // of the variable being bound), results mailed to the host by the last workgroup (finish_in_kernel of k_sumcheck.hip, here for every
 // instance of the batch at once).
-__device__ __forceinline__ void finish_many(Fr (&acc)[3], const Mailbox &mb) {
+// An instance without a third table (a product circuit: L.C[y] == nullptr): its three totals are (Q(0), Q(1), leading coefficient) of a quadratic (product-circuit instances of the nine-limb
+// round kernel) and leave as its values at 0, 2, 3; otherwise they are those values already (dot-product triples).
+__device__ __forceinline__ void finish_many(Fr (&acc)[3], const Mailbox &mb, const PcList &L) {
     block_reduce<3>(acc);
     const unsigned total = gridDim.x * gridDim.y, ny = gridDim.y;
     if (total == 1) {
         if (threadIdx.x == 0) {
+            if (!L.C[0]) quadratic_to_023(acc);
             for (int k = 0; k < 3; k++) mb.host_results[mb.slot + k] = acc[k];
             __threadfence_system();
             __hip_atomic_store(mb.host_flag, mb.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         return;
     }
+    __shared__ Fr s_tot[3 * 64];
     if (threadIdx.x == 0) for (int k = 0; k < 3; k++) store_words_sc1(&mb.partials[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 3 + k], acc[k].v, 8);
     if (!arrive_and_check_last(mb.counter, total)) return;
     // last workgroup: output o = (instance, t) is summed by four adjacent lanes
@@ -107,49 +111,73 @@ __device__ __forceinline__ void finish_many(Fr (&acc)[3], const Mailbox &mb) {
         for (unsigned b = sub; b < gridDim.x; b += 4) { Fr t; load_words_sc1(t.v, &mb.partials[((size_t)y * gridDim.x + b) * 3 + k], 8); s = fr_add(s, t); }
     }
     s = fr_add(s, shfl_xor_fr(s, 1)); s = fr_add(s, shfl_xor_fr(s, 2));
-    if (o < 3 * ny && sub == 0) mb.host_results[mb.slot + o] = s;
+    if (o < 3 * ny && sub == 0) s_tot[o] = s;
+    __syncthreads();
+    if (threadIdx.x < ny) {
+        Fr q[3] = {s_tot[3 * threadIdx.x], s_tot[3 * threadIdx.x + 1], s_tot[3 * threadIdx.x + 2]};
+        if (!L.C[threadIdx.x]) quadratic_to_023(q);
+        for (int k = 0; k < 3; k++) mb.host_results[mb.slot + 3 * threadIdx.x + k] = q[k];
+    }
     __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(mb.host_flag, mb.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-__device__ __forceinline__ void abc_accum(Fr (&acc)[3], const Pair &a, const Pair &b, const Pair &c) {
-    acc[0] = fr_add(acc[0], fr_mul(fr_mul(a.lo, b.lo), c.lo));
-    const Fr da = fr_sub(a.hi, a.lo), db = fr_sub(b.hi, b.lo), dc = fr_sub(c.hi, c.lo);
-    Fr x = fr_add(a.hi, da), y = fr_add(b.hi, db), z = fr_add(c.hi, dc);
-    acc[1] = fr_add(acc[1], fr_mul(fr_mul(x, y), z));
-    x = fr_add(x, da); y = fr_add(y, db); z = fr_add(z, dc);
-    acc[2] = fr_add(acc[2], fr_mul(fr_mul(x, y), z));
+// ---- nine-limb forms (fr9.h).  Product-circuit instance (third table = the shared eq table, never stored): per item
+//   Q(0) += E a_lo b_lo,  Q(1) += E a_hi b_hi,  Q_inf += E (a_hi - a_lo)(b_hi - b_lo)   (E goes in times 2^10: two radix corrections)
+// — the quadratic's values at 0, 1 and its leading coefficient; finish_many turns the totals into the values at 0, 2, 3.
+// a_*, b_* normalised below 2.2 l; e10 normalised below 2^10 l.
+__device__ __forceinline__ void abe_accum9(Fr9 (&acc)[3], const Fr9 &a_lo, const Fr9 &a_hi, const Fr9 &b_lo, const Fr9 &b_hi, const Fr9 &e10) {
+    const Fr9 da = fr9_norm(fr9_sub_kl<4>(a_hi, a_lo)), db = fr9_sub_kl<4>(b_hi, b_lo);     // values < 6.2 l
+    acc[0] = fr9_add(acc[0], fr9_mul(e10, fr9_mul(a_lo, b_lo)));                            // inner products < 1.1 l; outer: 2^10 * 1.1 / 2^9 + 1 < 3.2 l
+    acc[1] = fr9_add(acc[1], fr9_mul(e10, fr9_mul(a_hi, b_hi)));
+    acc[2] = fr9_add(acc[2], fr9_mul(e10, fr9_mul(da, db)));
 }
-__device__ __forceinline__ void abe_accum(Fr (&acc)[3], const Pair &a, const Pair &b, const Fr &e) {
-    acc[0] = fr_add(acc[0], fr_mul(fr_mul(a.lo, b.lo), e));
-    const Fr da = fr_sub(a.hi, a.lo), db = fr_sub(b.hi, b.lo);
-    Fr x = fr_add(a.hi, da), y = fr_add(b.hi, db);
-    acc[1] = fr_add(acc[1], fr_mul(fr_mul(x, y), e));
-    x = fr_add(x, da); y = fr_add(y, db);
-    acc[2] = fr_add(acc[2], fr_mul(fr_mul(x, y), e));
+// Dot-product triple (three real tables): the cubic's values at 0, 2, 3 as they stand.  a_* plain, b_*5 and c_*5 times 32.
+__device__ __forceinline__ void abc_accum9(Fr9 (&acc)[3], const Fr9 &a_lo, const Fr9 &a_hi, const Fr9 &b_lo5, const Fr9 &b_hi5, const Fr9 &c_lo5, const Fr9 &c_hi5) {
+    acc[0] = fr9_add(acc[0], fr9_mul(fr9_mul(a_lo, b_lo5), c_lo5));
+    // point 2: x = 2 a_hi - a_lo + 4l (carried down), y5, z5 = 2 X_hi5 - X_lo5 + 128 l (limbs < 2^31): values 8.4 l, 270 l: products < 5.5 l, < 3.9 l
+    const Fr9 x2 = fr9_norm(fr9_sub_kl<4>(fr9_add(a_hi, a_hi), a_lo));
+    const Fr9 y2 = fr9_sub_kl<128>(fr9_add(b_hi5, b_hi5), b_lo5), z2 = fr9_sub_kl<128>(fr9_add(c_hi5, c_hi5), c_lo5);
+    acc[1] = fr9_add(acc[1], fr9_mul(fr9_mul(x2, y2), z2));
+    // point 3: X_3 = X_2 + (X_hi - X_lo): carried down on every side (their limbs would reach 3.5 * 2^30)
+    const Fr9 x3 = fr9_norm(fr9_add(x2, fr9_sub_kl<4>(a_hi, a_lo)));
+    const Fr9 y3 = fr9_norm(fr9_add(y2, fr9_sub_kl<128>(b_hi5, b_lo5))), z3 = fr9_norm(fr9_add(z2, fr9_sub_kl<128>(c_hi5, c_lo5)));
+    acc[2] = fr9_add(acc[2], fr9_mul(fr9_mul(x3, y3), z3));          // values 14.6 l, 469 l: 14.6 * 469 / 512 + 1 = 14.4 l, then 14.4 * 469 / 512 + 1 = 14.2 l
 }
 // kFold: the tables have 4q entries and are folded by r to 2q (pairs (i, i + q)); otherwise they have 2q entries as they are
 template <bool kFold> __global__ __launch_bounds__(kBlock) void k_pc_round(PcList L, size_t q, Fr r, EqSrc E, Mailbox mb, Armed go) {
     if (kFold && go.want) { Fr v[1]; if (!armed_fetch<1>(go, v)) return; r = v[0]; }
     Fr *A = L.A[blockIdx.y], *B = L.B[blockIdx.y], *C = L.C[blockIdx.y];
-    Fr acc[3] = {fr_zero(), fr_zero(), fr_zero()};
+    const Fr9 r5 = fr9_unpack5(r);
+    Fr9 acc[3] = {fr9_zero(), fr9_zero(), fr9_zero()}; unsigned n = 0;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < q; i += (size_t)gridDim.x * blockDim.x) {
-        Pair a, b;
+        Fr9 a_lo, a_hi, b_lo, b_hi;
         if (kFold) {
             const Fr a0 = A[i], a1 = A[i + q], a2 = A[i + 2 * q], a3 = A[i + 3 * q];
             const Fr b0 = B[i], b1 = B[i + q], b2 = B[i + 2 * q], b3 = B[i + 3 * q];
             __builtin_amdgcn_sched_barrier(0);
-            a = fold_regs(a0, a1, a2, a3, r); A[i] = a.lo; A[i + q] = a.hi;
-            b = fold_regs(b0, b1, b2, b3, r); B[i] = b.lo; B[i + q] = b.hi;
-        } else { a.lo = A[i]; a.hi = A[i + q]; b.lo = B[i]; b.hi = B[i + q]; }
+            Fr w0, w1;
+            a_lo = fold9(a0, a2, r5, w0); a_hi = fold9(a1, a3, r5, w1); A[i] = w0; A[i + q] = w1;
+            b_lo = fold9(b0, b2, r5, w0); b_hi = fold9(b1, b3, r5, w1); B[i] = w0; B[i + q] = w1;
+        } else {
+            const Fr a0 = A[i], a1 = A[i + q], b0 = B[i], b1 = B[i + q];
+            __builtin_amdgcn_sched_barrier(0);
+            a_lo = fr9_unpack(a0); a_hi = fr9_unpack(a1); b_lo = fr9_unpack(b0); b_hi = fr9_unpack(b1);
+        }
         if (C) {
-            Pair c;
-            if (kFold) { const Fr c0 = C[i], c1 = C[i + q], c2 = C[i + 2 * q], c3 = C[i + 3 * q]; c = fold_regs(c0, c1, c2, c3, r); C[i] = c.lo; C[i + q] = c.hi; }
-            else { c.lo = C[i]; c.hi = C[i + q]; }
-            abc_accum(acc, a, b, c);
-        } else abe_accum(acc, a, b, eq_at(E, i));
+            Fr9 c_lo5, c_hi5;
+            if (kFold) {
+                const Fr c0 = C[i], c1 = C[i + q], c2 = C[i + 2 * q], c3 = C[i + 3 * q];
+                Fr w0, w1;
+                const Fr9 c_lo = fold9(c0, c2, r5, w0), c_hi = fold9(c1, c3, r5, w1); C[i] = w0; C[i + q] = w1;
+                c_lo5 = fr9_shl5(c_lo); c_hi5 = fr9_shl5(c_hi);
+            } else { c_lo5 = fr9_unpack5(C[i]); c_hi5 = fr9_unpack5(C[i + q]); }
+            abc_accum9(acc, a_lo, a_hi, fr9_shl5(b_lo), fr9_shl5(b_hi), c_lo5, c_hi5);
+        } else abe_accum9(acc, a_lo, a_hi, b_lo, b_hi, eq_s_at<10>(E, i));
+        if ((++n & 3u) == 0) acc9_carry(acc);
     }
-    finish_many(acc, mb);
+    Fr tot[3]; acc9_canon<3>(tot, acc);
+    finish_many(tot, mb, L);
 }
 static Mailbox pc_mailbox(DevCtx &c, int slot, int nblocks) {
     if ((size_t)nblocks * 3 > c.partials.n) throw Error(OTTI_ERR_INTERNAL, "round partials exceed the context's buffer");

@@ -9,7 +9,12 @@ namespace otti {
 template <bool kSmall> __device__ __forceinline__ Fr entry_term(const DCsr3 &m, int k, uint32_t p, const Fr *x) {
     const Fr xv = x[m.idx[k][p]];
     if (kSmall) { const int32_t c = m.small[k][p]; if (c != kNotSmall) return fr_mul_small(xv, c); }
-    return fr_mul(m.val[k][p], xv);
+    return fr9_pack_lt2l(fr9_mul(fr9_unpack5(m.val[k][p]), fr9_unpack(xv)));           // nine limbs (fr9.h): 32 v x / 2^261 + l < 1.1 l
+}
+// c0 a0 + c1 a1 + c2 a2 in nine limbs (fr9.h): three products summed limb by limb, one reduction (each product < 1.1 l)
+__device__ __forceinline__ Fr combine3(const Fr &c0, const Fr &c1, const Fr &c2, const Fr &a0, const Fr &a1, const Fr &a2) {
+    const Fr9 t = fr9_add(fr9_add(fr9_mul(fr9_unpack5(c0), fr9_unpack(a0)), fr9_mul(fr9_unpack5(c1), fr9_unpack(a1))), fr9_mul(fr9_unpack5(c2), fr9_unpack(a2)));
+    return fr9_canon(fr9_norm(t));
 }
 template <bool kSmall> __device__ __forceinline__ Fr row_dot(const DCsr3 &m, int k, const Fr *x, size_t r) {
     Fr acc = fr_zero();
@@ -24,7 +29,7 @@ template <bool kSmall> __global__ __launch_bounds__(kBlock) void k_spmv3_light(D
         Fr a0 = row_dot<kSmall>(m, 0, x, r);
         Fr a1 = row_dot<kSmall>(m, 1, x, r);
         Fr a2 = row_dot<kSmall>(m, 2, x, r);
-        if (combine) o0[r] = fr_add(fr_add(fr_mul(c0, a0), fr_mul(c1, a1)), fr_mul(c2, a2));
+        if (combine) o0[r] = combine3(c0, c1, c2, a0, a1, a2);
         else { o0[r] = a0; o1[r] = a1; o2[r] = a2; }
     }
 }
@@ -48,7 +53,7 @@ template <bool kSmall> __global__ __launch_bounds__(kBlock) void k_spmv3_quad(DC
         }
         for (int k = 0; k < 3; k++) a[k] = quad_sum(a[k]);         // every lane of the wave takes part (rows are padded to whole waves above)
         if (r < rows && !heavy && q == 0) {
-            if (combine) o0[r] = fr_add(fr_add(fr_mul(c0, a[0]), fr_mul(c1, a[1])), fr_mul(c2, a[2]));
+            if (combine) o0[r] = combine3(c0, c1, c2, a[0], a[1], a[2]);
             else { o0[r] = a[0]; o1[r] = a[1]; o2[r] = a[2]; }
         }
     }

@@ -21,7 +21,8 @@ __global__ __launch_bounds__(1024) void k_eq_small(FrArgs r, int ell, Fr *out, F
 // out[i] = hi[i >> lo_bits] * lo[i & (2^lo_bits - 1)]  (index bits are MSB-first over r, so the product of two sub-tables is the table)
 __global__ __launch_bounds__(kBlock) void k_eq_expand(const Fr *hi, const Fr *lo, int lo_bits, Fr *out, size_t n) {
     size_t mask = ((size_t)1 << lo_bits) - 1;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = fr_mul(hi[i >> lo_bits], lo[i & mask]);
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = fr9_pack_lt2l(fr9_mul(fr9_unpack5(hi[i >> lo_bits]), fr9_unpack(lo[i & mask])));       // nine limbs (fr9.h): 32 hi * lo / 2^261 + l < 1.1 l
 }
 void dev_eq_evals(DevCtx &c, const Fr *r, size_t ell, Fr *out, Fr *scratch) {
     auto small = [&](const Fr *rr, int e, Fr *dst, Fr *tmp) {
@@ -40,20 +41,6 @@ void dev_eq_evals(DevCtx &c, const Fr *r, size_t ell, Fr *out, Fr *scratch) {
 }
 
 // ------------------------------------------------------------------------------------------------ K3/K4/K7 sum-check rounds
-__device__ __forceinline__ void cubic_accum(Fr (&acc)[3], const Pair &a, const Pair &b, const Pair &c, const Pair &d) {
-    // comb = A * (B * C - D) at t = 0, 2, 3 with X(2) = 2 X[hi] - X[lo], X(3) = X(2) + X[hi] - X[lo]
-    acc[0] = fr_add(acc[0], fr_mul(a.lo, fr_sub(fr_mul(b.lo, c.lo), d.lo)));
-    Fr da = fr_sub(a.hi, a.lo), db = fr_sub(b.hi, b.lo), dc = fr_sub(c.hi, c.lo), dd = fr_sub(d.hi, d.lo);
-    Fr a2 = fr_add(a.hi, da), b2 = fr_add(b.hi, db), c2 = fr_add(c.hi, dc), d2 = fr_add(d.hi, dd);
-    acc[1] = fr_add(acc[1], fr_mul(a2, fr_sub(fr_mul(b2, c2), d2)));
-    Fr a3 = fr_add(a2, da), b3 = fr_add(b2, db), c3 = fr_add(c2, dc), d3 = fr_add(d2, dd);
-    acc[2] = fr_add(acc[2], fr_mul(a3, fr_sub(fr_mul(b3, c3), d3)));
-}
-__device__ __forceinline__ void quad_accum(Fr (&acc)[2], const Pair &a, const Pair &b) {
-    acc[0] = fr_add(acc[0], fr_mul(a.lo, b.lo));
-    Fr a2 = fr_sub(fr_add(a.hi, a.hi), a.lo), b2 = fr_sub(fr_add(b.hi, b.hi), b.lo);
-    acc[1] = fr_add(acc[1], fr_mul(a2, b2));
-}
 __device__ __forceinline__ Pair load_pair(const Fr *T, size_t i, size_t half) { Pair p; p.lo = T[i]; p.hi = T[i + half]; return p; }
 // fold the table of length 4q by r (bound_poly_var_top) for the two entries that form pair i of the folded table
 __device__ __forceinline__ Pair fold_pair(Fr *T, size_t i, size_t q, const Fr &r) {
@@ -69,23 +56,9 @@ template <int K> __device__ __forceinline__ void store_partials(Fr (&acc)[K], Fr
 // Round sums without a second launch or a stream synchronise: every workgroup publishes its partial sums, the last one to arrive
 // (agent-scope counter; release/acquire per the gfx950 inter-workgroup recipe) adds them up, writes the K totals straight into
 // pinned host memory and then stores the launch's sequence number into a host-visible flag the prover thread is spinning on.
-// What the LAST thread does to the launch's totals before they go to the host (the nine-limb kernels below sum other quantities than
-// the transcript wants, in a Montgomery radix of their own; both corrections are linear, so they are applied once per launch, not per item):
-//   POST_CUBIC3: (Q(0), Q(1), leading coefficient) of a quadratic  ->  its values at 0, 2, 3;   POST_X32: every total times 32
-enum { POST_NONE = 0, POST_CUBIC3 = 1, POST_X32 = 2 };
-__device__ __forceinline__ Fr fr_const_32() {                 // 32 in the memory format (32 * 2^256 mod l)
-    Fr r; r.v[0] = 0x714df9edu; r.v[1] = 0x334c2e60u; r.v[2] = 0xb3bdf026u; r.v[3] = 0x56eb3c98u; r.v[4] = 0xffffffd6u; r.v[5] = 0xffffffffu; r.v[6] = 0xffffffffu; r.v[7] = 0x0fffffffu; return r;
-}
-__device__ __forceinline__ Fr fr_const_1024() {               // 1024 in the memory format
-    Fr r; r.v[0] = 0xe7fa93edu; r.v[1] = 0xbf4bcbdcu; r.v[2] = 0xbbc206d1u; r.v[3] = 0x56675120u; r.v[4] = 0xfffffac8u; r.v[5] = 0xffffffffu; r.v[6] = 0xffffffffu; r.v[7] = 0x0fffffffu; return r;
-}
-// q = (Q(0), Q(1), Q_inf) of Q(t) = Q(0) + c t + Q_inf t^2  ->  (Q(0), Q(2), Q(3)):  Q(2) = 2 (Q(1) + Q_inf) - Q(0),  Q(3) = 3 Q(1) + 6 Q_inf - 2 Q(0)
-__device__ __forceinline__ void quadratic_to_023(Fr (&q)[3]) {
-    const Fr t = fr_add(q[1], q[2]), t2 = fr_dbl(t);
-    const Fr s2 = fr_sub(t2, q[0]);
-    const Fr s3 = fr_sub(fr_add(fr_add(t2, t), fr_add(fr_dbl(q[2]), q[2])), fr_dbl(q[0]));
-    q[1] = s2; q[2] = s3;
-}
+// What the LAST thread does to the launch's totals before they go to the host: POST_CUBIC3 turns (Q(0), Q(1), leading coefficient) of a
+// quadratic into its values at 0, 2, 3 (the nine-limb kernels below sum the former: linear, so applied once per launch, not per item).
+enum { POST_NONE = 0, POST_CUBIC3 = 1 };
 template <int K, int kPost = POST_NONE> __device__ __forceinline__ void finish_in_kernel(Fr (&acc)[K], const Mailbox &mb) {
     block_reduce<K>(acc);
     if (gridDim.x > 1) {
@@ -98,44 +71,57 @@ template <int K, int kPost = POST_NONE> __device__ __forceinline__ void finish_i
     }
     if (threadIdx.x == 0) {
         if constexpr (kPost == POST_CUBIC3) { static_assert(K == 3, "three totals"); quadratic_to_023(acc); }
-        if constexpr (kPost == POST_X32) {
-            const Fr c32 = fr_const_32();
-#pragma unroll
-            for (int k = 0; k < K; k++) acc[k] = fr_mul(acc[k], c32);
-        }
         for (int k = 0; k < K; k++) mb.host_results[mb.slot + k] = acc[k];
         __threadfence_system();
         __hip_atomic_store(mb.host_flag, mb.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
+// ---- the four-table cubic round (kernel-level ABI; the prover itself uses the three-table form below), in nine limbs (fr9.h):
+// comb = A (B C - D) at t = 0, 2, 3 as it stands — a cubic in t has no shorter set of sums — with X(2) = 2 X_hi - X_lo and
+// X(3) = X(2) + X_hi - X_lo carried down where both sides of a product would otherwise have 31-bit limbs.  A and C go in times 32.
+// a_*5, c_*5 normalised below 71 l; b_*, d_* normalised below 2.2 l.
+__device__ __forceinline__ void cubic4_accum9(Fr9 (&acc)[3], const Fr9 &a_lo5, const Fr9 &a_hi5, const Fr9 &b_lo, const Fr9 &b_hi, const Fr9 &c_lo5, const Fr9 &c_hi5,
+                                              const Fr9 &d_lo, const Fr9 &d_hi) {
+    acc[0] = fr9_add(acc[0], fr9_mul(a_lo5, fr9_sub_kl<4>(fr9_mul(b_lo, c_lo5), d_lo)));
+    const Fr9 da5 = fr9_sub_kl<128>(a_hi5, a_lo5), db = fr9_sub_kl<4>(b_hi, b_lo), dc5 = fr9_sub_kl<128>(c_hi5, c_lo5), dd = fr9_sub_kl<4>(d_hi, d_lo);
+    const Fr9 a2 = fr9_norm(fr9_add(a_hi5, da5)), b2 = fr9_norm(fr9_add(b_hi, db)), c2 = fr9_add(c_hi5, dc5), d2 = fr9_norm(fr9_add(d_hi, dd));   // 270 l, 8.4 l, 270 l, 8.4 l
+    acc[1] = fr9_add(acc[1], fr9_mul(a2, fr9_sub_kl<16>(fr9_mul(b2, c2), d2)));                 // B C < 5.5 l; X < 21.5 l; A X / 2^261 + l < 12.4 l
+    const Fr9 a3 = fr9_norm(fr9_add(a2, da5)), b3 = fr9_norm(fr9_add(b2, db)), c3 = fr9_norm(fr9_add(c2, dc5)), d3 = fr9_norm(fr9_add(d2, dd));   // 469 l, 14.6 l, 469 l, 14.6 l
+    acc[2] = fr9_add(acc[2], fr9_mul(a3, fr9_sub_kl<16>(fr9_mul(b3, c3), d3)));                 // B C < 14.4 l; X < 30.4 l; A X / 2^261 + l < 28.9 l
+}
 // All of an item's loads are issued before any arithmetic so that their HBM latency is paid once per item, not once per table.
 __global__ __launch_bounds__(kBlock) void k_sc_cubic_eval(const Fr *A, const Fr *B, const Fr *C, const Fr *D, size_t half, Mailbox mb) {
-    Fr acc[3] = {fr_zero(), fr_zero(), fr_zero()};
+    Fr9 acc[3] = {fr9_zero(), fr9_zero(), fr9_zero()}; unsigned n = 0;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x) {
-        Pair a, b, c, d;
-        a.lo = A[i]; a.hi = A[i + half]; b.lo = B[i]; b.hi = B[i + half]; c.lo = C[i]; c.hi = C[i + half]; d.lo = D[i]; d.hi = D[i + half];
+        const Fr a0 = A[i], a1 = A[i + half], b0 = B[i], b1 = B[i + half], c0 = C[i], c1 = C[i + half], d0 = D[i], d1 = D[i + half];
         __builtin_amdgcn_sched_barrier(0);                    // keep the scheduler from sinking the loads next to their uses
-        cubic_accum(acc, a, b, c, d);
+        cubic4_accum9(acc, fr9_unpack5(a0), fr9_unpack5(a1), fr9_unpack(b0), fr9_unpack(b1), fr9_unpack5(c0), fr9_unpack5(c1), fr9_unpack(d0), fr9_unpack(d1));
+        if ((++n & 3u) == 0) acc9_carry(acc);
     }
-    finish_in_kernel<3>(acc, mb);
+    Fr tot[3]; acc9_canon<3>(tot, acc);
+    finish_in_kernel<3>(tot, mb);
 }
 __global__ __launch_bounds__(kBlock) void k_sc_cubic_fold_eval(Fr *A, Fr *B, Fr *C, Fr *D, size_t q, Fr r, Mailbox mb) {
-    Fr acc[3] = {fr_zero(), fr_zero(), fr_zero()};
+    const Fr9 r5 = fr9_unpack5(r);
+    Fr9 acc[3] = {fr9_zero(), fr9_zero(), fr9_zero()}; unsigned n = 0;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < q; i += (size_t)gridDim.x * blockDim.x) {
-        // two load groups of eight elements: all sixteen in flight at once would need the whole register file (one wave per SIMD)
-        Fr a0 = A[i], a1 = A[i + q], a2 = A[i + 2 * q], a3 = A[i + 3 * q];
-        Fr b0 = B[i], b1 = B[i + q], b2 = B[i + 2 * q], b3 = B[i + 3 * q];
+        // two load groups of eight elements: all sixteen in flight at once would need the whole register file
+        const Fr a0 = A[i], a1 = A[i + q], a2 = A[i + 2 * q], a3 = A[i + 3 * q];
+        const Fr b0 = B[i], b1 = B[i + q], b2 = B[i + 2 * q], b3 = B[i + 3 * q];
         __builtin_amdgcn_sched_barrier(0);
-        Pair a = fold_regs(a0, a1, a2, a3, r); A[i] = a.lo; A[i + q] = a.hi;
-        Fr c0 = C[i], c1 = C[i + q], c2 = C[i + 2 * q], c3 = C[i + 3 * q];
-        Fr d0 = D[i], d1 = D[i + q], d2 = D[i + 2 * q], d3 = D[i + 3 * q];
+        Fr w0, w1;
+        const Fr9 a_lo = fold9(a0, a2, r5, w0), a_hi = fold9(a1, a3, r5, w1); A[i] = w0; A[i + q] = w1;
+        const Fr c0 = C[i], c1 = C[i + q], c2 = C[i + 2 * q], c3 = C[i + 3 * q];
+        const Fr d0 = D[i], d1 = D[i + q], d2 = D[i + 2 * q], d3 = D[i + 3 * q];
         __builtin_amdgcn_sched_barrier(0);
-        Pair b = fold_regs(b0, b1, b2, b3, r); B[i] = b.lo; B[i + q] = b.hi;
-        Pair c = fold_regs(c0, c1, c2, c3, r); C[i] = c.lo; C[i + q] = c.hi;
-        Pair d = fold_regs(d0, d1, d2, d3, r); D[i] = d.lo; D[i + q] = d.hi;
-        cubic_accum(acc, a, b, c, d);
+        const Fr9 b_lo = fold9(b0, b2, r5, w0), b_hi = fold9(b1, b3, r5, w1); B[i] = w0; B[i + q] = w1;
+        const Fr9 c_lo = fold9(c0, c2, r5, w0), c_hi = fold9(c1, c3, r5, w1); C[i] = w0; C[i + q] = w1;
+        const Fr9 d_lo = fold9(d0, d2, r5, w0), d_hi = fold9(d1, d3, r5, w1); D[i] = w0; D[i + q] = w1;
+        cubic4_accum9(acc, fr9_shl5(a_lo), fr9_shl5(a_hi), b_lo, b_hi, fr9_shl5(c_lo), fr9_shl5(c_hi), d_lo, d_hi);
+        if ((++n & 3u) == 0) acc9_carry(acc);
     }
-    finish_in_kernel<3>(acc, mb);
+    Fr tot[3]; acc9_canon<3>(tot, acc);
+    finish_in_kernel<3>(tot, mb);
 }
 // ---- phase one without the eq table.  eq(tau, .) is a tensor product, so after j rounds the fourth table of the cubic sum-check is
 // D_j[(b, i)] = c_j * (b ? tau_j : 1 - tau_j) * E_j[i]  with  E_j = eq(tau_{j+1..}, .)  and  c_j = prod_{k<j} eq(tau_k, r_k):
@@ -149,10 +135,6 @@ __global__ __launch_bounds__(kBlock) void k_sc_cubic_fold_eval(Fr *A, Fr *B, Fr 
 // operand carried down beyond one normalisation (the points 2 and 3 would want 2 X_hi - X_lo and 3 X_hi - 2 X_lo: limbs of 31 bits on both
 // sides of a product) — and the launch's last thread turns the totals into S_0, S_2, S_3 (POST_CUBIC3).  Montgomery radix 2^261: C and E go
 // in times 32 (shifted unpack / fr9_shl5), everything else as it is, and every product comes out in the memory format.
-__device__ __forceinline__ Fr9 eq5_at(const EqSrc &e, size_t i) {                 // 32 E[i] (mod l): < 3 l from two factors, < 32 l from one table
-    if (!e.hi) return fr9_unpack5(e.lo[i]);
-    return fr9_mul(fr9_unpack5(e.hi[i >> e.lo_bits]), fr9_unpack5(e.lo[i & (((size_t)1 << e.lo_bits) - 1)]));
-}
 // b_*, d_* normalised below 2.2 l; c_*5 normalised below 71 l (32 times an element below 2.2 l); e5 normalised below 32 l.
 // Products: (norm x norm), (norm x limbs < 2^30.6): column sums < 2^63; values: P < 1.4 l, X < 5.4 l, E X / 2^261 + l < 1.4 l.
 __device__ __forceinline__ void cubic3_accum9(Fr9 (&acc)[3], const Fr9 &e5, const Fr9 &b_lo, const Fr9 &b_hi, const Fr9 &c_lo5, const Fr9 &c_hi5, const Fr9 &d_lo, const Fr9 &d_hi) {
@@ -164,22 +146,6 @@ __device__ __forceinline__ void cubic3_accum9(Fr9 (&acc)[3], const Fr9 &e5, cons
     acc[0] = fr9_add(acc[0], fr9_mul(e5, x0));
     acc[1] = fr9_add(acc[1], fr9_mul(e5, x1));
     acc[2] = fr9_add(acc[2], fr9_mul(e5, xi));
-}
-// a thread's three running sums (limbs grow by < 2^29 per item: carried down every fourth item) -> canonical words
-__device__ __forceinline__ void acc9_carry(Fr9 (&acc)[3]) {
-#pragma unroll
-    for (int k = 0; k < 3; k++) acc[k] = fr9_norm(acc[k]);
-}
-template <int K> __device__ __forceinline__ void acc9_canon(Fr (&out)[K], const Fr9 (&acc)[K]) {
-#pragma unroll
-    for (int k = 0; k < K; k++) out[k] = fr9_canon(fr9_norm(acc[k]));
-}
-// bound_poly_var_top of (x0, x2) by r (r5 = 32 r): the folded element, normalised and below 2.2 l, and its canonical word for the table
-__device__ __forceinline__ Fr9 fold9(const Fr &x0, const Fr &x2, const Fr9 &r5, Fr &word) {
-    const Fr9 a = fr9_unpack(x0);
-    const Fr9 s = fr9_norm(fr9_add(a, fr9_mul(r5, fr9_sub_kl<2>(fr9_unpack(x2), a))));   // r5 (x2 - x0 + 2l) / 2^261 + l < 1.2 l
-    word = fr9_pack_lt3l(s);
-    return s;
 }
 __global__ __launch_bounds__(kBlock) void k_sc_cubic3_eval(const Fr *B, const Fr *C, const Fr *D, size_t half, EqSrc E, Mailbox mb) {
     Fr9 acc[3] = {fr9_zero(), fr9_zero(), fr9_zero()}; unsigned n = 0;
@@ -229,24 +195,24 @@ __global__ __launch_bounds__(1024) void k_eq_pyramid(FrArgs r0, int n0, Fr *out0
     }
 }
 // ---- phase two in nine limbs: e_0 = sum A_lo B_lo and e_2 = sum (2 A_hi - A_lo)(2 B_hi - B_lo) as they stand (a third sum for the point 1
-// would cost a product; one carried-down operand costs 24 light instructions).  Nothing goes in times 32 here: both totals come out divided
-// by 32 and the launch's last thread multiplies them back (POST_X32).  a_*, b_* normalised below 2.2 l.
-__device__ __forceinline__ void quad_accum9(Fr9 (&acc)[2], const Fr9 &a_lo, const Fr9 &a_hi, const Fr9 &b_lo, const Fr9 &b_hi) {
-    acc[0] = fr9_add(acc[0], fr9_mul(a_lo, b_lo));
-    const Fr9 u = fr9_norm(fr9_sub_kl<4>(fr9_add(a_hi, a_hi), a_lo));             // limbs < 2^31 before the sweep; value < 8.4 l
-    const Fr9 v = fr9_sub_kl<4>(fr9_add(b_hi, b_hi), b_lo);                       // limbs < 2^31: 9 * 2^29 * 2^31 + 6 * 2^58 < 2^63.4
-    acc[1] = fr9_add(acc[1], fr9_mul(u, v));
+// would cost a product; one carried-down operand costs 24 light instructions).  B goes in times 32 (radix 2^261, fr9.h).
+// a_* normalised below 2.2 l, b_*5 normalised below 71 l; values: u < 8.4 l, v5 < 270 l, u v5 / 2^261 + l < 5.5 l.
+__device__ __forceinline__ void quad_accum9(Fr9 (&acc)[2], const Fr9 &a_lo, const Fr9 &a_hi, const Fr9 &b_lo5, const Fr9 &b_hi5) {
+    acc[0] = fr9_add(acc[0], fr9_mul(a_lo, b_lo5));
+    const Fr9 u = fr9_norm(fr9_sub_kl<4>(fr9_add(a_hi, a_hi), a_lo));             // limbs < 2^31 before the sweep
+    const Fr9 v5 = fr9_sub_kl<128>(fr9_add(b_hi5, b_hi5), b_lo5);                 // limbs < 2^31: 9 * 2^29 * 2^31 + 6 * 2^58 < 2^63.4
+    acc[1] = fr9_add(acc[1], fr9_mul(u, v5));
 }
 __global__ __launch_bounds__(kBlock) void k_sc_quad_eval(const Fr *A, const Fr *B, size_t half, Mailbox mb) {
     Fr9 acc[2] = {fr9_zero(), fr9_zero()}; unsigned n = 0;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x) {
         const Fr a0 = A[i], a1 = A[i + half], b0 = B[i], b1 = B[i + half];
         __builtin_amdgcn_sched_barrier(0);
-        quad_accum9(acc, fr9_unpack(a0), fr9_unpack(a1), fr9_unpack(b0), fr9_unpack(b1));
+        quad_accum9(acc, fr9_unpack(a0), fr9_unpack(a1), fr9_unpack5(b0), fr9_unpack5(b1));
         if ((++n & 3u) == 0) { acc[0] = fr9_norm(acc[0]); acc[1] = fr9_norm(acc[1]); }
     }
     Fr tot[2]; acc9_canon<2>(tot, acc);
-    finish_in_kernel<2, POST_X32>(tot, mb);
+    finish_in_kernel<2>(tot, mb);
 }
 __global__ __launch_bounds__(kBlock) void k_sc_quad_fold_eval(Fr *A, Fr *B, size_t q, Fr r, Mailbox mb, Armed go) {
     if (go.want) { Fr v[1]; if (!armed_fetch<1>(go, v)) return; r = v[0]; }
@@ -259,11 +225,11 @@ __global__ __launch_bounds__(kBlock) void k_sc_quad_fold_eval(Fr *A, Fr *B, size
         Fr w0, w1;
         const Fr9 a_lo = fold9(a0, a2, r5, w0), a_hi = fold9(a1, a3, r5, w1); A[i] = w0; A[i + q] = w1;
         const Fr9 b_lo = fold9(b0, b2, r5, w0), b_hi = fold9(b1, b3, r5, w1); B[i] = w0; B[i + q] = w1;
-        quad_accum9(acc, a_lo, a_hi, b_lo, b_hi);
+        quad_accum9(acc, a_lo, a_hi, fr9_shl5(b_lo), fr9_shl5(b_hi));
         if ((++n & 3u) == 0) { acc[0] = fr9_norm(acc[0]); acc[1] = fr9_norm(acc[1]); }
     }
     Fr tot[2]; acc9_canon<2>(tot, acc);
-    finish_in_kernel<2, POST_X32>(tot, mb);
+    finish_in_kernel<2>(tot, mb);
 }
 __global__ __launch_bounds__(kBlock) void k_fold_top(Fr *Z, size_t half, Fr r) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x) {

@@ -156,4 +156,37 @@ __device__ __forceinline__ Fr eq_at(const EqSrc &e, size_t i) {
     return fr_mul(e.hi[i >> e.lo_bits], e.lo[i & (((size_t)1 << e.lo_bits) - 1)]);
 }
 
+
+// ------------------------------------------------------------------------------------------------ nine-limb helpers (fr9.h) of the round kernels
+// E[i] << S-ish: the eq factor carrying S bits of radix correction: 32 E (S = 5) or 1024 E (S = 10), below 3 l / 65 l from two factors,
+// below 2^S l from one table
+template <int S> __device__ __forceinline__ Fr9 eq_s_at(const EqSrc &e, size_t i) {
+    if (!e.hi) return fr9_unpack_s<S>(e.lo[i]);
+    return fr9_mul(fr9_unpack_s<S>(e.hi[i >> e.lo_bits]), fr9_unpack5(e.lo[i & (((size_t)1 << e.lo_bits) - 1)]));
+}
+__device__ __forceinline__ Fr9 eq5_at(const EqSrc &e, size_t i) { return eq_s_at<5>(e, i); }
+// q = (Q(0), Q(1), Q_inf) of Q(t) = Q(0) + c t + Q_inf t^2  ->  (Q(0), Q(2), Q(3)):  Q(2) = 2 (Q(1) + Q_inf) - Q(0),  Q(3) = 3 Q(1) + 6 Q_inf - 2 Q(0)
+__device__ __forceinline__ void quadratic_to_023(Fr (&q)[3]) {
+    const Fr t = fr_add(q[1], q[2]), t2 = fr_dbl(t);
+    const Fr s2 = fr_sub(t2, q[0]);
+    const Fr s3 = fr_sub(fr_add(fr_add(t2, t), fr_add(fr_dbl(q[2]), q[2])), fr_dbl(q[0]));
+    q[1] = s2; q[2] = s3;
+}
+// a thread's running sums (limbs grow by < 2^29 per item: carried down every fourth item) -> canonical words
+__device__ __forceinline__ void acc9_carry(Fr9 (&acc)[3]) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) acc[k] = fr9_norm(acc[k]);
+}
+template <int K> __device__ __forceinline__ void acc9_canon(Fr (&out)[K], const Fr9 (&acc)[K]) {
+#pragma unroll
+    for (int k = 0; k < K; k++) out[k] = fr9_canon(fr9_norm(acc[k]));
+}
+// bound_poly_var_top of (x0, x2) by r (r5 = 32 r): the folded element, normalised and below 2.2 l, and its canonical word for the table
+__device__ __forceinline__ Fr9 fold9(const Fr &x0, const Fr &x2, const Fr9 &r5, Fr &word) {
+    const Fr9 a = fr9_unpack(x0);
+    const Fr9 s = fr9_norm(fr9_add(a, fr9_mul(r5, fr9_sub_kl<2>(fr9_unpack(x2), a))));   // r5 (x2 - x0 + 2l) / 2^261 + l < 1.2 l
+    word = fr9_pack_lt3l(s);
+    return s;
+}
+
 }  // namespace otti
