@@ -73,6 +73,12 @@ int32_t otti_gens_points(const otti_gens *gens, uint8_t *out32, size_t count);
    (OTTI_MSM_WINDOW pins it; otherwise the widest whose table fits OTTI_MSM_TABLE_GB, default 128) and its size; zeros before that.
    No reference counterpart: dalek's vartime MSM builds per-call tables. */
 int32_t otti_gens_table_info(const otti_gens *gens, uint32_t *window_bits, uint64_t *table_bytes);
+/* frees the device-side window table (tens of GB); it is built again by the next otti_prepare_device or proof with these generators.
+ * For a process that moves between instance sizes: two wide tables do not fit one card.  Not while a proof with them is running. */
+int32_t otti_gens_release_device(otti_gens *gens);
+/* what building the table took, in ms: the HBM allocations (driver work: differs widely between boxes and between a fresh and a used
+ * process) and the upload + fill kernels (proportional to the table); zeros before it has been built */
+int32_t otti_gens_build_ms(const otti_gens *gens, double *alloc_ms, double *kernels_ms);
 
 /* NIZK::prove(&inst, vars, &inputs, &gens, &mut Transcript::new(tlabel)) -> NIZK, bincode-serialised.
    VarsAssignment::new / InputsAssignment::new validation (InvalidScalar) happens here.

@@ -106,6 +106,8 @@ _sig("otti_bench_madd_peak", _i32, ctypes.POINTER(ctypes.c_double))
 _sig("otti_stats_enable", _i32, _i32)
 _sig("otti_stats_select", _i32, ctypes.c_char_p)
 _sig("otti_armed_launches_on", _i32, ctypes.POINTER(_i32))
+_sig("otti_gens_release_device", _i32, _vp)
+_sig("otti_gens_build_ms", _i32, _vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double))
 _sig("otti_bench_fr_mul_peak", _i32, ctypes.POINTER(ctypes.c_double))
 _sig("otti_stats_read", _i32, ctypes.c_char_p, ctypes.POINTER(_u64), ctypes.POINTER(ctypes.c_double))
 _sig("otti_lanes_pack", None, _vp, _sz, _vp)
@@ -294,6 +296,17 @@ class NIZKGens:
         c, b = ctypes.c_uint32(), _u64()
         _check(lib.otti_gens_table_info(self._h, ctypes.byref(c), ctypes.byref(b)))
         return c.value, b.value
+
+    @property
+    def build_ms(self):
+        """(allocations, upload + kernels) of the last window-table build, in ms"""
+        a, k = ctypes.c_double(), ctypes.c_double()
+        _check(lib.otti_gens_build_ms(self._h, ctypes.byref(a), ctypes.byref(k)))
+        return a.value, k.value
+
+    def release_device(self):
+        """free the device-side window table (rebuilt by the next prepare_device / proof)"""
+        _check(lib.otti_gens_release_device(self._h))
 
     def points(self, count):
         out = np.zeros((count, 32), dtype=np.uint8)

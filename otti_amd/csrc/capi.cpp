@@ -248,6 +248,22 @@ int32_t otti_gens_table_info(const otti_gens *gens, uint32_t *window_bits, uint6
         return OTTI_OK;
     });
 }
+int32_t otti_gens_build_ms(const otti_gens *gens, double *alloc_ms, double *kernels_ms) {
+    return guarded([&] {
+        if (!gens) throw Error(OTTI_ERR_BAD_ARG, "null argument");
+        const DeviceGens *d = gens->g->dev.get();
+        if (alloc_ms) *alloc_ms = d ? d->build_ms[0] : 0.0;
+        if (kernels_ms) *kernels_ms = d ? d->build_ms[1] : 0.0;
+        return OTTI_OK;
+    });
+}
+int32_t otti_gens_release_device(otti_gens *gens) {
+    return guarded([&] {
+        if (!gens) throw Error(OTTI_ERR_BAD_ARG, "null argument");
+        release_gens_device(*gens->g);
+        return OTTI_OK;
+    });
+}
 int32_t otti_gens_points(const otti_gens *gens, uint8_t *out32, size_t count) {
     return guarded([&] {
         if (!gens || count > gens->g->P.size()) throw Error(OTTI_ERR_BAD_ARG, "count exceeds the generator stream");

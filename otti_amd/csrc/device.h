@@ -47,6 +47,7 @@ struct DeviceShard { int rank = 0, world = 1; DeviceCsrSet by_row, by_col; };
 // fixed-base window table: entry (base b, window w, digit d in 1..E) = d * 2^(c*w) * P[b] in affine Niels form
 struct DeviceGens {
     DevBuf<TabEntry> table; int c = 0, W = 0; size_t E = 0, nbases = 0;
+    double build_ms[2] = {0, 0};                            // what building it took: allocations / upload + kernels
     const TabEntry *entry0(size_t base) const { return table.p + base * (size_t)W * E; }
 };
 
@@ -162,6 +163,7 @@ struct DeviceWitness {
 void ensure_device_objects(Instance &I, Gens &g);          // lazily built, shared by every prover thread (guarded)
 void ensure_instance_device(Instance &I);
 void ensure_gens_device(Gens &g);
+void release_gens_device(Gens &g);                                     // frees the window table; the next ensure_gens_device rebuilds it
 int device_window_bits(size_t nbases);                   // window width of the fixed-base table (prover.cpp)
 // R1CSInstance::evaluate on the device: (A,B,C)(rx,ry) = <eq(rx), M * eq(ry)> for M in {A,B,C}  (verifier's O(nnz + N + V) work)
 constexpr int kInstEvalSlot = 16;                            // result slots of the instance evaluation (nothing a verifier launches in between writes them)

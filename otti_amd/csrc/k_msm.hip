@@ -525,19 +525,25 @@ std::shared_ptr<DeviceGens> build_device_gens(const Gens &g, int c) {
     d->c = c; d->W = 253 / c + 1; d->E = (size_t)1 << (c - 1); d->nbases = g.P.size();
     const size_t per_base = (size_t)d->W * d->E;
     const int lgT = std::min(6, c - 1); const size_t T = (size_t)1 << lgT, nblk = d->E / T;
+    // laps (otti_gens_build_ms): the allocation of tens of GB is the part that differs by an order of magnitude between boxes and between
+    // a fresh and a used process (the driver maps and clears the pages); the kernels scale with the table and nothing else
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
     d->table.alloc(d->nbases * per_base);
-    DevBuf<Pt> bases(d->nbases), starts(d->nbases * d->W * nblk);
-    OTTI_HIP(hipMemcpy(bases.p, g.P.data(), d->nbases * sizeof(Pt), hipMemcpyHostToDevice));
-    { size_t n = d->nbases * d->W; hipLaunchKernelGGL(k_table_starts, (unsigned)((n + kBlock - 1) / kBlock), kBlock, 0, ctx.stream, (const Pt *)bases.p, d->nbases, c, d->W, nblk, lgT, starts.p); }
     size_t chunk = std::max<size_t>(1, ((size_t)4 << 30) / (per_base * sizeof(Pt)));            // <= 4 GiB of extended temporaries
     chunk = std::min(chunk, d->nbases);
-    DevBuf<Pt> tmp(chunk * per_base);
+    DevBuf<Pt> bases(d->nbases), starts(d->nbases * d->W * nblk), tmp(chunk * per_base);
+    const double t1 = now();
+    OTTI_HIP(hipMemcpy(bases.p, g.P.data(), d->nbases * sizeof(Pt), hipMemcpyHostToDevice));
+    { size_t n = d->nbases * d->W; hipLaunchKernelGGL(k_table_starts, (unsigned)((n + kBlock - 1) / kBlock), kBlock, 0, ctx.stream, (const Pt *)bases.p, d->nbases, c, d->W, nblk, lgT, starts.p); }
     for (size_t b0 = 0; b0 < d->nbases; b0 += chunk) {
         size_t nb = std::min(chunk, d->nbases - b0), nrows = nb * d->W, nthreads = nrows * nblk;
         hipLaunchKernelGGL(k_table_fill, (unsigned)((nthreads + kBlock - 1) / kBlock), kBlock, 0, ctx.stream, (const Pt *)(starts.p + b0 * d->W * nblk), nrows, nblk, T,
                            tmp.p, d->table.p + b0 * per_base);
     }
     ctx.sync();
+    const double t2 = now();
+    d->build_ms[0] = t1 - t0; d->build_ms[1] = t2 - t1;
     return d;
 }
 

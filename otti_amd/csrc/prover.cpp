@@ -22,14 +22,16 @@ static double now_ms() { return std::chrono::duration<double, std::milli>(std::c
 
 // Window width c of the fixed-base table.  Every bit of c removes additions from every MSM of every proof (W = floor(253/c)+1 per
 // scalar) and doubles the table; the table is built once per generator set and HBM is 288 GB, so take the widest window whose table
-// fits a budget (default 128 GiB: c = 16 for R = 1024 (51.6 GB) and R = 2048 (103 GB), 15 for R = 4096 (110 GB)).  OTTI_MSM_WINDOW pins c;
+// fits a budget (default 128 GiB: c = 17 for R = 1024 (96.8 GB; round 3 stopped at 16), 16 for R = 2048 (103 GB), 15 for R = 4096 (110 GB)).  A 200 GiB
+// budget (c = 17 / 17 / 16) was measured in round 4: the commitment MSMs gain their 6 %, but with 190+ GB in one allocation the streaming kernels of a
+// 2^22 proof ran 0.25 ms slower per sum-check and the table took seconds to allocate: not the default.  OTTI_MSM_WINDOW pins c;
 // OTTI_MSM_TABLE_GB changes the budget (one-shot callers such as spzk pick a small table: building it costs more than it saves).
 int device_window_bits(size_t nbases) {
     if (const char *e = getenv("OTTI_MSM_WINDOW")) { int c = atoi(e); if (c >= 4 && c <= 17) return c; }
     double budget_gb = 128.0;
     if (const char *e = getenv("OTTI_MSM_TABLE_GB")) { double v = atof(e); if (v > 0) budget_gb = v; }
     int best = 8;
-    const int widest = nbases < 256 ? 12 : 16;             // tiny instances (R < 256) are launch-bound whatever the window: keep their tables small
+    const int widest = nbases < 256 ? 12 : 17;             // tiny instances (R < 256) are launch-bound whatever the window: keep their tables small
     for (int c = 8; c <= widest; c++) {
         const double W = 253 / c + 1, bytes = (double)nbases * W * (double)((size_t)1 << (c - 1)) * sizeof(TabEntry);
         if (bytes <= budget_gb * 1073741824.0) best = c;
@@ -44,16 +46,18 @@ void ensure_gens_device(Gens &g) {
     if (g.dev) return;
     // the widest window the budget allows; if HBM is short right now (other tenants of the GPU, other generator sets), a narrower one
     const int want = device_window_bits(g.R + 2);
-    for (int c = want;; c -= 2) {
+    for (int c = want;; c--) {
         try {
             g.dev = build_device_gens(g, c);
             // a narrower table means more additions in every MSM of every proof: say so once (otti_gens_table_info reports the width in use)
             if (c != want) fprintf(stderr, "[otti] notice: HBM is short: generator window table built with c = %d instead of %d (%zu generators); proofs are unchanged, MSMs slower\n", c, want, g.R + 2);
             return;
         }
-        catch (const OutOfDeviceMemory &) { if (c - 2 < 8 || getenv("OTTI_MSM_WINDOW")) throw; }
+        catch (const OutOfDeviceMemory &) { if (c - 1 < 8 || getenv("OTTI_MSM_WINDOW")) throw; }
     }
 }
+// frees the window table (the next ensure_gens_device builds it again): a caller that needs the HBM for another generator set's table
+void release_gens_device(Gens &g) { std::lock_guard<std::mutex> lk(device_objects_mu()); g.dev.reset(); }
 void ensure_device_objects(Instance &I, Gens &g) { ensure_instance_device(I); ensure_gens_device(g); }
 
 // the verifiers' fixed-base sums (spartan.h g_fixed_base_msm_hook): one row over the resident table; never builds a table for it
