@@ -12,7 +12,10 @@ namespace otti {
 
 #define OTTI_HIP(expr) ::otti::hip_check((expr), #expr, __FILE__, __LINE__)
 void hip_check(hipError_t e, const char *what, const char *file, int line);
-struct OutOfDeviceMemory : Error { using Error::Error; };   // hipErrorOutOfMemory: callers that can make do with less catch this one
+struct OutOfDeviceMemory : Error { using Error::Error; };
+// the persistent sum-check tail (snark_dev.h) never answered: its grid was not resident as a whole (another tenant of the GPU, a CU mask, a
+// partition).  SNARK::prove catches this one, switches the tail off for the process and proves again with a launch per round.
+struct TailTimeout : Error { using Error::Error; };   // hipErrorOutOfMemory: callers that can make do with less catch this one
 
 template <class T> struct DevBuf {
     T *p = nullptr; size_t n = 0;
@@ -57,10 +60,10 @@ struct Mailbox { Fr *partials; unsigned *counter; Fr *host_results; unsigned lon
 // Armed launches.  The sequential rounds cost a launch + dispatch (10-15 us) on top of the kernel itself when the kernel can only be
 // launched once the host knows the round's challenge.  An ARMED kernel is queued before that: its first workgroup spins on a pinned host
 // word until the host publishes the value (DevCtx::go), copies it to HBM for the other workgroups, and the round starts within a PCIe
-// read of the challenge being known.  Every spin has a deadline (3 s of s_memrealtime) and an abort value, so a grid always drains.
+// read of the challenge being known.  Every spin has a deadline (kArmDeadlineTicks of s_memrealtime: 30 s) and an abort value, so a grid always drains.
 // ONE decision per armed launch: only the launch's first workgroup watches the host word and its deadline, and what it decides (the
-// value arrived / aborted / gave up) is what every other workgroup acts on (they watch dev->seq alone, with a backstop far beyond
-// the leader's deadline) — a grid never folds in part.  A leader that gives up says so in host->timed_out, so the host fails the
+// value arrived / aborted / gave up) is what every other workgroup acts on (they watch dev->seq alone, with a backstop of
+// the leader's deadline plus a quarter: the leader never ran) — a grid never folds in part.  A leader that gives up says so in host->timed_out, so the host fails the
 // proof at once instead of waiting for a result that will not come.
 // Layout: the sequence number, a tag and the first value share one 64-byte line, so a poll that finds the number it waits for has the
 // value in the same batch of loads (one PCIe round trip, not two).  The tag = go_tag(seq, values) makes a batch self-validating: the

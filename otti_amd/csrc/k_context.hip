@@ -214,6 +214,7 @@ void DevCtx::ensure_tail_mail() {
     memset(h_tail, 0, (size_t)kTailMaxGroups * sizeof(TailMail));
     OTTI_HIP(hipHostGetDevicePointer((void **)&d_tail_alias, h_tail, 0));
 }
+static long tail_timeout_ms() { static const long v = [] { const char *e = getenv("OTTI_TAIL_TIMEOUT_MS"); long x = e ? atol(e) : 0; return x > 0 ? x : 5000L; }(); return v; }
 void DevCtx::wait_tail(int n_groups, unsigned long long want) {
     const auto t0 = std::chrono::steady_clock::now();
     int done = 0;                                             // lines [0, done) have arrived
@@ -227,28 +228,58 @@ void DevCtx::wait_tail(int n_groups, unsigned long long want) {
             go_abort();
             throw Error(OTTI_ERR_INTERNAL, "the persistent sum-check launch gave up waiting for the host (the proving thread was stalled beyond the launch's deadline)");
         }
-        if ((spins & 0xffff) == 0xffff && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) {
+        // a round of the persistent launch takes tens of microseconds; seconds without every line in mean that part of its grid is not
+        // resident (the workgroups that are wait for the host, the host for all of them): give the launch up — the caller proves again without it
+        if ((spins & 0xffff) == 0xffff && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(tail_timeout_ms())) {
             if (go_published < go_issued) go_abort(); else { (void)hipStreamSynchronize(stream); reset_arrival_counters(); }
-            throw Error(OTTI_ERR_INTERNAL, "sum-check round result never arrived (persistent launch)");
+            throw TailTimeout(OTTI_ERR_INTERNAL, "sum-check round result never arrived (persistent launch: its grid was not resident as a whole)");
         }
     }
 }
 // the same wait, adding up the W partial sums of every instance as its lines come in (lines a few ahead are prefetched: each is a fresh
 // cache line the device has just written, and 144 dependent misses in a row would cost more than the round's arithmetic)
-void DevCtx::wait_tail_sums(int n_inst, int W, unsigned long long want, Fr *sums /* [n_inst][3] */) {
-    const int n = n_inst * W;
+// lines [i0, i1) of a round's mails: wait for each (bounded when `bounded`: a helper thread must not throw) and add the W partials of every instance up
+static bool tail_sum_range(TailMail *h_tail, int i0, int i1, int W, unsigned long long want, Fr *sums, bool bounded) {
 #if defined(__x86_64__)
-    for (int i = 0; i < n && i < 16; i++) { _mm_prefetch((const char *)&h_tail[i], _MM_HINT_T0); _mm_prefetch((const char *)&h_tail[i] + 64, _MM_HINT_T0); }
+    for (int i = i0; i < i1 && i < i0 + 16; i++) { _mm_prefetch((const char *)&h_tail[i], _MM_HINT_T0); _mm_prefetch((const char *)&h_tail[i] + 64, _MM_HINT_T0); }
 #endif
-    for (int i = 0; i < n; i++) {
+    for (int i = i0; i < i1; i++) {
 #if defined(__x86_64__)
-        if (i + 16 < n) { _mm_prefetch((const char *)&h_tail[i + 16], _MM_HINT_T0); _mm_prefetch((const char *)&h_tail[i + 16] + 64, _MM_HINT_T0); }
+        if (i + 16 < i1) { _mm_prefetch((const char *)&h_tail[i + 16], _MM_HINT_T0); _mm_prefetch((const char *)&h_tail[i + 16] + 64, _MM_HINT_T0); }
 #endif
-        if (__atomic_load_n(&h_tail[i].seq, __ATOMIC_ACQUIRE) < want) { wait_tail(i + 1, want); }     // not in yet: the slow path (with its failure handling) up to this line
+        if (bounded) {
+            unsigned spins = 0;
+            while (__atomic_load_n(&h_tail[i].seq, __ATOMIC_ACQUIRE) < want) {
+                if (++spins > 2000000u) return false;             // ~ a millisecond or more: the calling thread takes the slow path with its failure handling
+#if defined(__x86_64__)
+                _mm_pause();
+#endif
+            }
+        }
         Fr *acc = sums + 3 * (i / W);
         if (i % W == 0) { acc[0] = h_tail[i].s[0]; acc[1] = h_tail[i].s[1]; acc[2] = h_tail[i].s[2]; }
         else { acc[0] = fr_add(acc[0], h_tail[i].s[0]); acc[1] = fr_add(acc[1], h_tail[i].s[1]); acc[2] = fr_add(acc[2], h_tail[i].s[2]); }
     }
+    return true;
+}
+void DevCtx::wait_tail_sums(int n_inst, int W, unsigned long long want, Fr *sums /* [n_inst][3] */) {
+    const int n = n_inst * W;
+    // 128-144 lines of 3 partial sums: adding them up on one core cost 2.6 us of every round (profiles/r3_tail_stamps.txt); the instances are
+    // independent, so the prover thread's helpers (pool.h: pinned next to it, ~55 ns hand-over) take a share each
+    SpinPool &pool = SpinPool::get();
+    const int nt = (n >= 48 && n_inst >= 2) ? std::min(std::min(4, pool.workers() + 1), n_inst) : 1;
+    if (nt > 1) {
+        bool ok[4] = {true, true, true, true};
+        std::function<void()> tasks[4];
+        for (int t = 0; t < nt; t++) {
+            const int y0 = n_inst * t / nt, y1 = n_inst * (t + 1) / nt;
+            tasks[t] = [this, t, y0, y1, W, want, sums, &ok] { ok[t] = tail_sum_range(h_tail, y0 * W, y1 * W, W, want, sums, true); };
+        }
+        pool.parallel(tasks, nt);
+        if (ok[0] && ok[1] && ok[2] && ok[3]) return;
+    }
+    wait_tail(n, want);                                       // (throws if the launch gave up or never answers)
+    tail_sum_range(h_tail, 0, n, W, want, sums, false);
 }
 void DevCtx::wait_points(unsigned long long ticket) {
     if (!ticket) { sync(); return; }

@@ -237,6 +237,7 @@ struct TailArgs {
     PcList L; int W; uint32_t len0, t_out; int fold_on_load; Fr r; EqSrc E;
     TailMail *mail; Fr *host_out; unsigned long long seq0; Armed go;        // go.want: the go() number of the first round's challenge
     unsigned long long *stamps;                                             // OTTI_TAIL_STAMPS: wall_clock64 (100 MHz) of workgroup (0,0) at the phase boundaries, 8 per round
+    int test_drop;                                                          // OTTI_TEST_TAIL_DROP (tests): every other workgroup returns at once, as if it had never become resident
 };
 // A wave works on ONE evaluation point (wave % 3) and group g = wave / 3 takes the pairs g*64 + lane, + 64*groups, ...: no divergence over
 // the point inside a wave, and a wave's 64 partial sums of its one point fold by shuffles of ONE field element per level (the first
@@ -265,6 +266,7 @@ __global__ __launch_bounds__(kTailThreads) void k_pc_tail(TailArgs a) {
     __shared__ Fr T0[3 * kTailCap];                                    // three tables of kTailCap elements: A, B, C (96 KB of the CU's 160: one workgroup per CU)
     __shared__ Fr s_part[3][16]; __shared__ Fr s_tot[3];
     const int w = blockIdx.x, y = blockIdx.y, W = a.W, tid = threadIdx.x, nthr = blockDim.x;
+    if (a.test_drop && ((w + y) & 1)) return;
     const Fr *src[3] = {a.L.A[y], a.L.B[y], a.L.C[y]};
     TailMail *const mail = a.mail + (size_t)y * W + w;
     uint32_t L = a.len0 / (uint32_t)W;                                  // this workgroup's share of every table
@@ -339,6 +341,8 @@ unsigned long long dev_pc_tail(DevCtx &c, const PcList &L, int W, size_t len0, s
     a.mail = c.d_tail_alias; a.host_out = c.d_results_alias + slot;
     a.seq0 = c.seq + 1; c.seq += (unsigned long long)rounds + 1;
     a.go = c.arm_many(rounds);
+    static const bool test_drop = getenv("OTTI_TEST_TAIL_DROP") != nullptr;
+    a.test_drop = test_drop ? 1 : 0;
     static const bool want_stamps = getenv("OTTI_TAIL_STAMPS") != nullptr;
     static thread_local unsigned long long *h_stamps = nullptr, *d_stamps = nullptr;
     a.stamps = nullptr;

@@ -54,7 +54,7 @@ __device__ __forceinline__ bool arrive_and_check_last(unsigned *counter, unsigne
 // ------------------------------------------------------------------------------------------------ armed launches (device.h)
 // Every workgroup calls this first.  Workgroup (0,0) — and only it — waits for the host's value in pinned memory against the launch's
 // deadline and republishes its DECISION in HBM: the value, or abort (host said so / deadline passed).  The others wait for that
-// decision alone; their own backstop (16 x the deadline: the leader never ran) only exists so that a grid always drains.
+// decision alone; their own backstop (the deadline plus a quarter: the leader never ran) only exists so that a grid always drains.
 // Returns false in every thread of the workgroup when the launch was aborted or gave up: the kernel then returns at once, having
 // touched nothing.
 template <int N> __device__ __forceinline__ bool armed_fetch(const Armed &a, Fr (&v)[N]) {
@@ -97,11 +97,14 @@ template <int N> __device__ __forceinline__ bool armed_fetch(const Armed &a, Fr 
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __hip_atomic_store(&a.dev->seq, ok ? a.want : (a.want | abort_bit), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
-            const unsigned long long backstop = a.deadline << 4;
-            while (ok < 0) {
+            const unsigned long long backstop = a.deadline + (a.deadline >> 2);   // the leader's deadline and a margin (it reports; this only drains the grid)
+            for (unsigned polls = 0; ok < 0; polls++) {
                 const unsigned long long s = __hip_atomic_load(&a.dev->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (s == a.want) ok = 1;
                 else if (s == (a.want | abort_bit) || __builtin_amdgcn_s_memrealtime() - t0 > backstop) ok = 0;
+                // a leader that is not resident (a grid larger than the CUs this process may use) cannot pass the host's abort on: look at the
+                // host word itself once in a while (one PCIe read per few thousand polls)
+                else if ((polls & 0xfffu) == 0xfffu && __hip_atomic_load(&a.host->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == ~0ull) ok = 0;
                 else __builtin_amdgcn_s_sleep(1);
             }
             if (ok) for (int k = 0; k < N; k++) load_words_sc1(t[k].v, &a.dev->v[k], 8);

@@ -10,6 +10,7 @@
 // not zero-knowledge: no commitments on the sequential path).  The three closing
 // polynomial-evaluation proofs reuse the log-size dot-product prover of NIZK mode (bullet rounds on the original generators).
 #include "snark.h"
+#include <atomic>
 #include "snark_dev.h"
 #include "pool.h"
 #include <chrono>
@@ -133,6 +134,8 @@ std::unique_ptr<CompComm> snark_encode_gpu(Instance &I, SnarkGens &g) {
 
 // ================================================================================================ product circuits and their batched proof
 namespace {
+// set when a persistent tail never answered (TailTimeout): the process goes on with a launch per round
+std::atomic<bool> g_tail_off{false};
 // a batch of product circuits of one size: layer k of circuit i is (left, right) = store + off[k] + {0, n >> (k + 1)}
 struct Circuits {
     size_t n = 0, nl = 0; int count = 0;
@@ -177,7 +180,9 @@ ProductCircuitEvalProofBatched pcbatch_prove(DevCtx &c, Circuits &C, const std::
     // also take the route where the tail picks up tables that earlier launches folded in HBM)
     static const bool tail_env = [] { const char *e = getenv("OTTI_PC_TAIL"); return !(e && e[0] == '0'); }();
     static const size_t tail_cap = [] { const char *e = getenv("OTTI_PC_TAIL_CAP"); size_t v = e ? (size_t)atoi(e) : 0; return (v >= 2 && v <= (size_t)kTailCap && !(v & (v - 1))) ? v : (size_t)kTailCap; }();
-    const bool tail_ok = arm_ok && tail_env;
+    const bool tail_ok = arm_ok && tail_env && !g_tail_off.load(std::memory_order_relaxed);
+    // its grid (W workgroups per instance, one per CU: 96 KB of LDS each) must be resident as a whole: never more workgroups than the device has CUs
+    const int tail_groups_max = std::min(kTailMaxGroups, c.num_cu);
     static const size_t lgt_env_many = [] { const char *e = getenv("OTTI_PC_LGT_MANY"); return e ? (size_t)atoi(e) : (size_t)0; }();
     static const size_t lgt_env_few = [] { const char *e = getenv("OTTI_PC_LGT_FEW"); return e ? (size_t)atoi(e) : (size_t)0; }();
     static const size_t pc_arm_max = [] { const char *e = getenv("OTTI_PC_ARM_MAX"); return e ? (size_t)atoll(e) : (size_t)1 << 22; }();     // (the sum-check kernels of the R1CS proof arm up to kArmMaxLen; here a round more or less ahead costs nothing else)
@@ -204,8 +209,8 @@ ProductCircuitEvalProofBatched pcbatch_prove(DevCtx &c, Circuits &C, const std::
         // must be resident as a whole: the workgroups wait for the host, the host for all of them) and no kernel class it belongs to is
         // being timed; otherwise, and for the rounds before k0, a launch per round as before.
         size_t k0 = ndev; int tailW = 1;
-        if (ndev && tail_ok) {
-            int Wmax = 1; while (2 * Wmax * ni <= kTailMaxGroups && (size_t)(2 * Wmax) <= T) Wmax *= 2;
+        if (ndev && tail_ok && ni <= tail_groups_max) {
+            int Wmax = 1; while (2 * Wmax * ni <= tail_groups_max && (size_t)(2 * Wmax) <= T) Wmax *= 2;
             const size_t cap_all = tail_cap * (size_t)Wmax;
             k0 = 0; while ((h >> k0) > cap_all) k0++;
             if (k0 >= ndev) k0 = ndev;                           // (cannot happen for cap_all >= 2 T; kept for a shrunken test capacity)
@@ -426,9 +431,12 @@ struct RowsAhead {
         static std::once_flag once; static hipStream_t ms = nullptr;   // running stalls the proving thread's launches, and helper threads lease a different pooled context each time
         std::call_once(once, [] {
             const char *e = getenv("OTTI_DEREFS_CUMASK");
-            const int free_words = masked_free_cus() / 32;
-            uint32_t mask[8]; for (int i = 0; i < 8; i++) mask[i] = i < free_words ? 0u : 0xffffffffu;
-            if (!(e && e[0] == '0') && hipExtStreamCreateWithCUMask(&ms, 8, mask) != hipSuccess) { (void)hipGetLastError(); ms = nullptr; }
+            // the mask is cut to the device's own CU count (a partition has fewer than 256); with fewer than 128 CUs there is nothing worth
+            // setting aside: no masked stream, and the caller does not commit ahead of time at all
+            const int ncu = DevCtx::get().num_cu, free_words = masked_free_cus() / 32, words = (ncu + 31) / 32;
+            if (ncu < 128 || words > 8 || free_words >= words) { ms = nullptr; return; }
+            uint32_t mask[8]; for (int i = 0; i < 8; i++) mask[i] = (i < free_words || i >= words) ? 0u : (i == words - 1 && (ncu & 31)) ? ((1u << (ncu & 31)) - 1u) : 0xffffffffu;
+            if (!(e && e[0] == '0') && hipExtStreamCreateWithCUMask(&ms, (uint32_t)words, mask) != hipSuccess) { (void)hipGetLastError(); ms = nullptr; }
         });
         return ms;
     }
@@ -449,7 +457,11 @@ struct RowsAhead {
             if (trace) fprintf(stderr, "[otti] rows ahead: %zu rows on %s: queued in %.3f ms, summed %.3f ms after the release\n", rows, ms ? "the CU-masked stream" : "an ordinary second stream (no CU mask)", t_queued - t_go, now_ms() - t_go);
             std::vector<CPoint> out(rows); memcpy(out.data(), hc.h_points, 32 * rows);
             std::lock_guard<std::mutex> lk(mu); C = std::move(out); done = true;
-        } catch (...) { std::lock_guard<std::mutex> lk(mu); err = std::current_exception(); done = true; }
+        } catch (...) {
+            // whatever was queued on the (shared) masked stream may still be using this context's buffers: drain it before the context goes back to the pool
+            if (hipStream_t ms = masked_stream()) (void)hipStreamSynchronize(ms);
+            std::lock_guard<std::mutex> lk(mu); err = std::current_exception(); done = true;
+        }
         cv.notify_all();
     }
 };
@@ -461,8 +473,21 @@ std::vector<uint8_t> snark_prove_gpu(Instance &I, CompComm &comm, const uint8_t 
     DeviceWitness wit(I, vars32, nvars, inputs);                 // uploaded (and checked for canonical scalars) inside the call
     return snark_prove_resident(I, comm, wit, g, tlabel, tlabel_len, seed32, tm);
 }
+static std::vector<uint8_t> snark_prove_resident_once(Instance &I, CompComm &comm, DeviceWitness &wit, SnarkGens &g, const void *tlabel, size_t tlabel_len,
+                                                      const uint8_t *seed32, SnarkTimings *tm);
 std::vector<uint8_t> snark_prove_resident(Instance &I, CompComm &comm, DeviceWitness &wit, SnarkGens &g, const void *tlabel, size_t tlabel_len,
                                           const uint8_t *seed32, SnarkTimings *tm) {
+    try { return snark_prove_resident_once(I, comm, wit, g, tlabel, tlabel_len, seed32, tm); }
+    catch (const TailTimeout &e) {
+        // the persistent tail's grid was not resident as a whole (the GPU is shared, partitioned or CU-masked): a proof is a function of its
+        // inputs and the tape seed, so proving again — with a launch per round from now on — gives the bytes the first attempt would have given
+        if (g_tail_off.exchange(true)) throw;
+        fprintf(stderr, "[otti] notice: %s; SNARK::prove repeats the proof with one launch per sum-check round, and this process keeps doing so\n", e.what());
+        return snark_prove_resident_once(I, comm, wit, g, tlabel, tlabel_len, seed32, tm);
+    }
+}
+static std::vector<uint8_t> snark_prove_resident_once(Instance &I, CompComm &comm, DeviceWitness &wit, SnarkGens &g, const void *tlabel, size_t tlabel_len,
+                                                      const uint8_t *seed32, SnarkTimings *tm) {
     DevCtx &c = DevCtx::get();
     ActiveProof active;
     SpinPool::Session pool_session;
@@ -494,7 +519,7 @@ std::vector<uint8_t> snark_prove_resident(Instance &I, CompComm &comm, DeviceWit
     // of the derefs commitment on the helper's stream (RowsAhead above); the column side follows after the R1CS proof
     const size_t rows_half = g.derefs.R ? 3 * N / g.derefs.R : 0;
     static const bool ahead_env = [] { const char *e = getenv("OTTI_DEREFS_AHEAD"); return !(e && e[0] == '0'); }();
-    const bool ahead = ahead_env && c.armed_ok() && N >= ((size_t)1 << 14) && rows_half >= 64 && rows_half * g.derefs.R == 3 * N && 2 * rows_half <= g.derefs.L;
+    const bool ahead = ahead_env && c.armed_ok() && c.num_cu >= 128 && N >= ((size_t)1 << 14) && rows_half >= 64 && rows_half * g.derefs.R == 3 * N && 2 * rows_half <= g.derefs.L;
     std::unique_ptr<RowsAhead> rows_job;
     if (ahead) rows_job.reset(new RowsAhead(*g.eval, derefs.p, g.derefs.R, rows_half));
     bool rows_queued = false;
