@@ -209,6 +209,8 @@ def main():
     # ONE over the real RCCL backend: how the N > 1 path is exercised on a one-GPU box beyond the gloo rehearsal
     shard = (world > 1 or bool(os.environ.get("OTTI_FORCE_SHARD"))) and not args.replicas
     lws = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
+    node_cpus = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None   # before any binding: what the CPU baseline of an N > 1 line may use
+    node_cores = usable_cores()
     bound_cpus = bind_rank_to_l3_groups(local_rank, lws) if (lws > 1 and os.environ.get("OTTI_BENCH_BIND", "1") != "0") else None
     cores_here = max(1, usable_cores() if bound_cpus else usable_cores() // lws)   # host cores of this rank (a bound rank's mask is already its share)
     conc = 0 if args.in_flight < 0 else (args.in_flight if args.in_flight > 0 else max(1, min(6, cores_here // 2)))
@@ -336,8 +338,11 @@ def main():
     barrier()
     t0 = time.perf_counter()
     stage_acc = {}
+    step_ms = []
     for _ in range(args.steps):
+        t_step = time.perf_counter()
         p = prove_once()                                       # returns after the library's stream has been synchronised
+        step_ms.append(1e3 * (time.perf_counter() - t_step))
         proofs.append(p)
         for k, v in p.stage_ms.items():
             stage_acc[k] = stage_acc.get(k, 0.0) + v
@@ -451,6 +456,8 @@ def main():
     def cpu_oracle_nizk(cr, cores):
         """one NIZK::prove (+ verify) of the instance by the plain-C oracle on `cores` host threads: (proof, seconds, stage ms, prove + verify ms)"""
         ci, cg = orc.OInstance(cr["num_cons"], cr["num_vars"], cr["num_inputs"], cr["A"], cr["B"], cr["C"]), orc.OGens(cr["num_cons"], cr["num_vars"], cr["num_inputs"])
+        if lws > 1 and bound_cpus and node_cpus:
+            os.sched_setaffinity(0, node_cpus)                  # the OpenMP team is created below, by a thread that may run anywhere on the node
         orc.set_threads(cores)
         tiny = oa.synth_r1cs(256, ni, 1)
         orc.nizk_prove(orc.OInstance(256, 256, ni, tiny["A"], tiny["B"], tiny["C"]), tiny["vars"], tiny["inputs"], orc.OGens(256, 256, ni))   # spin up the OpenMP team
@@ -459,9 +466,14 @@ def main():
         ct = time.perf_counter() - t0_
         t0_ = time.perf_counter()
         assert orc.nizk_verify(ci, cr["inputs"], cg, cp) == 0
-        return cp, ct, cms, 1e3 * (ct + time.perf_counter() - t0_)
+        te = 1e3 * (ct + time.perf_counter() - t0_)
+        if lws > 1 and bound_cpus and node_cpus:
+            os.sched_setaffinity(0, bound_cpus)
+        return cp, ct, cms, te
 
-    cpu_cores = int(os.environ.get("OTTI_CPU_THREADS", min(usable_cores(), 16)))   # a 1-GPU box's CPU share is 16 cores
+    # N = 1: the box's CPU share (16 cores for one GPU).  N > 1: north_star wants the reference "on the node's own host cores" — every core
+    # the launcher's process may use (rank 0 steps out of its L3 binding for that leg; the other ranks are idle at their barrier by then)
+    cpu_cores = int(os.environ.get("OTTI_CPU_THREADS", min(usable_cores(), 16) if lws == 1 else node_cores))
 
     # ---- extra: the other sizes of BASELINE.json's range, sharded like the headline when N > 1 (collective: every rank takes part)
     sweep = None
@@ -774,6 +786,11 @@ def main():
     out = {
         "metric": "R1CS constraints/sec proved (Spartan NIZK) at 2^%d" % lg, "value": round(value, 1), "unit": "constraints/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+        # scalars a reader of a truncated record wants early: the slowest timed step beside the mean, and SNARK mode's figure (details in `snark`)
+        "ms_per_step_p50": round(sorted(step_ms)[len(step_ms) // 2], 3), "ms_per_step_p99": round(sorted(step_ms)[min(len(step_ms) - 1, (99 * len(step_ms)) // 100)], 3),
+        "ms_per_step_max": round(max(step_ms), 3),
+        "snark_ms_per_proof": (snark or {}).get("ms_per_proof") if world == 1 else (snark_multi or {}).get("ms_per_proof"),
+        "snark_value": (snark or {}).get("value") if world == 1 else (snark_multi or {}).get("value"),
         "scaling": "weak" if (world == 1 or not shard) else "strong", "vs_baseline": None, "dtype": "u256 (GF(l) / GF(2^255-19), 8 x u32 limbs)", "data": "synthetic",
         "config": {"workload": (f"synthetic satisfiable R1CS, 2^{lg} constraints = variables, 10 inputs, 1 nnz/row/matrix, uniform GF(l) witness "
                                 if args.dist == "uniform" else

@@ -8,6 +8,12 @@
  *                                           that NIZK::prove reports "no device" cleanly when there is none, and verifies the proof
  *                                           file (made by the CPU oracle in the test) plus a tampered copy
  *   otti_caller prove <log2 n> <proof-out>  needs the MI355X: prove (seeded), verify, reject a tampered copy, write the proof
+ *
+ * SNARK mode — what upstream spartan-zkinterface runs WITHOUT --nizk: SNARKGens::new, SNARK::encode, SNARK::prove, SNARK::verify:
+ *   otti_caller snark-host <comm-in> <proof-in>          no GPU needed: ComputationCommitment from bytes, SNARK::verify of a proof made
+ *                                                        elsewhere (the CPU oracle's, in the test), a tampered copy, another label
+ *   otti_caller snark <log2 n> <comm-out> <proof-out>    needs the MI355X: encode, prove (seeded), verify with the verifier's copy of the
+ *                                                        commitment (bytes only), reject a tampered proof, write commitment and proof
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -53,6 +59,26 @@ static ProofVerifyError NIZK_verify(const NIZK *p, const Instance *I, const Assi
     return rc == 0 ? VERIFY_OK : rc == OTTI_ERR_VERIFY_DECOMPRESS ? DecompressionError : InternalError;
 }
 
+/* ---- SNARK mode: upstream lib.rs SNARKGens / ComputationCommitment (+ ComputationDecommitment) / SNARK */
+typedef struct { otti_snark_gens *h; } SNARKGens;
+typedef struct { otti_comp_comm *h; } ComputationCommitment;           /* made by encode: carries the decommitment SNARK::prove needs */
+typedef NIZK SNARK;
+static int SNARKGens_new(size_t nc, size_t nv, size_t ni, size_t num_nz_entries, SNARKGens *out) { return otti_snark_gens_new(nc, nv, ni, num_nz_entries, &out->h); }
+/* let (comm, decomm) = SNARK::encode(&inst, &gens); */
+static int SNARK_encode(const Instance *I, const SNARKGens *g, ComputationCommitment *out) { return otti_snark_encode(I->h, g->h, &out->h); }
+static int ComputationCommitment_from_bytes(const uint8_t *b, size_t n, ComputationCommitment *out) { return otti_comp_comm_from_bytes(b, n, &out->h); }
+/* SNARK::prove(&inst, &comm, &decomm, vars, &inputs, &gens, &mut Transcript::new(label)) */
+static int SNARK_prove(const Instance *I, const ComputationCommitment *comm, const Assignment *vars, const Assignment *inputs, const SNARKGens *g, const char *label,
+                       const uint8_t *seed32, SNARK *out) {
+    return otti_snark_prove(I->h, comm->h, (const uint8_t *)vars->bytes, vars->n, (const uint8_t *)inputs->bytes, inputs->n, g->h, (const uint8_t *)label, strlen(label),
+                            seed32, OTTI_FLAG_GPU, &out->bytes, &out->len, NULL);
+}
+/* proof.verify(&comm, &inputs, &mut Transcript::new(label), &gens): the commitment's bytes are all the verifier holds of the circuit */
+static ProofVerifyError SNARK_verify(const SNARK *p, const ComputationCommitment *comm, const Assignment *inputs, const char *label, const SNARKGens *g) {
+    int32_t rc = otti_snark_verify(comm->h, (const uint8_t *)inputs->bytes, inputs->n, g->h, (const uint8_t *)label, strlen(label), p->bytes, p->len);
+    return rc == 0 ? VERIFY_OK : rc == OTTI_ERR_VERIFY_DECOMPRESS ? DecompressionError : InternalError;
+}
+
 #define CHECK(cond, what) do { if (!(cond)) { char m[256]; last_error(m, sizeof m); fprintf(stderr, "otti_caller: %s (%s)\n", what, m); return 1; } } while (0)
 
 static int load_file(const char *path, NIZK *p) {
@@ -62,8 +88,58 @@ static int load_file(const char *path, NIZK *p) {
     int ok = fread(p->bytes, 1, p->len, f) == p->len; fclose(f); return ok;
 }
 
+static int write_file(const char *path, const uint8_t *b, size_t n) { FILE *f = fopen(path, "wb"); if (!f) return 0; int ok = fwrite(b, 1, n, f) == n; fclose(f); return ok; }
+
+/* `snark-host <comm> <proof>` and `snark <log2 n> <comm-out> <proof-out>` */
+static int snark_main(int argc, char **argv) {
+    const int host_only = !strcmp(argv[1], "snark-host");
+    if (argc < (host_only ? 4 : 5)) { fprintf(stderr, "usage: otti_caller snark-host <comm-in> <proof-in> | snark <log2 n> <comm-out> <proof-out>\n"); return 2; }
+    const size_t n = host_only ? 256 : (size_t)1 << atoi(argv[2]), ni = 10;
+    const char *label = "snark_example";
+    uint8_t seed[32]; memset(seed, 0x2a, 32);
+    otti_r1cs *r = NULL;
+    CHECK(otti_synth_r1cs(n, ni, 1, &r) == 0, "synthetic instance");
+    Instance inst; SNARKGens gens; Assignment vars, inputs;
+    CHECK(Instance_new(r->num_cons, r->num_vars, r->num_inputs, r->A, r->nA, r->B, r->nB, r->C, r->nC, &inst) == R1CS_OK, "Instance::new");
+    CHECK(Assignment_new((const uint8_t (*)[32])r->vars32, r->nvars, &vars) == R1CS_OK, "VarsAssignment::new");
+    CHECK(Assignment_new((const uint8_t (*)[32])r->inputs32, r->ninputs, &inputs) == R1CS_OK, "InputsAssignment::new");
+    size_t nz = r->nA > r->nB ? r->nA : r->nB; if (r->nC > nz) nz = r->nC;             /* what spartan-zkinterface passes: the largest matrix */
+    CHECK(SNARKGens_new(r->num_cons, r->num_vars, r->num_inputs, nz, &gens) == 0, "SNARKGens::new");
+    SNARK proof = {0, 0}; NIZK comm_bytes = {0, 0}; ComputationCommitment verifier_comm;
+    if (host_only) {
+        if (otti_device_count() == 0) {
+            ComputationCommitment none; CHECK(SNARK_encode(&inst, &gens, &none) == OTTI_ERR_NO_DEVICE, "SNARK::encode without a device must return OTTI_ERR_NO_DEVICE (no CPU fallback)");
+        }
+        CHECK(load_file(argv[2], &comm_bytes) && load_file(argv[3], &proof), "commitment / proof file");
+    } else {
+        ComputationCommitment comm;
+        CHECK(SNARK_encode(&inst, &gens, &comm) == 0, "SNARK::encode");
+        CHECK(otti_comp_comm_bytes(comm.h, &comm_bytes.bytes, &comm_bytes.len) == 0, "commitment bytes");
+        CHECK(SNARK_prove(&inst, &comm, &vars, &inputs, &gens, label, seed, &proof) == 0, "SNARK::prove");
+        CHECK(write_file(argv[3], comm_bytes.bytes, comm_bytes.len) && write_file(argv[4], proof.bytes, proof.len), "write commitment / proof");
+        otti_comp_comm_free(comm.h);
+    }
+    CHECK(ComputationCommitment_from_bytes(comm_bytes.bytes, comm_bytes.len, &verifier_comm) == 0, "ComputationCommitment from bytes");
+    CHECK(SNARK_verify(&proof, &verifier_comm, &inputs, label, &gens) == VERIFY_OK, "SNARK::verify");
+    CHECK(SNARK_verify(&proof, &verifier_comm, &inputs, "another label", &gens) != VERIFY_OK, "a different transcript label must not verify");
+    {
+        SNARK t = {malloc(proof.len), proof.len}; memcpy(t.bytes, proof.bytes, proof.len);
+        t.bytes[(2 * proof.len) / 3] ^= 0x40;
+        CHECK(SNARK_verify(&t, &verifier_comm, &inputs, label, &gens) != VERIFY_OK, "a tampered proof must not verify");
+        free(t.bytes);
+    }
+    {
+        ComputationCommitment bad; CHECK(ComputationCommitment_from_bytes(comm_bytes.bytes, comm_bytes.len / 2, &bad) != 0, "a truncated commitment must not parse");
+    }
+    printf("otti_caller ok: SNARK mode, %zu constraints, commitment %zu bytes, proof %zu bytes\n", n, comm_bytes.len, proof.len);
+    if (host_only) { free(comm_bytes.bytes); free(proof.bytes); } else { otti_buf_free(comm_bytes.bytes); otti_buf_free(proof.bytes); }
+    otti_comp_comm_free(verifier_comm.h); free(vars.bytes); free(inputs.bytes); otti_snark_gens_free(gens.h); otti_instance_free(inst.h); otti_r1cs_free(r);
+    return 0;
+}
+
 int main(int argc, char **argv) {
-    if (argc < 3) { fprintf(stderr, "usage: otti_caller host <proof-in> | prove <log2 n> <proof-out>\n"); return 2; }
+    if (argc < 3) { fprintf(stderr, "usage: otti_caller host <proof-in> | prove <log2 n> <proof-out> | snark-host <comm-in> <proof-in> | snark <log2 n> <comm-out> <proof-out>\n"); return 2; }
+    if (!strncmp(argv[1], "snark", 5)) return snark_main(argc, argv);
     const int host_only = !strcmp(argv[1], "host");
     const size_t n = host_only ? 256 : (size_t)1 << atoi(argv[2]), ni = 10;
     const char *label = "nizk_example";

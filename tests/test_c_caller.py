@@ -42,6 +42,34 @@ def test_c_caller_proves_on_the_gpu_byte_identical_to_the_oracle(caller, tmp_pat
     assert out.read_bytes() == _oracle_proof(1 << 12)
 
 
+def _oracle_snark(n):
+    r = oa.synth_r1cs(n, 10, 1)
+    nz = int(max(r["A"].size, r["B"].size, r["C"].size))
+    oi, og = orc.OInstance(n, n, 10, r["A"], r["B"], r["C"]), orc.OSnarkGens(n, n, 10, nz)
+    comm = orc.OSnarkComm.encode(oi, og)
+    return comm.bytes, orc.snark_prove(oi, comm, r["vars"], r["inputs"], og, b"snark_example", SEED)[0]
+
+
+def test_c_caller_snark_mode_host_side(caller, tmp_path):
+    """no GPU: SNARK mode through the C ABI as upstream spartan-zkinterface runs it without --nizk — the verifier's half: commitment from
+    bytes, SNARK::verify of the CPU oracle's proof, a tampered copy, another label, `no device` from SNARK::encode"""
+    cb, pb = _oracle_snark(256)
+    cf, pf = tmp_path / "c.bin", tmp_path / "p.bin"; cf.write_bytes(cb); pf.write_bytes(pb)
+    res = subprocess.run([caller, "snark-host", str(cf), str(pf)], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and "otti_caller ok: SNARK mode" in res.stdout, res.stdout + res.stderr
+
+
+@pytest.mark.gpu
+def test_c_caller_snark_mode_on_the_gpu_byte_identical_to_the_oracle(caller, tmp_path):
+    """SNARKGens::new / SNARK::encode / prove / verify from a compiled caller: commitment and proof equal the oracle's at 2^12"""
+    cf, pf = tmp_path / "c.bin", tmp_path / "p.bin"
+    res = subprocess.run([caller, "snark", "12", str(cf), str(pf)], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and "otti_caller ok: SNARK mode" in res.stdout, res.stdout + res.stderr
+    cb, pb = _oracle_snark(1 << 12)
+    assert cf.read_bytes() == cb, "computation commitment differs from the oracle's"
+    assert pf.read_bytes() == pb, "SNARK proof differs from the oracle's"
+
+
 def test_cargo_runner_drops_the_built_binary_and_forwards_the_arguments(tmp_path):
     rel = tmp_path / "target" / "release"; rel.mkdir(parents=True)
     (rel / "spzk").write_text("#!/bin/sh\necho the-rust-binary\n"); os.chmod(rel / "spzk", 0o755)
