@@ -96,6 +96,7 @@ _sig("otti_comp_comm_free", None, _vp)
 _sig("otti_snark_prove", _i32, _vp, _vp, _vp, _sz, _vp, _sz, _vp, ctypes.c_char_p, _sz, _vp, ctypes.c_uint32,
      ctypes.POINTER(_vp), ctypes.POINTER(_sz), ctypes.POINTER(ctypes.c_double))
 _sig("otti_snark_prove_resident", _i32, _vp, _vp, _vp, _vp, ctypes.c_char_p, _sz, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_sz), ctypes.POINTER(ctypes.c_double))
+_sig("otti_snark_prove_sharded", _i32, _vp, _vp, _vp, _vp, ctypes.c_char_p, _sz, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_sz), ctypes.POINTER(ctypes.c_double))
 _sig("otti_snark_verify", _i32, _vp, _vp, _sz, _vp, ctypes.c_char_p, _sz, _vp, _sz)
 _sig("otti_zkif_load", _i32, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.POINTER(_R1CS)))
 _sig("otti_zkif_write", _i32, ctypes.POINTER(_R1CS), ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p)
@@ -451,6 +452,14 @@ class SNARK:
         v, i = _scalars(vars_.assignment, "vars"), _scalars(inputs.assignment, "inputs")
         _check(lib.otti_snark_prove(inst._h, comm._h, _ptr(v), v.shape[0], _ptr(i), i.shape[0], gens._h, label, len(label), _seed(seed), 1,
                                     ctypes.byref(p), ctypes.byref(n), ms))
+        return cls(NIZK._take(p, n), dict(zip(SNARK_STAGES, ms)))
+
+    @classmethod
+    def prove_sharded(cls, inst, comm, witness, gens, transcript_label=b"snark_example", seed=None):
+        """This rank's part of ONE SNARK::prove spread over the GPUs of a node (collective over the ranks of ``shard_init``)."""
+        label = bytes(transcript_label)
+        p, n, ms = _vp(), _sz(), (ctypes.c_double * 10)()
+        _check(lib.otti_snark_prove_sharded(inst._h, comm._h, witness._h, gens._h, label, len(label), _seed(seed), ctypes.byref(p), ctypes.byref(n), ms))
         return cls(NIZK._take(p, n), dict(zip(SNARK_STAGES, ms)))
 
     def verify(self, comm, inputs, gens, transcript_label=b"snark_example"):

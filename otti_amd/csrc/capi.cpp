@@ -435,6 +435,18 @@ int32_t otti_snark_prove_resident(otti_instance *inst, otti_comp_comm *comm, ott
         *proof = to_malloc(pf, proof_len); return OTTI_OK;
     });
 }
+int32_t otti_snark_prove_sharded(otti_instance *inst, otti_comp_comm *comm, otti_witness *wit, otti_snark_gens *gens, const uint8_t *tlabel, size_t tlabel_len,
+                                 const uint8_t *seed32, uint8_t **proof, size_t *proof_len, double *stage_ms) {
+    return guarded([&] {
+        if (!inst || !comm || !wit || !gens || !proof || !proof_len) throw Error(OTTI_ERR_BAD_ARG, "null argument");
+        if (!shard_comm()) throw Error(OTTI_ERR_BAD_ARG, "otti_shard_init has not been called");
+        if (!seed32) throw Error(OTTI_ERR_BAD_ARG, "a sharded proof needs an explicit random-tape seed (the same on every rank)");
+        SnarkTimings tm{};
+        std::vector<uint8_t> pf = snark_prove_resident(*inst->I, *comm->c, *wit->w, *gens->g, tlabel, tlabel_len, seed32, &tm, shard_comm());
+        if (stage_ms) memcpy(stage_ms, tm.ms, sizeof tm.ms);
+        *proof = to_malloc(pf, proof_len); return OTTI_OK;
+    });
+}
 int32_t otti_snark_verify(const otti_comp_comm *comm, const uint8_t *inputs32, size_t ninputs, const otti_snark_gens *gens, const uint8_t *tlabel, size_t tlabel_len,
                           const uint8_t *proof, size_t proof_len) {
     return guarded([&] {

@@ -134,6 +134,7 @@ struct DevCtx {
     void ensure_points(size_t rows, size_t splits);
 };
 struct RowSumSlot { DevBuf<uint8_t> comp; DevBuf<Niels> pts; DevBuf<Fr> sc; DevBuf<Pt> out; DevBuf<unsigned> bad; bool busy = false; };
+hipStream_t bulk_masked_stream();                                    // the process's CU-masked stream for chip-filling MSM launches beside latency-bound rounds (k_context.hip); nullptr if there is none
 struct ActiveProof { ActiveProof(); ~ActiveProof(); static int count(); };       // RAII around one prove call: counts the proofs in flight in this process
 constexpr int kResultSlots = 2048;                          // 64 KB pinned: round sums, sum-check tails (SNARK: up to 18 x 3 tables x 16 elements)
 constexpr size_t kHostEncodeRows = 8;

@@ -161,6 +161,25 @@ bool DevCtx::armed_ok() const {
     const KStats &ks = KStats::get();
     return env_on && host_coherent && !(ks.on && (ks.mask & kArmedClasses)) && g_active_proofs.load(std::memory_order_relaxed) <= 1;
 }
+// ONE stream for the process confined to all but a few CUs (hipExtStreamCreateWithCUMask), for chip-filling fixed-base MSM launches that run
+// BESIDE latency-bound rounds: SNARK mode's ahead-of-time derefs rows (snark_prover.cpp), and the witness commitments while several
+// proofs are in flight (prover.cpp) — an MSM workgroup holds its CU's registers for the whole launch, and without the mask a round's
+// kernel on another stream waits for one to end (profiles/r3_cumask_probe.txt: 2 ms against 18 us; profiles/r4_inflight_*: rounds
+// of 52-84 us on average with six proofs in flight).  Made on first use and kept: creating a stream while a proof runs stalls launches.
+// OTTI_DEREFS_FREE_CUS: CUs left out of the mask (32 ... 192, default 64); OTTI_DEREFS_CUMASK=0: no masked stream (callers fall back).
+hipStream_t bulk_masked_stream() {
+    static std::once_flag once; static hipStream_t ms = nullptr;
+    std::call_once(once, [] {
+        const char *e = getenv("OTTI_DEREFS_CUMASK"), *f = getenv("OTTI_DEREFS_FREE_CUS");
+        const int free_cus = 32 * (f ? std::max(1, std::min(6, atoi(f) / 32)) : 2);
+        // the mask is cut to the device's own CU count (a partition has fewer than 256); with fewer than 128 CUs there is nothing worth setting aside
+        const int ncu = DevCtx::get().num_cu, free_words = free_cus / 32, words = (ncu + 31) / 32;
+        if ((e && e[0] == '0') || ncu < 128 || words > 8 || free_words >= words) { ms = nullptr; return; }
+        uint32_t mask[8]; for (int i = 0; i < 8; i++) mask[i] = (i < free_words || i >= words) ? 0u : (i == words - 1 && (ncu & 31)) ? ((1u << (ncu & 31)) - 1u) : 0xffffffffu;
+        if (hipExtStreamCreateWithCUMask(&ms, (uint32_t)words, mask) != hipSuccess) { (void)hipGetLastError(); ms = nullptr; }
+    });
+    return ms;
+}
 Armed DevCtx::arm() { Armed a; a.host = d_go_alias; a.dev = d_go.p; a.want = ++go_issued; a.deadline = arm_deadline; return a; }
 Armed DevCtx::arm_many(int count) { Armed a; a.host = d_go_alias; a.dev = d_go.p; a.want = go_issued + 1; a.deadline = arm_deadline; go_issued += (unsigned long long)count; return a; }
 void DevCtx::go(const Fr *v, int n) {

@@ -405,7 +405,21 @@ void r1cs_prove_device(Instance &I, DeviceWitness &wit, Gens &g, Transcript &tr,
     // ---- polycommit: DensePolynomial::commit (K8).  The witness terms of every row are summed first (no host input needed);
     // meanwhile the host draws the whole random tape (its label sequence is known in advance); the blind terms are added last.
     t0 = now_ms();
-    dev_msm_rows(c, DG, my_rows, Rsz, Rsz, Ll, nullptr, nullptr, 0, MSM_KEEP, nullptr, wit.small_fraction > kSparseWitness);
+    {
+        // several proofs in flight in this process: the chip-filling launch goes to the process's CU-masked stream, so that the other
+        // proofs' rounds (tens of workgroups each) find CUs whose registers no MSM workgroup holds; ordered against this context's
+        // stream by events on both sides (OTTI_INFLIGHT_MASK=0: as before)
+        static const bool mask_env = [] { const char *e = getenv("OTTI_INFLIGHT_MASK"); return !(e && e[0] == '0'); }();
+        hipStream_t bulk = (mask_env && !sh && ActiveProof::count() > 1) ? bulk_masked_stream() : nullptr;
+        if (bulk) {
+            hipStream_t own = c.stream;
+            OTTI_HIP(hipEventRecord(c.ev1, own)); OTTI_HIP(hipStreamWaitEvent(bulk, c.ev1, 0));
+            c.stream = bulk;
+            struct Restore { DevCtx &c; hipStream_t s; ~Restore() { c.stream = s; } } restore{c, own};
+            dev_msm_rows(c, DG, my_rows, Rsz, Rsz, Ll, nullptr, nullptr, 0, MSM_KEEP, nullptr, wit.small_fraction > kSparseWitness);
+            OTTI_HIP(hipEventRecord(c.ev1, bulk)); OTTI_HIP(hipStreamWaitEvent(own, c.ev1, 0));
+        } else dev_msm_rows(c, DG, my_rows, Rsz, Rsz, Ll, nullptr, nullptr, 0, MSM_KEEP, nullptr, wit.small_fraction > kSparseWitness);
+    }
     size_t off_sc1 = 0, off_sc2 = 0;                                  // where the two sum-checks' draws sit in the prefetched tape
     {
         std::vector<std::pair<const char *, size_t>> sched;

@@ -12,6 +12,7 @@
 #include "snark.h"
 #include <atomic>
 #include "snark_dev.h"
+#include "shard.h"
 #include "pool.h"
 #include <chrono>
 #include <functional>
@@ -136,6 +137,8 @@ std::unique_ptr<CompComm> snark_encode_gpu(Instance &I, SnarkGens &g) {
 namespace {
 // set when a persistent tail never answered (TailTimeout): the process goes on with a launch per round
 std::atomic<bool> g_tail_off{false};
+thread_local bool t_sharded_proof = false;                  // this thread is inside a sharded SNARK::prove (no persistent tail: see snark_prove_resident)
+bool shard_comm_active() { return t_sharded_proof; }
 // a batch of product circuits of one size: layer k of circuit i is (left, right) = store + off[k] + {0, n >> (k + 1)}
 struct Circuits {
     size_t n = 0, nl = 0; int count = 0;
@@ -180,7 +183,7 @@ ProductCircuitEvalProofBatched pcbatch_prove(DevCtx &c, Circuits &C, const std::
     // also take the route where the tail picks up tables that earlier launches folded in HBM)
     static const bool tail_env = [] { const char *e = getenv("OTTI_PC_TAIL"); return !(e && e[0] == '0'); }();
     static const size_t tail_cap = [] { const char *e = getenv("OTTI_PC_TAIL_CAP"); size_t v = e ? (size_t)atoi(e) : 0; return (v >= 2 && v <= (size_t)kTailCap && !(v & (v - 1))) ? v : (size_t)kTailCap; }();
-    const bool tail_ok = arm_ok && tail_env && !g_tail_off.load(std::memory_order_relaxed);
+    const bool tail_ok = arm_ok && tail_env && !g_tail_off.load(std::memory_order_relaxed) && !shard_comm_active();
     // its grid (W workgroups per instance, one per CU: 96 KB of LDS each) must be resident as a whole: never more workgroups than the device has CUs
     const int tail_groups_max = std::min(kTailMaxGroups, c.num_cu);
     static const size_t lgt_env_many = [] { const char *e = getenv("OTTI_PC_LGT_MANY"); return e ? (size_t)atoi(e) : (size_t)0; }();
@@ -423,23 +426,7 @@ struct RowsAhead {
         if (err) std::rethrow_exception(err);
         return std::move(C);
     }
-    static int masked_free_cus() {                              // CUs left to the proving thread's stream, in units of 32 (measured 32 ... 128: 64 is best)
-        static const int n = [] { const char *f = getenv("OTTI_DEREFS_FREE_CUS"); return 32 * (f ? std::max(1, std::min(6, atoi(f) / 32)) : 2); }();
-        return n;
-    }
-    static hipStream_t masked_stream() {                        // ONE for the process (made on first use, kept): creating a stream while a proof is
-        static std::once_flag once; static hipStream_t ms = nullptr;   // running stalls the proving thread's launches, and helper threads lease a different pooled context each time
-        std::call_once(once, [] {
-            const char *e = getenv("OTTI_DEREFS_CUMASK");
-            // the mask is cut to the device's own CU count (a partition has fewer than 256); with fewer than 128 CUs there is nothing worth
-            // setting aside: no masked stream, and the caller does not commit ahead of time at all
-            const int ncu = DevCtx::get().num_cu, free_words = masked_free_cus() / 32, words = (ncu + 31) / 32;
-            if (ncu < 128 || words > 8 || free_words >= words) { ms = nullptr; return; }
-            uint32_t mask[8]; for (int i = 0; i < 8; i++) mask[i] = (i < free_words || i >= words) ? 0u : (i == words - 1 && (ncu & 31)) ? ((1u << (ncu & 31)) - 1u) : 0xffffffffu;
-            if (!(e && e[0] == '0') && hipExtStreamCreateWithCUMask(&ms, (uint32_t)words, mask) != hipSuccess) { (void)hipGetLastError(); ms = nullptr; }
-        });
-        return ms;
-    }
+    static hipStream_t masked_stream() { return bulk_masked_stream(); }   // k_context.hip: ONE CU-masked stream for the process
     void run() {
         try {
             { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return stage != 0; }); if (stage < 0) { done = true; cv.notify_all(); return; } }
@@ -474,23 +461,27 @@ std::vector<uint8_t> snark_prove_gpu(Instance &I, CompComm &comm, const uint8_t 
     return snark_prove_resident(I, comm, wit, g, tlabel, tlabel_len, seed32, tm);
 }
 static std::vector<uint8_t> snark_prove_resident_once(Instance &I, CompComm &comm, DeviceWitness &wit, SnarkGens &g, const void *tlabel, size_t tlabel_len,
-                                                      const uint8_t *seed32, SnarkTimings *tm);
+                                                      const uint8_t *seed32, SnarkTimings *tm, ShardComm *sh);
 std::vector<uint8_t> snark_prove_resident(Instance &I, CompComm &comm, DeviceWitness &wit, SnarkGens &g, const void *tlabel, size_t tlabel_len,
-                                          const uint8_t *seed32, SnarkTimings *tm) {
-    try { return snark_prove_resident_once(I, comm, wit, g, tlabel, tlabel_len, seed32, tm); }
+                                          const uint8_t *seed32, SnarkTimings *tm, ShardComm *sh) {
+    // (sharded: every rank of a node sees the same device conditions or none does — a rank that alone repeated its proof would leave the
+    // others waiting in the exchange — so the persistent tail, which can time out, is not used at all there)
+    if (sh) return snark_prove_resident_once(I, comm, wit, g, tlabel, tlabel_len, seed32, tm, sh);
+    try { return snark_prove_resident_once(I, comm, wit, g, tlabel, tlabel_len, seed32, tm, nullptr); }
     catch (const TailTimeout &e) {
         // the persistent tail's grid was not resident as a whole (the GPU is shared, partitioned or CU-masked): a proof is a function of its
         // inputs and the tape seed, so proving again — with a launch per round from now on — gives the bytes the first attempt would have given
         if (g_tail_off.exchange(true)) throw;
         fprintf(stderr, "[otti] notice: %s; SNARK::prove repeats the proof with one launch per sum-check round, and this process keeps doing so\n", e.what());
-        return snark_prove_resident_once(I, comm, wit, g, tlabel, tlabel_len, seed32, tm);
+        return snark_prove_resident_once(I, comm, wit, g, tlabel, tlabel_len, seed32, tm, nullptr);
     }
 }
 static std::vector<uint8_t> snark_prove_resident_once(Instance &I, CompComm &comm, DeviceWitness &wit, SnarkGens &g, const void *tlabel, size_t tlabel_len,
-                                                      const uint8_t *seed32, SnarkTimings *tm) {
+                                                      const uint8_t *seed32, SnarkTimings *tm, ShardComm *sh) {
     DevCtx &c = DevCtx::get();
     ActiveProof active;
     SpinPool::Session pool_session;
+    struct Sharded { bool was; explicit Sharded(bool on) : was(t_sharded_proof) { t_sharded_proof = on; } ~Sharded() { t_sharded_proof = was; } } sharded_scope(sh != nullptr);
     if (!comm.dec) throw Error(OTTI_ERR_BAD_ARG, "this computation commitment carries no decommitment (it was parsed from bytes): SNARK::prove needs the one SNARK::encode returned");
     if (I.num_cons != comm.num_cons || I.num_vars != comm.num_vars || I.num_inputs != comm.num_inputs) throw Error(OTTI_ERR_BAD_ARG, "commitment belongs to another instance");
     const double t_start = now_ms(); SnarkTimings T{}; double t0;
@@ -519,7 +510,7 @@ static std::vector<uint8_t> snark_prove_resident_once(Instance &I, CompComm &com
     // of the derefs commitment on the helper's stream (RowsAhead above); the column side follows after the R1CS proof
     const size_t rows_half = g.derefs.R ? 3 * N / g.derefs.R : 0;
     static const bool ahead_env = [] { const char *e = getenv("OTTI_DEREFS_AHEAD"); return !(e && e[0] == '0'); }();
-    const bool ahead = ahead_env && c.armed_ok() && c.num_cu >= 128 && N >= ((size_t)1 << 14) && rows_half >= 64 && rows_half * g.derefs.R == 3 * N && 2 * rows_half <= g.derefs.L;
+    const bool ahead = !sh && ahead_env && c.armed_ok() && c.num_cu >= 128 && N >= ((size_t)1 << 14) && rows_half >= 64 && rows_half * g.derefs.R == 3 * N && 2 * rows_half <= g.derefs.L;
     std::unique_ptr<RowsAhead> rows_job;
     if (ahead) rows_job.reset(new RowsAhead(*g.eval, derefs.p, g.derefs.R, rows_half));
     bool rows_queued = false;
@@ -533,7 +524,7 @@ static std::vector<uint8_t> snark_prove_resident_once(Instance &I, CompComm &com
     // the helper starts once the second sum-check is past its bandwidth-bound rounds: those want the whole chip (confined to the CUs the
     // helper leaves free they took 3.2 ms instead of 0.75), the short rounds after them and the evaluation proof do not
     R1csHooks hooks; hooks.on_rx = queue_rows; hooks.on_idle = [&] { if (rows_job) rows_job->release(); };
-    { ProveTimings pt{}; r1cs_prove_device(I, wit, *g.sat, tr, tape, S.r1cs, pt, nullptr, ahead ? &hooks : nullptr); for (int k = 0; k < 6; k++) T.ms[k] = pt.ms[k]; }
+    { ProveTimings pt{}; r1cs_prove_device(I, wit, *g.sat, tr, tape, S.r1cs, pt, sh, ahead ? &hooks : nullptr); for (int k = 0; k < 6; k++) T.ms[k] = pt.ms[k]; }
     lap("r1cs proof");
     // inst.evaluate(rx, ry) is not computed by a sparse product of its own: M(rx, ry) = sum_i val_i eq(rx)[row_i] eq(ry)[col_i] is exactly
     // the dot product of the dereferenced vectors the evaluation proof needs anyway (its two halves are E.dotp_left / dotp_right below),
@@ -573,6 +564,25 @@ static std::vector<uint8_t> snark_prove_resident_once(Instance &I, CompComm &com
         const std::vector<CPoint> head = rows_job->take();
         memcpy(E.comm_derefs[0].b, head[0].b, 32 * rows_half);
         rows_job.reset();
+    } else if (sh && sh->world() > 1) {
+        // one proof over several GPUs: the commitment's rows are independent MSMs over the same generators, so every rank sums a block of
+        // them and the 32-byte results are gathered (rank order = row order), as the witness commitment of the R1CS proof is.  Only the
+        // rows that can be non-zero are dealt out (the polynomial ends in 2 N zeros: their rows are the identity, 32 zero bytes).
+        const size_t Lr = g.derefs.L, Rr = g.derefs.R, nzr = std::min(Lr, (6 * N + Rr - 1) / Rr), world = (size_t)sh->world();
+        const size_t per = (nzr + world - 1) / world, r0 = std::min(nzr, per * (size_t)sh->rank()), mine = std::min(per, nzr - r0);
+        if (per * 32 > ShardComm::kSlotBytes) throw Error(OTTI_ERR_BAD_ARG, "derefs commitment: too many rows per rank for the exchange");
+        ensure_gens_device(*g.eval);
+        std::vector<CPoint> block(per); for (auto &z : block) memset(z.b, 0, 32);
+        if (mine) {
+            dev_msm_rows(c, *g.eval->dev, derefs.p + r0 * Rr, Rr, Rr, mine, nullptr, nullptr, 0, MSM_COMPRESSED, nullptr, false);
+            c.sync();
+            memcpy(block[0].b, c.h_points, 32 * mine);
+        }
+        std::vector<CPoint> all(per * world);
+        sh->allgather(block.data(), per * 32, all.data());
+        E.comm_derefs.assign(Lr, CPoint{});
+        for (auto &z : E.comm_derefs) memset(z.b, 0, 32);
+        memcpy(E.comm_derefs[0].b, all[0].b, 32 * nzr);              // rank k's block starts at row k * per: contiguous up to nzr
     } else E.comm_derefs = commit_poly(c, *g.eval, derefs.p, g.derefs, 0);      // values of eq tables: uniform field elements
     tr.append_message("derefs_commitment", "begin_derefs_commitment", 23);
     append_poly_commitment(tr, "comm_poly_row_col_ops_val", E.comm_derefs);

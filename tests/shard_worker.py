@@ -1,6 +1,7 @@
 """One rank of a sharded proof (tests/test_gpu_shard.py and tests/test_shard_cpu.py start several of these as child processes).
 usage: shard_worker.py exchange <segment> <rank> <world> <out.npz>
-       shard_worker.py prove    <segment> <rank> <world> <out.bin> <log2 n> <uniform|compiler> <num_inputs>"""
+       shard_worker.py prove    <segment> <rank> <world> <out.bin> <log2 n> <uniform|compiler> <num_inputs>
+       shard_worker.py snark    <segment> <rank> <world> <out.bin> <log2 n> <uniform|compiler> <num_inputs>   (SNARK mode: commitment bytes + proof bytes)"""
 import os
 import sys
 import numpy as np
@@ -58,9 +59,25 @@ def prove(seg, rank, world, out, lg, dist, ni):
     open(out, "wb").write(pf.bytes)
 
 
+def snark(seg, rank, world, out, lg, dist, ni):
+    r = make_r1cs(lg, dist, ni)
+    nz = int(max(r["A"].size, r["B"].size, r["C"].size))
+    inst = oa.Instance.new(r["num_cons"], r["num_vars"], r["num_inputs"], r["A"], r["B"], r["C"])
+    gens = oa.SNARKGens.new(r["num_cons"], r["num_vars"], r["num_inputs"], nz)
+    comm = oa.ComputationCommitment.encode(inst, gens)          # every rank encodes (once per circuit; the verifier's bytes are the same everywhere)
+    wit = oa.Witness(inst, oa.VarsAssignment.new(r["vars"]), oa.InputsAssignment.new(r["inputs"]))
+    oa.shard_init(seg, rank, world)
+    for _ in range(2):
+        pf = oa.SNARK.prove_sharded(inst, comm, wit, gens, LABEL, SEED)
+    oa.shard_finalize()
+    open(out, "wb").write(len(comm.bytes).to_bytes(8, "little") + comm.bytes + pf.bytes)
+
+
 if __name__ == "__main__":
     mode, seg, rank, world, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
     if mode == "exchange":
         exchange(seg, rank, world, out)
+    elif mode == "snark":
+        snark(seg, rank, world, out, int(sys.argv[6]), sys.argv[7], int(sys.argv[8]))
     else:
         prove(seg, rank, world, out, int(sys.argv[6]), sys.argv[7], int(sys.argv[8]))

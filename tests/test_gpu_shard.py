@@ -48,6 +48,40 @@ def test_sharded_proof_is_byte_identical(tmp_path, world, lg, dist, ni):
         assert got == single, "rank %d of %d returned different proof bytes" % (r, world)
 
 
+@pytest.mark.parametrize("world,lg,dist,ni", [(2, 10, "uniform", 4), (4, 12, "uniform", 10), (4, 11, "compiler", 3), (2, 6, "uniform", 2)])
+def test_sharded_snark_proof_is_byte_identical(tmp_path, world, lg, dist, ni):
+    """SNARK mode over g rank processes (sharing the box's one card): the R1CS part sharded as in NIZK mode, the rows of the derefs commitment
+    dealt out over the ranks and gathered; commitment and proof bytes of every rank equal the single-GPU prover's and the CPU oracle's."""
+    from shard_worker import make_r1cs
+    r = make_r1cs(lg, dist, ni)
+    nz = int(max(r["A"].size, r["B"].size, r["C"].size))
+    inst = oa.Instance.new(r["num_cons"], r["num_vars"], r["num_inputs"], r["A"], r["B"], r["C"])
+    gens = oa.SNARKGens.new(r["num_cons"], r["num_vars"], r["num_inputs"], nz)
+    comm = oa.ComputationCommitment.encode(inst, gens)
+    inputs = oa.InputsAssignment.new(r["inputs"])
+    single = oa.SNARK.prove(inst, comm, oa.VarsAssignment.new(r["vars"]), inputs, gens, LABEL, SEED)
+    single.verify(oa.ComputationCommitment.from_bytes(comm.bytes), inputs, gens, LABEL)
+    oi, og = orc.OInstance(r["num_cons"], r["num_vars"], r["num_inputs"], r["A"], r["B"], r["C"]), orc.OSnarkGens(r["num_cons"], r["num_vars"], r["num_inputs"], nz)
+    oc = orc.OSnarkComm.encode(oi, og)
+    assert oc.bytes == comm.bytes
+    assert orc.snark_prove(oi, oc, r["vars"], r["inputs"], og, LABEL, SEED)[0] == single.bytes
+    seg = "otti-test-" + uuid.uuid4().hex
+    env_dev = os.environ.get("OTTI_DEVICE")
+    os.environ["OTTI_DEVICE"] = "0"
+    try:
+        run_ranks(lambda k: ["snark", seg, str(k), str(world), str(tmp_path / ("s%d.bin" % k)), str(lg), dist, str(ni)], world, timeout=900)
+    finally:
+        if env_dev is None:
+            os.environ.pop("OTTI_DEVICE")
+        else:
+            os.environ["OTTI_DEVICE"] = env_dev
+    for k in range(world):
+        got = open(tmp_path / ("s%d.bin" % k), "rb").read()
+        nc = int.from_bytes(got[:8], "little")
+        assert got[8:8 + nc] == comm.bytes, "rank %d of %d: another computation commitment" % (k, world)
+        assert got[8 + nc:] == single.bytes, "rank %d of %d returned different SNARK proof bytes" % (k, world)
+
+
 def test_too_many_ranks_for_the_instance_is_refused():
     r = oa.synth_r1cs(4, 1, 5)                                                      # 2 x 2 witness matrix: cannot give 4 ranks a row each
     inst = oa.Instance.new(r["num_cons"], r["num_vars"], r["num_inputs"], r["A"], r["B"], r["C"])
