@@ -55,7 +55,8 @@ struct DeviceGens {
 };
 
 // where a sum-check kernel's last workgroup delivers the round's totals (see finish_in_kernel)
-struct Mailbox { Fr *partials; unsigned *counter; Fr *host_results; unsigned long long *host_flag; unsigned long long seq; int slot; };
+struct Mailbox { Fr *partials; unsigned *counter; Fr *host_results; unsigned long long *host_flag; unsigned long long seq; int slot;
+                 Fr *dev_results; };   // dev_results: the totals once more in HBM (same slots), for a device-side collective over them (shard.h, RCCL transport)
 
 // Armed launches.  The sequential rounds cost a launch + dispatch (10-15 us) on top of the kernel itself when the kernel can only be
 // launched once the host knows the round's challenge.  An ARMED kernel is queued before that: its first workgroup spins on a pinned host
@@ -257,6 +258,8 @@ unsigned long long dev_bullet_round(DevCtx &c, const DeviceGens &g, size_t R, si
 void dev_decode_niels(DevCtx &c, const uint8_t *compressed_dev, size_t n, Niels *out, unsigned *bad);
 int dev_msm_var(DevCtx &c, const Niels *pts, const Fr *scalars, size_t n, Pt *out, size_t out_cap, int *n_windows, int *n_splits);
 double dev_madd_peak(DevCtx &c);                                          // mixed point additions per second, whole chip (the MSM's ALU roof)
+// v[i] (times *factor when given: a device-resident scalar is not needed, it travels by value) as 8 u32 limbs widened to u64 lanes, on `st`
+void dev_fr_to_lanes(hipStream_t st, const Fr *d_src, const Fr *factor, unsigned long long *d_lanes, size_t n);
 double dev_fr_mul_peak(DevCtx &c);                                        // Montgomery products in GF(l) per second, whole chip (the streaming kernels' second roof)
 void dev_scale(DevCtx &c, const Fr *in, const Fr &k, Fr *out, size_t n);
 void dev_fill_one(DevCtx &c, Fr *p, size_t n);

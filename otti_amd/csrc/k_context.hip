@@ -148,7 +148,7 @@ void KStats::reset() { used = 0; for (int k = 0; k < KC_COUNT; k++) { total_ms[k
 
 Mailbox DevCtx::next_mailbox(int slot) {
     Mailbox mb; mb.partials = partials.p; mb.counter = d_counter.p; mb.host_results = d_results_alias; mb.host_flag = d_flag_alias;
-    mb.seq = ++seq; mb.slot = slot; return mb;
+    mb.seq = ++seq; mb.slot = slot; mb.dev_results = results.p; return mb;
 }
 static std::atomic<int> g_active_proofs{0};
 ActiveProof::ActiveProof() { g_active_proofs.fetch_add(1, std::memory_order_relaxed); }
@@ -160,6 +160,17 @@ bool DevCtx::armed_ok() const {
     static const bool env_on = [] { const char *e = getenv("OTTI_ARMED"); return !(e && e[0] == '0'); }();
     const KStats &ks = KStats::get();
     return env_on && host_coherent && !(ks.on && (ks.mask & kArmedClasses)) && g_active_proofs.load(std::memory_order_relaxed) <= 1;
+}
+// the per-round sums of a sharded proof for the RCCL transport: packed into u64 lanes where they were produced (no host pack, no upload)
+__global__ void k_fr_to_lanes(const Fr *src, Fr factor, int scale, unsigned long long *lanes, size_t n) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fr v = src[i]; if (scale) v = fr_mul(v, factor);
+    for (int k = 0; k < 8; k++) lanes[8 * i + k] = v.v[k];
+}
+void dev_fr_to_lanes(hipStream_t st, const Fr *d_src, const Fr *factor, unsigned long long *d_lanes, size_t n) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_fr_to_lanes, (unsigned)((n + 63) / 64), 64, 0, st, d_src, factor ? *factor : fr_zero(), factor ? 1 : 0, d_lanes, n);
 }
 // ONE stream for the process confined to all but a few CUs (hipExtStreamCreateWithCUMask), for chip-filling fixed-base MSM launches that run
 // BESIDE latency-bound rounds: SNARK mode's ahead-of-time derefs rows (snark_prover.cpp), and the witness commitments while several

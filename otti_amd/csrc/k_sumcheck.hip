@@ -71,7 +71,7 @@ template <int K, int kPost = POST_NONE> __device__ __forceinline__ void finish_i
     }
     if (threadIdx.x == 0) {
         if constexpr (kPost == POST_CUBIC3) { static_assert(K == 3, "three totals"); quadratic_to_023(acc); }
-        for (int k = 0; k < K; k++) mb.host_results[mb.slot + k] = acc[k];
+        for (int k = 0; k < K; k++) { mb.dev_results[mb.slot + k] = acc[k]; mb.host_results[mb.slot + k] = acc[k]; }
         __threadfence_system();
         __hip_atomic_store(mb.host_flag, mb.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }

@@ -537,7 +537,8 @@ void r1cs_prove_device(Instance &I, DeviceWitness &wit, Gens &g, Transcript &tr,
             if (j < dsum) {
                 c.wait_ticket(tk[j]);
                 e[0] = c.h_results[0]; e[1] = c.h_results[1]; e[2] = c.h_results[2];       // S_t = sum_i E_j[i] (Az_t Bz_t - Cz_t)[i], t = 0, 2, 3
-                if (sh) { for (auto &x : e) x = fr_mul(x, eq_ranks[rk]); sh->allreduce_fr(e, 3); }   // per-round exchange: 96 bytes per rank
+                // per-round exchange: 96 bytes per rank (RCCL transport: the sums are packed into lanes, scaled, where the kernel left them in HBM)
+                if (sh) { for (auto &x : e) x = fr_mul(x, eq_ranks[rk]); sh->allreduce_fr_device(c.results.p, &eq_ranks[rk], e, 3); }
                 // e_t = c_j * w_t * S_t with w_t = (1 - tau_j) + t (2 tau_j - 1): the eq factor of the variable bound in this round
                 const Fr w0 = fr_sub(one, tau[j]), dw = fr_sub(fr_add(tau[j], tau[j]), one), w2 = fr_add(w0, fr_add(dw, dw)), w3 = fr_add(w2, dw);
                 e[0] = fr_mul(fr_mul(cj, w0), e[0]); e[1] = fr_mul(fr_mul(cj, w2), e[1]); e[2] = fr_mul(fr_mul(cj, w3), e[2]);
@@ -643,7 +644,7 @@ void r1cs_prove_device(Instance &I, DeviceWitness &wit, Gens &g, Transcript &tr,
             if (j < dsum) {
                 c.wait_ticket(tk[j]);
                 e[0] = c.h_results[0]; e[1] = c.h_results[1];
-                if (sh) sh->allreduce_fr(e, 2);
+                if (sh) sh->allreduce_fr_device(c.results.p, nullptr, e, 2);
             } else host_quad_evals(tail2, e);
             Fr ev[3] = {e[0], fr_sub(st.claim, e[0]), e[1]};
             RoundPart1 p1 = sumcheck_round_begin(P.sc2, j, ev, 3, st, g, g.sc_3, tr);

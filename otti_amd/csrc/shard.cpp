@@ -81,6 +81,14 @@ struct ShardComm::Rccl {
         OTTI_HIP(hipStreamSynchronize(stream));
         lanes_to_fr(h_lanes, n, v);
     }
+    void allreduce_device(const Fr *d_src, const Fr *factor, Fr *v, size_t n) {
+        reserve(8 * n);
+        dev_fr_to_lanes(stream, d_src, factor, (unsigned long long *)d_lanes, n);
+        check(AllReduce(d_lanes, d_lanes, 8 * n, ncclUint64, ncclSum, comm, stream), "ncclAllReduce");
+        OTTI_HIP(hipMemcpyAsync(h_lanes, d_lanes, 64 * n, hipMemcpyDeviceToHost, stream));
+        OTTI_HIP(hipStreamSynchronize(stream));
+        lanes_to_fr(h_lanes, n, v);
+    }
     ~Rccl() {
         if (comm && CommDestroy) (void)CommDestroy(comm);
         if (stream) (void)hipStreamDestroy(stream);
@@ -160,6 +168,10 @@ void ShardComm::allgather(const void *mine, size_t n, void *out) {
 void ShardComm::allreduce_fr(Fr *v, size_t n) {
     if (rccl_) { rccl_->allreduce(v, n); return; }                      // also with a world of one: the path is exercised on a one-GPU box
     allreduce_mailbox(v, n);
+}
+void ShardComm::allreduce_fr_device(const Fr *d_src, const Fr *factor, Fr *v, size_t n) {
+    if (rccl_ && d_src) { rccl_->allreduce_device(d_src, factor, v, n); return; }
+    allreduce_fr(v, n);                                                  // v: the host copy, already multiplied by the caller
 }
 void ShardComm::allreduce_mailbox(Fr *v, size_t n) {
     if (world_ == 1) return;

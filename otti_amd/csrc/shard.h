@@ -27,6 +27,10 @@ public:
     void allgather(const void *mine, size_t n, void *out);
     // v[i] <- sum over ranks of v[i]  (exact arithmetic in GF(l): the order of summation cannot change the result)
     void allreduce_fr(Fr *v, size_t n);
+    // the same for values a kernel has just left in HBM (d_src, complete: the caller has seen the kernel's result), each times *factor when
+    // given: with the RCCL transport they are packed into lanes on the device and reduced from there — no host pack, no upload, one
+    // download of the result; with the mailbox the host copy in v (already multiplied by the caller) is exchanged as always
+    void allreduce_fr_device(const Fr *d_src, const Fr *factor, Fr *v, size_t n);
     void barrier() { uint8_t b = 0, all[64]; allgather(&b, 1, all); }
     static constexpr size_t kSlotBytes = (size_t)1 << 20;
     static constexpr int kMaxWorld = 64;

@@ -44,8 +44,11 @@ def test_two_rank_rehearsal_of_the_drivers_command(tmp_path):
     line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1]
     d = json.loads(line)
     _check_sharded_line(d, 2)
-    sn = d["snark"]                                                      # SNARK mode at N > 1: one independent proof per rank, checked against the committed digest
-    assert sn and "error" not in sn and sn["value"] > 0 and sn["scaling"] == "weak" and sn["n_gpus"] == 2 and sn["equals_oracle_digest"] is True, sn
+    sn = d["snark"]                                                      # SNARK mode at N > 1: ONE proof sharded over the ranks (strong), the replicas figure beside it (weak); digests checked
+    assert sn and "error" not in sn and "sharded_error" not in sn and sn["value"] > 0 and sn["scaling"] == "strong" and sn["n_gpus"] == 2 and sn["equals_oracle_digest"] is True, sn
+    rp = sn["replicas"]
+    assert rp["scaling"] == "weak" and rp["value"] > 0 and rp["proof_sha256"] == sn["proof_sha256"], rp
+    assert d["snark_ms_per_proof"] == sn["ms_per_proof"] and d["ms_per_step_p99"] >= d["ms_per_step_p50"] > 0
 
 
 @pytest.mark.gpu

@@ -91,6 +91,25 @@ def test_too_many_ranks_for_the_instance_is_refused():
         oa.NIZK.prove_sharded(inst, wit, gens, LABEL, SEED)                         # no otti_shard_init
 
 
+def test_sharded_proof_over_the_rccl_transport_with_a_world_of_one(tmp_path):
+    """The per-round sums of a sharded proof through the RCCL transport's device path (allreduce_fr_device: the round kernel's totals packed into
+    u64 lanes where it left them in HBM, scaled by the rank's eq factor, ncclAllReduce, one download) — RCCL refuses two ranks on one
+    card, so a world of one: the proof must equal the unsharded one."""
+    single, oracle = _reference_proofs(10, "uniform", 4)
+    seg = "otti-test-" + uuid.uuid4().hex
+    saved = {k: os.environ.get(k) for k in ("OTTI_DEVICE", "OTTI_SHARD_TRANSPORT")}
+    os.environ["OTTI_DEVICE"] = "0"; os.environ["OTTI_SHARD_TRANSPORT"] = "rccl"
+    try:
+        run_ranks(lambda r: ["prove", seg, "0", "1", str(tmp_path / "p0.bin"), "10", "uniform", "4"], 1, timeout=500)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    assert open(tmp_path / "p0.bin", "rb").read() == single == oracle
+
+
 def test_rccl_lane_transport_of_the_round_sums_on_one_card(tmp_path):
     """OTTI_SHARD_TRANSPORT=rccl: allreduce_fr goes pack -> ncclAllReduce(ncclUint64, ncclSum) on the GPU -> normalise mod l.  RCCL
     refuses two ranks on one card, so this box can only run a world of one — which still exercises the whole path (bootstrap of the
