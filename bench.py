@@ -404,7 +404,7 @@ def main():
     # ---- extra: B independent proofs in flight per GPU, each prover thread with its own instance, witness and seed
     in_flight = None
     if conc >= 1:
-        isteps = max(2, min(args.steps, 10))
+        isteps = max(2, min(2 * args.steps, 40))              # 40 proofs per thread by default: a tenth of a second of proving said little (the figure moved by 2 x between runs)
         jobs = []
         for t in range(conc):
             if t == 0 and not shard:

@@ -67,7 +67,15 @@ inline bool enabled() { static const bool on = [] { const char *e = getenv("OTTI
 class SpinPool {
 public:
     static SpinPool &get() { thread_local SpinPool p; return p; }   // helpers belong to the prover thread that uses them
-    int workers() const { return (int)th_.size(); }
+    // helpers this prover thread may use right now: all of them while it is the process's only prover at work; with several proofs in flight
+    // on threads of their own, the cores are shared out (cores / provers - 1 each): six provers with three spinning helpers each on a 16-core
+    // share ran at 470 M constraints/s, with one helper each at 730 (tools/inflight_variants.sh, profiles/r4_inflight_variants.txt).
+    // The helpers beyond the budget stop spinning (run()).
+    int workers() const {
+        const int n = (int)th_.size(), s = cpu_place::sessions().load(std::memory_order_relaxed);
+        if (s <= 1 || fixed_) return n;
+        return std::max(0, std::min(n, (int)cores_ / s - 1));
+    }
 
     struct Session {                                  // RAII: workers spin while one is alive
         Session() { SpinPool::get().set_active(true); }
@@ -99,6 +107,7 @@ private:
     std::vector<Slot> slots_;
     std::atomic<bool> quit_{false};
     std::atomic<int> active_{0};
+    unsigned cores_ = 1; bool fixed_ = false;
     std::mutex mu_; std::condition_variable cv_;
 
     static void relax() {
@@ -121,7 +130,9 @@ private:
         }
         if (const char *e = getenv("LOCAL_WORLD_SIZE")) { int v = atoi(e); if (v > 1) hc = hc / (unsigned)v; }
         int n = hc >= 8 ? 3 : hc >= 4 ? 2 : hc >= 2 ? 1 : 0;
+        cores_ = hc ? hc : 1;
         if (const char *e = getenv("OTTI_HOST_THREADS")) { int v = atoi(e); if (v >= 1 && v <= 16) n = v - 1; }
+        if (const char *e = getenv("OTTI_HOST_THREADS_FIXED")) fixed_ = e[0] == '1';      // keep every helper whatever the number of provers at work
         slots_ = std::vector<Slot>(n > 0 ? n : 1);
         for (int i = 0; i < n; i++) th_.emplace_back([this, i] { run(i); });
     }
@@ -192,7 +203,11 @@ private:
         for (;;) {
             if (quit_.load()) return;
             if (s.state.load(std::memory_order_acquire) == 1) { s.fn(); s.state.store(2, std::memory_order_release); continue; }
-            if (active_.load(std::memory_order_relaxed) > 0) { relax(); continue; }
+            if (active_.load(std::memory_order_relaxed) > 0) {
+                if (i < workers()) relax();
+                else std::this_thread::sleep_for(std::chrono::microseconds(20));      // over the budget of a crowded process: leave the core to a prover thread
+                continue;
+            }
             std::unique_lock<std::mutex> lk(mu_);
             cv_.wait_for(lk, std::chrono::milliseconds(50), [&] { return quit_.load() || active_.load() > 0 || s.state.load() == 1; });
         }

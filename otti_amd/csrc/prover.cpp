@@ -408,8 +408,10 @@ void r1cs_prove_device(Instance &I, DeviceWitness &wit, Gens &g, Transcript &tr,
     {
         // several proofs in flight in this process: the chip-filling launch goes to the process's CU-masked stream, so that the other
         // proofs' rounds (tens of workgroups each) find CUs whose registers no MSM workgroup holds; ordered against this context's
-        // stream by events on both sides (OTTI_INFLIGHT_MASK=0: as before)
-        static const bool mask_env = [] { const char *e = getenv("OTTI_INFLIGHT_MASK"); return !(e && e[0] == '0'); }();
+        // stream by events on both sides
+        // (measured, tools/inflight_variants.sh, three runs each: 439-497 M constraints/s with the mask, 457-471 without — what held the in-flight
+        // figure down was the helper threads' spinning, pool.h — so the mask is opt-in: OTTI_INFLIGHT_MASK=1)
+        static const bool mask_env = [] { const char *e = getenv("OTTI_INFLIGHT_MASK"); return e && e[0] == '1'; }();
         hipStream_t bulk = (mask_env && !sh && ActiveProof::count() > 1) ? bulk_masked_stream() : nullptr;
         if (bulk) {
             hipStream_t own = c.stream;
