@@ -51,6 +51,51 @@ def test_cubic3_fused_fold_round(rng, n):
     assert eq(e, _cubic3_want(orc.eq_evals(tau), fb, fc, fd))
 
 
+def _edge_tables(rng, n, count):
+    """tables made of the values that sit at the ends of the nine-limb forms' ranges: 0, 1, l - 1, l - 2, 2^252, and a few random ones"""
+    l = orc.L_ORDER
+    pool = [0, 1, 2, l - 1, l - 2, 1 << 252, (1 << 252) - 1, (l - 1) // 2, (1 << 29) - 1, 1 << 29, (1 << 232) - 1, 1 << 232]
+    out = []
+    for t in range(count):
+        kind = t % 4
+        if kind == 0:
+            vals = [l - 1] * n
+        elif kind == 1:
+            vals = [pool[int(x)] for x in rng.integers(0, len(pool), n)]
+        elif kind == 2:
+            vals = [0] * n
+        else:
+            vals = [pool[int(x)] if x < len(pool) else int(rng.integers(0, 2 ** 62)) ** 4 % l for x in rng.integers(0, 2 * len(pool), n)]
+        out.append(orc.fr_from_ints(vals))
+    return out
+
+
+@pytest.mark.parametrize("n,shift", [(8, 0), (1 << 11, 1), (1 << 15, 2), (1 << 17, 3)])
+def test_round_kernels_on_values_at_the_ends_of_the_field(rng, n, shift):
+    """every round kernel of both sum-checks (three- and four-table cubic, quad; plain and fused with the fold) on tables full of l - 1, 0, 1,
+    2^252, limb-boundary values and mixtures — the nine-limb arithmetic's offsets, carries and accumulations at their extremes"""
+    l = orc.L_ORDER
+    T = _edge_tables(rng, n, 8)
+    T = T[shift:] + T[:shift]
+    A, B, C, D = T[0], T[1], T[2], T[3]
+    for r_int in (l - 1, 1, 0, int(rng.integers(0, 2 ** 62)) ** 4 % l):
+        r = orc.fr_from_ints([r_int])
+        assert eq(K.sc_cubic_round(A, B, C, D)[0], orc.sc_cubic_evals(A, B, C, D))
+        assert eq(K.sc_quad_round(A, B)[0], orc.sc_quad_evals(A, B))
+        fa, fb, fc, fd = (orc.fold_top(x, r) for x in (A, B, C, D))
+        out, e, _ = K.sc_cubic_fold_round(A, B, C, D, r)
+        assert all(eq(out[k], f) for k, f in enumerate((fa, fb, fc, fd))) and eq(e, orc.sc_cubic_evals(fa, fb, fc, fd))
+        out2, e2, _ = K.sc_quad_fold_round(A, B, r)
+        assert eq(out2[0], fa) and eq(out2[1], fb) and eq(e2, orc.sc_quad_evals(fa, fb))
+        for tau_int in (l - 1, 1):
+            tau = orc.fr_from_ints([tau_int] * (n.bit_length() - 2))
+            assert eq(K.sc_cubic3_round(B, C, D, tau)[0], _cubic3_want(orc.eq_evals(tau), B, C, D))
+            if n >= 8:
+                out3, e3, _ = K.sc_cubic3_fold_round(B, C, D, r, tau[1:])
+                assert eq(out3[0], fb) and eq(out3[1], fc) and eq(out3[2], fd) and eq(e3, _cubic3_want(orc.eq_evals(tau[1:]), fb, fc, fd))
+        A, B, C, D = B, C, D, A
+
+
 def test_cubic3_rounds_chain_like_phase_one(rng):
     """the prover's loop: evaluate, then fold+evaluate per challenge, with E_j = eq(tau[j+1:]); the scalar factors the host applies
     (c_j and the bound variable's eq factor) turn S_t into upstream's four-table sums"""
