@@ -583,7 +583,7 @@ def main():
                 replicas = snark_multi
                 if sh_err is None:
                     snark_multi = {"value": round(n / (sh_ms * 1e-3), 1), "unit": "constraints/s", "ms_per_proof": round(sh_ms, 3), "n_gpus": world, "scaling": "strong",
-                                   "parallelism": "1 SNARK::prove sharded over %d GPUs: R1CS proof as the headline, derefs commitment rows dealt out over the ranks; layered sum-checks and evaluation proofs on every rank alike" % world,
+                                   "parallelism": "1 SNARK::prove sharded over %d GPUs: R1CS proof as the headline, derefs commitment rows dealt out over the ranks, product circuits by residue classes (per-round sums over the exchange); host rounds and evaluation proofs on every rank alike" % world,
                                    "stage_ms": {k: round(v, 3) for k, v in sp_s.stage_ms.items()}, "proof_sha256": sh_dig, "equals_oracle_digest": replicas["equals_oracle_digest"],
                                    "encode_ms": replicas["encode_ms"], "replicas": replicas,
                                    "note": "ms_per_proof = best of three between barriers, max over ranks; `replicas` = the weak-scaling figure (one independent proof per GPU)"}

@@ -138,7 +138,8 @@ int32_t otti_snark_prove_resident(otti_instance *inst, otti_comp_comm *comm, ott
                                   size_t tlabel_len, const uint8_t *seed32, uint8_t **proof, size_t *proof_len, double *stage_ms);
 /* this rank's part of ONE SNARK::prove over the GPUs of a node (after otti_shard_init, like otti_nizk_prove_sharded: every rank passes the
    same instance, commitment, resident witness, generators, label and seed and receives the same proof bytes): the R1CS satisfiability proof
-   sharded as in NIZK mode, the rows of the derefs commitment dealt out over the ranks; the layered sum-checks run on every rank alike */
+   sharded as in NIZK mode, the rows of the derefs commitment dealt out over the ranks, the product circuits split by residue classes of the
+   element index (their per-round sums cross the ranks); host rounds and evaluation proofs run on every rank alike */
 int32_t otti_snark_prove_sharded(otti_instance *inst, otti_comp_comm *comm, otti_witness *wit, otti_snark_gens *gens, const uint8_t *tlabel,
                                  size_t tlabel_len, const uint8_t *seed32, uint8_t **proof, size_t *proof_len, double *stage_ms);
 int32_t otti_snark_verify(const otti_comp_comm *comm, const uint8_t *inputs32, size_t ninputs, const otti_snark_gens *gens,

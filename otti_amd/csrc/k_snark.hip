@@ -36,28 +36,38 @@ void dev_u32_to_fr(DevCtx &c, const uint32_t *in, Fr *out, size_t n) {
 __device__ __forceinline__ Fr hash3(const Fr &addr, const Fr &val, const Fr &ts, const Fr &r, const Fr &r2, const Fr &gamma) {
     return fr_sub(fr_add(fr_add(fr_mul(ts, r2), fr_mul(val, r)), addr), gamma);
 }
+// A rank's residue class of a hashed vector (sharded SNARK::prove, snark_prover.cpp): local element j of a vector of 2 * half_loc elements is
+// global element (j / half_loc) * half_glob + (j % half_loc) * G + rk — the circuit's input is its left half then its right half, and every
+// layer pairs index i with i + (side length) / 2, so both halves keep the elements with i = rk (mod G).  G = 1: the identity.
+struct ShardMap { size_t half_loc, half_glob; uint32_t G, rk; };
+__device__ __forceinline__ size_t shard_global(const ShardMap &m, size_t j) { return m.G == 1 ? j : (j / m.half_loc) * m.half_glob + (j % m.half_loc) * m.G + m.rk; }
 // memory cells: addr = the cell index, val = the eq table, ts = 0 (init) or the audit timestamp
-__global__ __launch_bounds__(kBlock) void k_hash_mem(const Fr *eval_table, const Fr *audit_ts, Fr *out_init, Fr *out_audit, size_t M, Fr r, Fr r2, Fr gamma) {
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < M; i += (size_t)gridDim.x * blockDim.x) {
+__global__ __launch_bounds__(kBlock) void k_hash_mem(const Fr *eval_table, const Fr *audit_ts, Fr *out_init, Fr *out_audit, size_t M, Fr r, Fr r2, Fr gamma, ShardMap sm) {
+    for (size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x; j < M; j += (size_t)gridDim.x * blockDim.x) {
+        const size_t i = shard_global(sm, j);
         const Fr base = fr_sub(fr_add(fr_mul(eval_table[i], r), fr_from_u64((uint64_t)i)), gamma);
-        out_init[i] = base;
-        out_audit[i] = fr_add(base, fr_mul(audit_ts[i], r2));
+        out_init[j] = base;
+        out_audit[j] = fr_add(base, fr_mul(audit_ts[i], r2));
     }
 }
 // operations: read uses the read timestamp, write the same plus one (so write = read + r^2)
-__global__ __launch_bounds__(kBlock) void k_hash_ops(const Fr *addr_f, const Fr *deref, const Fr *read_ts, Fr *out_read, Fr *out_write, size_t N, Fr r, Fr r2, Fr gamma) {
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < N; i += (size_t)gridDim.x * blockDim.x) {
+__global__ __launch_bounds__(kBlock) void k_hash_ops(const Fr *addr_f, const Fr *deref, const Fr *read_ts, Fr *out_read, Fr *out_write, size_t N, Fr r, Fr r2, Fr gamma, ShardMap sm) {
+    for (size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x; j < N; j += (size_t)gridDim.x * blockDim.x) {
+        const size_t i = shard_global(sm, j);
         const Fr rd = hash3(addr_f[i], deref[i], read_ts[i], r, r2, gamma);
-        out_read[i] = rd; out_write[i] = fr_add(rd, r2);
+        out_read[j] = rd; out_write[j] = fr_add(rd, r2);
     }
 }
-void dev_hash_mem(DevCtx &c, const Fr *eval_table, const Fr *audit_ts, Fr *out_init, Fr *out_audit, size_t M, const Fr &r, const Fr &gamma) {
+// n = the GLOBAL vector length; G ranks: this rank writes its n / G elements
+void dev_hash_mem(DevCtx &c, const Fr *eval_table, const Fr *audit_ts, Fr *out_init, Fr *out_audit, size_t M, const Fr &r, const Fr &gamma, int G, int rk) {
     KScope ks(c, KC_HASH_LAYER);
-    hipLaunchKernelGGL(k_hash_mem, grid_for(M), kBlock, 0, c.stream, eval_table, audit_ts, out_init, out_audit, M, r, fr_mul(r, r), gamma);
+    const size_t Ml = M / (size_t)G; const ShardMap sm = {std::max<size_t>(1, Ml / 2), M / 2, (uint32_t)G, (uint32_t)rk};
+    hipLaunchKernelGGL(k_hash_mem, grid_for(Ml), kBlock, 0, c.stream, eval_table, audit_ts, out_init, out_audit, Ml, r, fr_mul(r, r), gamma, sm);
 }
-void dev_hash_ops(DevCtx &c, const Fr *addr_f, const Fr *deref, const Fr *read_ts, Fr *out_read, Fr *out_write, size_t N, const Fr &r, const Fr &gamma) {
+void dev_hash_ops(DevCtx &c, const Fr *addr_f, const Fr *deref, const Fr *read_ts, Fr *out_read, Fr *out_write, size_t N, const Fr &r, const Fr &gamma, int G, int rk) {
     KScope ks(c, KC_HASH_LAYER);
-    hipLaunchKernelGGL(k_hash_ops, grid_for(N), kBlock, 0, c.stream, addr_f, deref, read_ts, out_read, out_write, N, r, fr_mul(r, r), gamma);
+    const size_t Nl = N / (size_t)G; const ShardMap sm = {std::max<size_t>(1, Nl / 2), N / 2, (uint32_t)G, (uint32_t)rk};
+    hipLaunchKernelGGL(k_hash_ops, grid_for(Nl), kBlock, 0, c.stream, addr_f, deref, read_ts, out_read, out_write, Nl, r, fr_mul(r, r), gamma, sm);
 }
 
 // one layer of every product circuit of a batch: out_left[i] = in_left[i] * in_right[i], out_right[i] = in_left[q + i] * in_right[q + i]

@@ -155,6 +155,7 @@ __device__ __forceinline__ Pair fold_regs(const Fr &x0, const Fr &x1, const Fr &
 }
 // eq table given as the tensor product of two small tables (k_eq_pyramid levels), or as one table once few variables are left
 __device__ __forceinline__ Fr eq_at(const EqSrc &e, size_t i) {
+    i = i * e.stride + e.offset;
     if (!e.hi) return e.lo[i];
     return fr_mul(e.hi[i >> e.lo_bits], e.lo[i & (((size_t)1 << e.lo_bits) - 1)]);
 }
@@ -164,6 +165,7 @@ __device__ __forceinline__ Fr eq_at(const EqSrc &e, size_t i) {
 // E[i] << S-ish: the eq factor carrying S bits of radix correction: 32 E (S = 5) or 1024 E (S = 10), below 3 l / 65 l from two factors,
 // below 2^S l from one table
 template <int S> __device__ __forceinline__ Fr9 eq_s_at(const EqSrc &e, size_t i) {
+    i = i * e.stride + e.offset;
     if (!e.hi) return fr9_unpack_s<S>(e.lo[i]);
     return fr9_mul(fr9_unpack_s<S>(e.hi[i >> e.lo_bits]), fr9_unpack5(e.lo[i & (((size_t)1 << e.lo_bits) - 1)]));
 }

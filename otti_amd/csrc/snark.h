@@ -141,8 +141,9 @@ std::vector<uint8_t> snark_prove_gpu(Instance &inst, CompComm &comm, const uint8
 struct DeviceWitness;                                        // device.h: the assignment resident in HBM (otti_witness_upload)
 class ShardComm;                                             // shard.h
 // sh != nullptr: this rank's part of ONE proof over the GPUs of a node (every rank passes the same inputs and gets the same bytes): the
-// R1CS satisfiability proof sharded as in NIZK mode, the rows of the derefs commitment split over the ranks; the layered sum-checks and
-// the evaluation proofs run on every rank alike
+// R1CS satisfiability proof sharded as in NIZK mode, the rows of the derefs commitment split over the ranks, the product circuits (hash layer,
+// product layers, the device rounds of the batched sum-checks) by residue classes of the element index; the host rounds and the evaluation
+// proofs run on every rank alike
 std::vector<uint8_t> snark_prove_resident(Instance &inst, CompComm &comm, DeviceWitness &wit, SnarkGens &g, const void *tlabel, size_t tlabel_len,
                                           const uint8_t *seed32, SnarkTimings *tm, ShardComm *sh = nullptr);
 

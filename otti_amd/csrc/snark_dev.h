@@ -38,8 +38,8 @@ unsigned long long dev_pc_tail(DevCtx &c, const PcList &L, int W, size_t len0, s
 
 void dev_gather(DevCtx &c, const Fr *table, const uint32_t *idx, Fr *out, size_t n);
 void dev_u32_to_fr(DevCtx &c, const uint32_t *in, Fr *out, size_t n);        // out[i] = in[i] as a field element (Montgomery form)
-void dev_hash_mem(DevCtx &c, const Fr *eval_table, const Fr *audit_ts, Fr *out_init, Fr *out_audit, size_t M, const Fr &r, const Fr &gamma);
-void dev_hash_ops(DevCtx &c, const Fr *addr_f, const Fr *deref, const Fr *read_ts, Fr *out_read, Fr *out_write, size_t N, const Fr &r, const Fr &gamma);
+void dev_hash_mem(DevCtx &c, const Fr *eval_table, const Fr *audit_ts, Fr *out_init, Fr *out_audit, size_t M, const Fr &r, const Fr &gamma, int G = 1, int rk = 0);   // G ranks: this rank's residue class (M / G elements) of the M-element vectors
+void dev_hash_ops(DevCtx &c, const Fr *addr_f, const Fr *deref, const Fr *read_ts, Fr *out_read, Fr *out_write, size_t N, const Fr &r, const Fr &gamma, int G = 1, int rk = 0);
 void dev_prod_layer(DevCtx &c, const LayerList &L, size_t q);
 // partials: >= 3 * kMaxBlocks elements of scratch.  Results arrive in c.h_results[slot ..] once the stream has been synchronised.
 void dev_pick0(DevCtx &c, const PtrList &L, int slot);

@@ -139,23 +139,64 @@ namespace {
 std::atomic<bool> g_tail_off{false};
 thread_local bool t_sharded_proof = false;                  // this thread is inside a sharded SNARK::prove (no persistent tail: see snark_prove_resident)
 bool shard_comm_active() { return t_sharded_proof; }
-// a batch of product circuits of one size: layer k of circuit i is (left, right) = store + off[k] + {0, n >> (k + 1)}
+// a batch of product circuits of one size: layer k of circuit i is (left, right) = store + off[k] + {0, n >> (k + 1)}.
+// Sharded (G ranks, rank rk): the device holds this rank's residue class of every layer whose sides have at least G elements (element i' here
+// is element i' G + rk there: every layer pairs i with i + side / 2, a multiple of G) — n_dev = n / G elements per circuit input, nl_dev layers;
+// the few layers above them (sides shorter than G) exist on the host only.  small[k][i] = (left, right) of layer k in full, for every layer
+// the host plays by itself (sides of at most kSmallSide elements), gathered from the ranks or computed from the layer below.
+constexpr size_t kSmallSide = 32;
 struct Circuits {
     size_t n = 0, nl = 0; int count = 0;
+    int G = 1, rk = 0; size_t n_dev = 0, nl_dev = 0;
     std::vector<Fr *> store; std::vector<size_t> off;
-    void init(int cnt, size_t n_, SnarkScratch &W, size_t first_slot) {
-        n = n_; count = cnt; nl = std::max<size_t>(1, ilog2(n)); store.resize(cnt); off.assign(nl, 0);
-        size_t o = 0; for (size_t k = 0; k < nl; k++) { off[k] = o; o += n >> k; }
+    std::vector<std::vector<std::pair<std::vector<Fr>, std::vector<Fr>>>> small;   // [layer][circuit], filled by gather_small() when sharded
+    void init(int cnt, size_t n_, SnarkScratch &W, size_t first_slot, int G_ = 1, int rk_ = 0) {
+        n = n_; count = cnt; nl = std::max<size_t>(1, ilog2(n)); G = G_; rk = rk_; n_dev = n / (size_t)G; nl_dev = std::max<size_t>(1, ilog2(n_dev));
+        store.resize(cnt); off.assign(nl_dev, 0);
+        size_t o = 0; for (size_t k = 0; k < nl_dev; k++) { off[k] = o; o += n_dev >> k; }
         for (int i = 0; i < cnt; i++) store[i] = W.get(first_slot + i, o);
     }
+    size_t side(size_t k) const { return n >> (k + 1); }                 // GLOBAL elements per side of layer k
+    size_t side_dev(size_t k) const { return n_dev >> (k + 1); }         // ... of which this rank holds
     Fr *left(int i, size_t k) { return store[i] + off[k]; }
-    Fr *right(int i, size_t k) { return store[i] + off[k] + (n >> (k + 1)); }
+    Fr *right(int i, size_t k) { return store[i] + off[k] + (n_dev >> (k + 1)); }
     Fr *input(int i) { return store[i]; }                     // layer 0: the hashed vector itself, left half then right half
     void build(DevCtx &c) {                                   // ProductCircuit::new: compute_layer, all circuits of the batch per launch
-        for (size_t k = 1; k < nl; k++) {
+        for (size_t k = 1; k < nl_dev; k++) {
             LayerList L; L.n = count;
             for (int i = 0; i < count; i++) { L.in_left[i] = left(i, k - 1); L.in_right[i] = right(i, k - 1); L.out_left[i] = left(i, k); L.out_right[i] = right(i, k); }
-            dev_prod_layer(c, L, n >> (k + 1));
+            dev_prod_layer(c, L, n_dev >> (k + 1));
+        }
+    }
+    // sharded: the layers the host plays alone, in full on every rank
+    void gather_small(DevCtx &c, ShardComm &sh) {
+        small.assign(nl, {});
+        for (size_t k = 0; k < nl; k++) {
+            const size_t h = side(k);
+            if (h > kSmallSide) continue;
+            small[k].resize(count);
+            if (k < nl_dev) {                                 // on the devices: every rank's share, interleaved
+                const size_t hl = side_dev(k);
+                std::vector<Fr> mine(2 * hl * count), all(mine.size() * (size_t)G);
+                for (int i = 0; i < count; i++) {
+                    OTTI_HIP(hipMemcpyAsync(&mine[(size_t)2 * i * hl], left(i, k), hl * sizeof(Fr), hipMemcpyDeviceToHost, c.stream));
+                    OTTI_HIP(hipMemcpyAsync(&mine[(size_t)(2 * i + 1) * hl], right(i, k), hl * sizeof(Fr), hipMemcpyDeviceToHost, c.stream));
+                }
+                OTTI_HIP(hipStreamSynchronize(c.stream));
+                sh.allgather(mine.data(), mine.size() * sizeof(Fr), all.data());
+                for (int i = 0; i < count; i++) {
+                    auto &lr = small[k][i]; lr.first.resize(h); lr.second.resize(h);
+                    for (int r = 0; r < G; r++) for (size_t e = 0; e < hl; e++) {
+                        lr.first[e * G + r] = all[(size_t)r * mine.size() + (size_t)2 * i * hl + e];
+                        lr.second[e * G + r] = all[(size_t)r * mine.size() + (size_t)(2 * i + 1) * hl + e];
+                    }
+                }
+            } else {                                          // above the devices' layers: compute_layer on the host from the layer below
+                for (int i = 0; i < count; i++) {
+                    const auto &below = small[k - 1][i]; auto &lr = small[k][i]; lr.first.resize(h); lr.second.resize(h);
+                    for (size_t e = 0; e < h; e++) { lr.first[e] = fr_mul(below.first[e], below.second[e]); lr.second[e] = fr_mul(below.first[h + e], below.second[h + e]); }
+                }
+            }
         }
     }
 };
@@ -171,9 +212,14 @@ struct DotpTables { Fr *l[6], *r[6], *w[6]; size_t len = 0; int n = 0; };
 // host applies c_j * ((1 - rand_j) + t (2 rand_j - 1)).  Once the tables are down to T elements they are exported to pinned memory and
 // the host plays the last rounds itself: a launch + hand-off costs more than the arithmetic of such a round on a host core.
 constexpr int kPcTailSlot = 128;
+// sh (sharded SNARK::prove): the tables are this rank's residue classes (Circuits above; D: strided copies); a device round works on them
+// with the eq factor taken at the global index, its sums are added across the ranks (allreduce_fr: 3 elements per instance), and where the
+// host takes a layer over the ranks' shares of its tables are gathered and interleaved.  Host rounds run on every rank alike.
 ProductCircuitEvalProofBatched pcbatch_prove(DevCtx &c, Circuits &C, const std::vector<Fr> &evals, DotpTables *D, const std::vector<Fr> &dotp_evals, Transcript &tr,
-                                             Fr *pyr, std::vector<Fr> &rand_out) {
+                                             Fr *pyr, std::vector<Fr> &rand_out, ShardComm *sh = nullptr) {
     const int np = C.count; const size_t nl = C.nl;
+    const size_t G = sh ? (size_t)sh->world() : 1, rk = sh ? (size_t)sh->rank() : 0;
+    if (sh && (C.G != (int)G || C.small.size() != nl)) throw Error(OTTI_ERR_INTERNAL, "sharded product circuits were not prepared for this exchange");
     ProductCircuitEvalProofBatched pf; pf.layers.resize(nl);
     std::vector<Fr> claims = evals, rand, rprod;
     const Fr one = fr_one();
@@ -201,12 +247,14 @@ ProductCircuitEvalProofBatched pcbatch_prove(DevCtx &c, Circuits &C, const std::
         const double tr_layer_start = trace ? now_ms() : 0;
         const size_t layer_id = nl - 1 - li, nr = rand.size(), h = (size_t)1 << nr;      // elements per side in this layer, one round per variable
         const bool with_dotp = layer_id == 0 && D && D->n;
-        if (with_dotp) { if (D->len != h) throw Error(OTTI_ERR_INTERNAL, "dot-product circuits do not match the input layer"); claims.insert(claims.end(), dotp_evals.begin(), dotp_evals.end()); }
+        if (with_dotp) { if (D->len != h / G) throw Error(OTTI_ERR_INTERNAL, "dot-product circuits do not match the input layer"); claims.insert(claims.end(), dotp_evals.begin(), dotp_evals.end()); }
+        const bool on_device = layer_id < C.nl_dev;             // (sharded: the layers with sides shorter than the number of ranks exist on the host only)
         PcList P; P.n = 0;
-        for (int i = 0; i < np; i++) { P.A[P.n] = C.left(i, layer_id); P.B[P.n] = C.right(i, layer_id); P.C[P.n] = nullptr; P.n++; }
+        for (int i = 0; i < np; i++) { P.A[P.n] = on_device ? C.left(i, layer_id) : nullptr; P.B[P.n] = on_device ? C.right(i, layer_id) : nullptr; P.C[P.n] = nullptr; P.n++; }
         if (with_dotp) for (int i = 0; i < D->n; i++) { P.A[P.n] = D->l[i]; P.B[P.n] = D->r[i]; P.C[P.n] = D->w[i]; P.n++; }
         const int ni = P.n;
         const size_t lgT = std::min<size_t>(nr, ni >= 8 ? lgt_many : lgt_few), T = (size_t)1 << lgT, ndev = nr - lgT;
+        if (sh && ndev && (T < G || !on_device)) throw Error(OTTI_ERR_INTERNAL, "sharded product circuits: more ranks than a host tail has elements");
         // The persistent tail (k_pc_tail, snark_dev.h): from round k0 on — the first round whose tables fit the LDS of W workgroups per
         // instance — ONE launch plays every remaining device round.  Only while this is the process's single proof in flight (its grid
         // must be resident as a whole: the workgroups wait for the host, the host for all of them) and no kernel class it belongs to is
@@ -230,6 +278,7 @@ ProductCircuitEvalProofBatched pcbatch_prove(DevCtx &c, Circuits &C, const std::
             EqSrc e;
             if (m <= n_lo) { e.hi = nullptr; e.lo = pyr_lo + (((size_t)1 << m) - 1); e.lo_bits = 0; }
             else { e.hi = pyr_hi + (((size_t)1 << (m - n_lo)) - 1); e.lo = pyr_lo + (((size_t)1 << n_lo) - 1); e.lo_bits = (int)n_lo; }
+            e.stride = (uint32_t)G; e.offset = (uint32_t)rk;       // sharded: item i of a kernel is element i G + rk of the table
             return e;
         };
         // launch k >= 1 folds by r_{k-1} and yields the sums of round k (k < ndev) or the exported tail (k == ndev).  Armed (device.h), it is
@@ -238,13 +287,13 @@ ProductCircuitEvalProofBatched pcbatch_prove(DevCtx &c, Circuits &C, const std::
         std::vector<unsigned long long> tick(ndev + 2, 0);
         auto launch_tail = [&](const Fr *r) { tail_seq = dev_pc_tail(c, P, tailW, h >> k0, T, r, eq_src(nr - k0), kPcTailSlot); };
         auto launch_for = [&](size_t k, const Fr *r) {
-            const size_t len_in = h >> (k - 1);
+            const size_t len_in = (h >> (k - 1)) / G;         // of this rank
             if (tail && k == k0) { launch_tail(r); return; }
             tick[k] = k < ndev ? dev_pc_fold_eval(c, P, len_in, r, eq_src(nr - k - 1), kSumSlot) : dev_pc_export(c, P, len_in, true, r, kPcTailSlot);
         };
         if (tail && k0 == 0) launch_tail(nullptr);
-        else if (ndev) { tick[0] = dev_pc_eval(c, P, h, eq_src(nr - 1), kSumSlot); if (armed(1)) launch_for(1, nullptr); }
-        else tick[0] = dev_pc_export(c, P, h, false, nullptr, kPcTailSlot);
+        else if (ndev) { tick[0] = dev_pc_eval(c, P, h / G, eq_src(nr - 1), kSumSlot); if (armed(1)) launch_for(1, nullptr); }
+        else if (!sh) tick[0] = dev_pc_export(c, P, h, false, nullptr, kPcTailSlot);     // (sharded: the host-only layers are in C.small already)
         std::vector<Fr> coeff = tr.challenge_vector("rand_coeffs_next_layer", claims.size());
         Fr e = fr_zero(); for (size_t k = 0; k < claims.size(); k++) e = fr_add(e, fr_mul(claims[k], coeff[k]));
         LayerProofBatched &L = pf.layers[li];
@@ -277,6 +326,7 @@ ProductCircuitEvalProofBatched pcbatch_prove(DevCtx &c, Circuits &C, const std::
                 if (trace) tr_tail_sum_ms += now_ms() - tr_round_start;
             } else if (j < ndev) {
                 c.wait_ticket(tick[j]);
+                if (sh) sh->allreduce_fr(&c.h_results[kSumSlot], (size_t)3 * ni);      // this round's sums over the ranks' residue classes (pinned memory: the next launch writes them afresh)
                 const Fr &tau = rand[j];
                 const Fr w0 = fr_sub(one, tau), dw = fr_sub(fr_add(tau, tau), one), w2 = fr_add(w0, fr_add(dw, dw)), w3 = fr_add(w2, dw);
                 const Fr f0 = fr_mul(cj, w0), f2 = fr_mul(cj, w2), f3 = fr_mul(cj, w3);
@@ -289,11 +339,28 @@ ProductCircuitEvalProofBatched pcbatch_prove(DevCtx &c, Circuits &C, const std::
                 c0 = fr_add(c0, fr_mul(f0, p0)); c2 = fr_add(c2, fr_mul(f2, p2)); c3 = fr_add(c3, fr_mul(f3, p3));
             } else {
                 if (!tail_built) {
+                    if (sh && ndev == 0) {                          // a layer the host plays alone: in full on every rank already (product circuits only)
+                        for (int k = 0; k < ni; k++) { tA[k] = C.small[layer_id][k].first; tB[k] = C.small[layer_id][k].second; }
+                    } else if (sh) {                                // every rank's share of the exported tables, interleaved: element e of rank r is element e G + r
+                        c.wait_ticket(tick[ndev]);
+                        const size_t Tl = T / G, per = (size_t)3 * ni * Tl;
+                        std::vector<Fr> all(per * G);
+                        sh->allgather(&c.h_results[kPcTailSlot], per * sizeof(Fr), all.data());
+                        for (int k = 0; k < ni; k++) {
+                            tA[k].resize(T); tB[k].resize(T); if (k >= np) tC[k].resize(T);
+                            for (size_t r = 0; r < G; r++) for (size_t e = 0; e < Tl; e++) {
+                                const Fr *base = &all[r * per + (size_t)3 * k * Tl];
+                                tA[k][e * G + r] = base[e]; tB[k][e * G + r] = base[Tl + e];
+                                if (k >= np) tC[k][e * G + r] = base[2 * Tl + e];
+                            }
+                        }
+                    } else {
                     if (tail) c.wait_tail(ni * tailW, tail_seq + (ndev - k0)); else c.wait_ticket(tick[ndev]);
                     for (int k = 0; k < ni; k++) {
                         const Fr *base = &c.h_results[kPcTailSlot + (size_t)3 * k * T];
                         tA[k].assign(base, base + T); tB[k].assign(base + T, base + 2 * T);
                         if (k >= np) tC[k].assign(base + 2 * T, base + 3 * T);
+                    }
                     }
                     tE = eq_evals_host(rand.data() + ndev, nr - ndev);
                     for (auto &x : tE) x = fr_mul(x, cj);
@@ -353,7 +420,9 @@ ProductCircuitEvalProofBatched pcbatch_prove(DevCtx &c, Circuits &C, const std::
                 if (j < ndev && tail && j >= k0) { tr_tail_ms += dt; tr_tail_rounds++; } else if (j < ndev) { tr_launch_ms += dt; tr_launch_rounds++; } else { tr_host_ms += dt; tr_host_rounds++; }
             }
         }
-        if (!tail_built) {                                   // a layer without rounds: the tables are single elements
+        if (!tail_built && sh) {                             // a layer without rounds, sharded: from the host copies
+            for (int k = 0; k < ni; k++) { tA[k].assign(1, C.small[layer_id][k].first[0]); tB[k].assign(1, C.small[layer_id][k].second[0]); }
+        } else if (!tail_built) {                            // a layer without rounds: the tables are single elements
             c.wait_ticket(tick[0]);
             for (int k = 0; k < ni; k++) { const Fr *base = &c.h_results[kPcTailSlot + (size_t)3 * k * T]; tA[k].assign(base, base + 1); tB[k].assign(base + T, base + T + 1); if (k >= np) tC[k].assign(base + 2 * T, base + 2 * T + 1); }
         }
@@ -593,33 +662,49 @@ static std::vector<uint8_t> snark_prove_resident_once(Instance &I, CompComm &com
     t0 = now_ms();
     const std::vector<Fr> r_mem_check = tr.challenge_vector("challenge_r_hash", 2);
     // PolyEvalNetwork::new: hash layers -> product circuits.  ops: row reads A,B,C; row writes; col reads; col writes.  mem: row init, row audit, col init, col audit.
+    // One proof over several GPUs: the product circuits (hash layer, product layers, the large rounds of the two batched sum-checks — the
+    // bandwidth-bound part of this stage) are split by residue classes of the element index; circuits too small for that run on every rank alike.
+    const int pcG = (sh && sh->world() > 1 && sh->world() <= 16 && N >= (size_t)64 * sh->world() && M >= (size_t)64 * sh->world()) ? sh->world() : 1;
+    const int pcR = pcG > 1 ? sh->rank() : 0;
+    ShardComm *const pc_sh = pcG > 1 ? sh : nullptr;
     Circuits ops, mem;
-    ops.init(12, N, W, SS_OPS); mem.init(4, M, W, SS_MEMC);
+    ops.init(12, N, W, SS_OPS, pcG, pcR); mem.init(4, M, W, SS_MEMC, pcG, pcR);
     lap("circuit allocations");
     for (int k = 0; k < 3; k++) {
-        dev_hash_ops(c, d.part(0, k), drow(k), d.part(1, k), ops.input(k), ops.input(3 + k), N, r_mem_check[0], r_mem_check[1]);
-        dev_hash_ops(c, d.part(2, k), dcol(k), d.part(3, k), ops.input(6 + k), ops.input(9 + k), N, r_mem_check[0], r_mem_check[1]);
+        dev_hash_ops(c, d.part(0, k), drow(k), d.part(1, k), ops.input(k), ops.input(3 + k), N, r_mem_check[0], r_mem_check[1], pcG, pcR);
+        dev_hash_ops(c, d.part(2, k), dcol(k), d.part(3, k), ops.input(6 + k), ops.input(9 + k), N, r_mem_check[0], r_mem_check[1], pcG, pcR);
     }
-    dev_hash_mem(c, mem_rx.p, d.comb_mem.p, mem.input(0), mem.input(1), M, r_mem_check[0], r_mem_check[1]);
-    dev_hash_mem(c, mem_ry.p, d.comb_mem.p + M, mem.input(2), mem.input(3), M, r_mem_check[0], r_mem_check[1]);
+    dev_hash_mem(c, mem_rx.p, d.comb_mem.p, mem.input(0), mem.input(1), M, r_mem_check[0], r_mem_check[1], pcG, pcR);
+    dev_hash_mem(c, mem_ry.p, d.comb_mem.p + M, mem.input(2), mem.input(3), M, r_mem_check[0], r_mem_check[1], pcG, pcR);
     lap("hash layer kernels");
     ops.build(c); mem.build(c);
+    if (pc_sh) { ops.gather_small(c, *pc_sh); mem.gather_small(c, *pc_sh); }
+    if (pc_sh && trace) fprintf(stderr, "[otti] snark_prove product circuits split by residue classes over %d ranks (rank %d: %zu of %zu operations, %zu of %zu memory cells)\n", pcG, pcR, ops.n_dev, N, mem.n_dev, M);
     lap("product layers");
     // the dot-product circuits: halves of (row_ops_val, col_ops_val, val) per matrix — copies, because the sum-check folds them in place
     const Ptr dotp{W.get(SS_DOTP, (size_t)9 * N)};
-    DotpTables D; D.len = H; D.n = 6;
+    DotpTables D; D.len = H / (size_t)pcG; D.n = 6;
     for (int k = 0; k < 3; k++) {
         Fr *base = dotp.p + (size_t)3 * k * N;
-        OTTI_HIP(hipMemcpyAsync(base, drow(k), N * sizeof(Fr), hipMemcpyDeviceToDevice, c.stream));
-        OTTI_HIP(hipMemcpyAsync(base + N, dcol(k), N * sizeof(Fr), hipMemcpyDeviceToDevice, c.stream));
-        OTTI_HIP(hipMemcpyAsync(base + 2 * N, d.part(4, k), N * sizeof(Fr), hipMemcpyDeviceToDevice, c.stream));
+        if (pc_sh) {                                              // this rank's residue class of every half: element e = element e G + rk of the half
+            const Fr *src[3] = {drow(k), dcol(k), d.part(4, k)};
+            for (int t = 0; t < 3; t++) for (int half = 0; half < 2; half++)
+                dev_gather_strided(c, src[t] + half * H, (size_t)pcG, (size_t)pcR, base + (size_t)t * N + half * H, D.len);
+        } else {
+            OTTI_HIP(hipMemcpyAsync(base, drow(k), N * sizeof(Fr), hipMemcpyDeviceToDevice, c.stream));
+            OTTI_HIP(hipMemcpyAsync(base + N, dcol(k), N * sizeof(Fr), hipMemcpyDeviceToDevice, c.stream));
+            OTTI_HIP(hipMemcpyAsync(base + 2 * N, d.part(4, k), N * sizeof(Fr), hipMemcpyDeviceToDevice, c.stream));
+        }
         for (int half = 0; half < 2; half++) { D.l[2 * k + half] = base + half * H; D.r[2 * k + half] = base + N + half * H; D.w[2 * k + half] = base + 2 * N + half * H; }
     }
     // PolyEvalNetworkProof::prove / ProductLayerProof::prove
     tr.append_protocol_name("Sparse polynomial evaluation proof");
     tr.append_protocol_name("Sparse polynomial product layer proof");
     std::vector<Fr> ops_evals(12), mem_evals(4);
-    {   // circuit outputs (left * right of the top layer); the dot-product claims were summed above
+    if (pc_sh) {   // circuit outputs, sharded: the top layers are on the host (Circuits::small)
+        for (int i = 0; i < 12; i++) ops_evals[i] = fr_mul(ops.small[ops.nl - 1][i].first[0], ops.small[ops.nl - 1][i].second[0]);
+        for (int i = 0; i < 4; i++) mem_evals[i] = fr_mul(mem.small[mem.nl - 1][i].first[0], mem.small[mem.nl - 1][i].second[0]);
+    } else {   // circuit outputs (left * right of the top layer); the dot-product claims were summed above
         PtrList pick; pick.n = 0;
         for (int i = 0; i < 12; i++) { pick.p[pick.n++] = ops.left(i, ops.nl - 1); pick.p[pick.n++] = ops.right(i, ops.nl - 1); }
         for (int i = 0; i < 4; i++) { pick.p[pick.n++] = mem.left(i, mem.nl - 1); pick.p[pick.n++] = mem.right(i, mem.nl - 1); }
@@ -646,9 +731,9 @@ static std::vector<uint8_t> snark_prove_resident_once(Instance &I, CompComm &com
     lap("dotp copies, circuit outputs");
     {
         const Ptr pyr{W.get(SS_PYR, 2 * 8192)};
-        E.proof_ops = pcbatch_prove(c, ops, ops_evals, &D, dotp_evals, tr, pyr.p, rand_ops);
+        E.proof_ops = pcbatch_prove(c, ops, ops_evals, &D, dotp_evals, tr, pyr.p, rand_ops, pc_sh);
         lap("batched proof: ops");
-        E.proof_mem = pcbatch_prove(c, mem, mem_evals, nullptr, {}, tr, pyr.p, rand_mem);
+        E.proof_mem = pcbatch_prove(c, mem, mem_evals, nullptr, {}, tr, pyr.p, rand_mem, pc_sh);
         lap("batched proof: mem");
     }
     T.ms[7] = now_ms() - t0;

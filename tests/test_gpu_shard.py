@@ -66,15 +66,18 @@ def test_sharded_snark_proof_is_byte_identical(tmp_path, world, lg, dist, ni):
     assert oc.bytes == comm.bytes
     assert orc.snark_prove(oi, oc, r["vars"], r["inputs"], og, LABEL, SEED)[0] == single.bytes
     seg = "otti-test-" + uuid.uuid4().hex
-    env_dev = os.environ.get("OTTI_DEVICE")
-    os.environ["OTTI_DEVICE"] = "0"
+    saved = {k: os.environ.get(k) for k in ("OTTI_DEVICE", "OTTI_TRACE")}
+    os.environ["OTTI_DEVICE"] = "0"; os.environ["OTTI_TRACE"] = "1"
     try:
-        run_ranks(lambda k: ["snark", seg, str(k), str(world), str(tmp_path / ("s%d.bin" % k)), str(lg), dist, str(ni)], world, timeout=900)
+        outs = run_ranks(lambda k: ["snark", seg, str(k), str(world), str(tmp_path / ("s%d.bin" % k)), str(lg), dist, str(ni)], world, timeout=900)
     finally:
-        if env_dev is None:
-            os.environ.pop("OTTI_DEVICE")
-        else:
-            os.environ["OTTI_DEVICE"] = env_dev
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    # the product circuits are split by residue classes whenever they are large enough for it (64 elements per rank): every case here but the 2^6 one
+    assert all(("product circuits split by residue classes over %d ranks" % world in o) == (lg >= 10) for o in outs), outs[0][-2000:]
     for k in range(world):
         got = open(tmp_path / ("s%d.bin" % k), "rb").read()
         nc = int.from_bytes(got[:8], "little")

@@ -27,6 +27,7 @@ def run_ranks(args_of_rank, world, timeout=300):
                 p.kill()
     for r, p in enumerate(procs):
         assert p.returncode == 0, "rank %d failed:\n%s" % (r, outs[r])
+    return outs
 
 
 @pytest.mark.parametrize("world", [2, 4])
