@@ -610,7 +610,7 @@ def main():
 
     def traffic_of(kernel_name, snark_run=False):
         """HBM bytes of the kernel's largest launch from a SEPARATE rocprofv3 --pmc pass kept under profiles/ (never measured in this run)"""
-        for cand in (("r3_snark_pmc_traffic.json",) if snark_run else ("r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json")):
+        for cand in (("r4_snark_pmc_traffic.json", "r3_snark_pmc_traffic.json") if snark_run else ("r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json")):
             try:
                 pm = json.load(open(os.path.join(ROOT, "profiles", cand)))
                 names = [k_.strip() for k_ in (kernel_name or "").split("/")]                     # a class may name two kernels: the first that was profiled

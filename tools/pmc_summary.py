@@ -37,7 +37,7 @@ def main():
         if best:
             out[k] = {"largest_launch_FETCH_SIZE_KiB": best[0], "largest_launch_WRITE_SIZE_KiB": best[1],
                       "traffic_bytes_corrected": int((2 * best[0] + best[1]) * 1024)}
-    json.dump({"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over the same command (tools/profile_round3.sh: bench.py for the NIZK kernels, "
+    json.dump({"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over the same command (tools/profile_round4.sh (round 3: profile_round3.sh): bench.py for the NIZK kernels, "
                        "tools/snark_probe.py for SNARK mode; 2^20; window width in msm_window_bits). Unit of the counters: KiB. gfx950 correction (MI355X guide): FETCH_SIZE reports half of the "
                        "bytes of wide coalesced 16-B-per-lane reads, so it is doubled; for the scattered 16-B loads of the window-table gathers that "
                        "factor is not calibrated and the corrected figure is an upper estimate.",
