@@ -481,7 +481,7 @@ def main():
         [int(x) for x in args.sweep.split(",") if x.strip() and int(x) != lg]
     if sweep_sizes:
         sweep = {}
-        ssteps = 3
+        ssteps = 4
         for slg in sweep_sizes:
             over = max_over_ranks(time.perf_counter() - t_start) > args.sweep_budget_s
             if over:
@@ -495,7 +495,7 @@ def main():
                 gens.release_device()
             si.prepare_device(sg)
             sw = oa.Witness(si, oa.VarsAssignment.new(sr["vars"]), oa.InputsAssignment.new(sr["inputs"]))
-            sp = [prove_once(si, sw, sg)]
+            sp = [prove_once(si, sw, sg), prove_once(si, sw, sg)]      # two warm-ups: the second proof of a size still ran 5 % slow (tools/gap_probe.py)
             barrier(); t0 = time.perf_counter()
             for _ in range(ssteps):
                 sp.append(prove_once(si, sw, sg))
@@ -527,7 +527,7 @@ def main():
         if not gens.table_info[1]:
             t0 = time.perf_counter(); inst.prepare_device(gens); t_reprepare = time.perf_counter() - t0
             assert gens.table_info[0] == cbits, "the headline's window table came back with another width"
-        sweep["note"] = ("NIZK::prove on the synthetic instance of each size, %s; instance, generator table and witness resident; %d timed proofs after one warm-up; "
+        sweep["note"] = ("NIZK::prove on the synthetic instance of each size, %s; instance, generator table and witness resident; %d timed proofs after two warm-ups; "
                          "every proof compared with tests/golden/proofs.json" % (("one proof sharded over %d GPUs" % world) if shard else "one GPU", ssteps))
 
     # SNARK mode at N > 1: SNARK::prove is not sharded — every GPU proves the same instance on its own (replicas), between barriers; the
