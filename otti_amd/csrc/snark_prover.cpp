@@ -11,6 +11,7 @@
 // polynomial-evaluation proofs reuse the log-size dot-product prover of NIZK mode (bullet rounds on the original generators).
 #include "snark.h"
 #include <atomic>
+#include <sched.h>
 #include "snark_dev.h"
 #include "shard.h"
 #include "pool.h"
@@ -498,6 +499,10 @@ struct RowsAhead {
     static hipStream_t masked_stream() { return bulk_masked_stream(); }   // k_context.hip: ONE CU-masked stream for the process
     void run() {
         try {
+            {   // created inside the prover's session: give back the affinity the session narrowed (this thread waits on the GPU, it does not belong on the helpers' cores)
+                cpu_set_t all; CPU_ZERO(&all); for (int i = 0; i < CPU_SETSIZE; i++) CPU_SET(i, &all);
+                (void)sched_setaffinity(0, sizeof all, &all);
+            }
             { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return stage != 0; }); if (stage < 0) { done = true; cv.notify_all(); return; } }
             DevCtx &hc = DevCtx::get();                           // this thread's own context: its own MSM partials, point buffers, stream
             hipStream_t own = hc.stream, ms = masked_stream();
@@ -549,6 +554,9 @@ static std::vector<uint8_t> snark_prove_resident_once(Instance &I, CompComm &com
                                                       const uint8_t *seed32, SnarkTimings *tm, ShardComm *sh) {
     DevCtx &c = DevCtx::get();
     ActiveProof active;
+    // first-use HIP objects are made BEFORE the session narrows this thread's affinity to its helpers' L3 group (pool.h hold_caller): a thread
+    // the runtime starts while making them would inherit the narrowed mask for good
+    if (!sh && c.num_cu >= 128) (void)bulk_masked_stream();
     SpinPool::Session pool_session;
     struct Sharded { bool was; explicit Sharded(bool on) : was(t_sharded_proof) { t_sharded_proof = on; } ~Sharded() { t_sharded_proof = was; } } sharded_scope(sh != nullptr);
     if (!comm.dec) throw Error(OTTI_ERR_BAD_ARG, "this computation commitment carries no decommitment (it was parsed from bytes): SNARK::prove needs the one SNARK::encode returned");
