@@ -33,6 +33,15 @@ def test_committed_two_rank_rehearsal_line_carries_cpu_baseline_transports_and_s
     assert any(k in d["sweep"] for k in ("2^22", "2^24")), "the rehearsal kept under profiles/ covers north_star's target size"
 
 
+def test_round4_rehearsal_line_has_the_sharded_snark_figure_and_the_early_scalars():
+    d = json.load(open(os.path.join(ROOT, "profiles", "r4_bench_rehearse_2ranks_one_gpu.json")))
+    _check_sharded_line(d, 2)
+    sn = d["snark"]
+    assert sn["scaling"] == "strong" and sn["replicas"]["scaling"] == "weak" and sn["equals_oracle_digest"] is True and sn["proof_sha256"] == sn["replicas"]["proof_sha256"]
+    assert d["snark_ms_per_proof"] == sn["ms_per_proof"] and d["ms_per_step_p50"] <= d["ms_per_step_p99"] <= d["ms_per_step_max"]
+    assert set(d["prepare_device_breakdown_ms"]) >= {"window_table_allocations", "window_table_upload_and_kernels", "instance_upload_and_csr_build"}
+
+
 @pytest.mark.gpu
 def test_two_rank_rehearsal_of_the_drivers_command(tmp_path):
     env = dict(os.environ); env["OTTI_BENCH_REHEARSE"] = "1"; env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
