@@ -194,6 +194,24 @@ def test_window_table_falls_back_when_hbm_is_short(rng):
         hip.hipFree(hog)
 
 
+def test_window_table_can_be_released_and_comes_back(rng):
+    """otti_gens_release_device frees the table (a process moving between instance sizes: two wide tables do not fit one card); the next
+    use builds it again — same width, same commitments — and otti_gens_build_ms says what the build took."""
+    nv = 1 << 14
+    gens, ogens = oa.NIZKGens.new(nv, nv, 1), orc.OGens(nv, nv, 1)
+    assert gens.table_info == (0, 0) and gens.build_ms == (0.0, 0.0)
+    R = ogens.R; L = 4
+    Z, blinds = orc.rand_fr(rng, L * R), orc.rand_fr(rng, L)
+    want = orc.commit_rows(ogens, Z, L, R, blinds)
+    assert eq(K.msm_rows(gens, Z, L, R, blinds)[0], want)
+    c, nbytes = gens.table_info
+    assert c >= 8 and nbytes > 0 and gens.build_ms[1] > 0
+    gens.release_device()
+    assert gens.table_info == (0, 0)
+    assert eq(K.msm_rows(gens, Z, L, R, blinds)[0], want)
+    assert gens.table_info == (c, nbytes)
+
+
 # ------------------------------------------------------------------------------------------------ whole proof
 def _prove_both(n, ni, seed=b"\x2a" * 32, label=b"nizk_example"):
     r = oa.synth_r1cs(n, ni, 1)
