@@ -496,9 +496,9 @@ def main():
             si.prepare_device(sg)
             sw = oa.Witness(si, oa.VarsAssignment.new(sr["vars"]), oa.InputsAssignment.new(sr["inputs"]))
             sp = [prove_once(si, sw, sg), prove_once(si, sw, sg)]      # two warm-ups: the second proof of a size still ran 5 % slow (tools/gap_probe.py)
-            barrier(); t0 = time.perf_counter()
+            barrier(); t0 = time.perf_counter(); s_each = []
             for _ in range(ssteps):
-                sp.append(prove_once(si, sw, sg))
+                t1 = time.perf_counter(); sp.append(prove_once(si, sw, sg)); s_each.append(1e3 * (time.perf_counter() - t1))
             barrier(); el = max_over_ranks(time.perf_counter() - t0)
             sd = {hashlib.sha256(p.bytes).hexdigest() for p in sp}
             assert len(sd) == 1
@@ -509,7 +509,8 @@ def main():
             ok = None if g_ is None else (g_["proof_sha256"] in sd)
             assert ok is not False, "sweep proof 2^%d differs from the oracle's committed digest" % slg
             sc, sb = sg.table_info
-            ent = {"ms_per_proof": round(1e3 * el / ssteps, 3), "value": round(sn * ssteps / el, 1), "unit": "constraints/s", "steps": ssteps,
+            ent = {"ms_per_proof": round(1e3 * el / ssteps, 3), "ms_per_proof_p50": round(sorted(s_each)[len(s_each) // 2], 3), "ms_per_proof_max": round(max(s_each), 3),
+                   "value": round(sn * ssteps / el, 1), "unit": "constraints/s", "steps": ssteps,
                    "hbm_frac_whole_proof": round(algorithmic_bytes(*si.dims[:2], 3 * sn) / (el / ssteps) / 1e9 / (HBM_PEAK_GBPS * (world if shard else 1)), 6),
                    "msm_window_bits": sc, "msm_table_GB": round(sb / 1e9, 2), "stage_ms": {k: round(v, 3) for k, v in sp[-1].stage_ms.items()},
                    "proof_sha256": next(iter(sd)), "equals_oracle_digest": ok}

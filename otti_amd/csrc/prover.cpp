@@ -22,13 +22,14 @@ static double now_ms() { return std::chrono::duration<double, std::milli>(std::c
 
 // Window width c of the fixed-base table.  Every bit of c removes additions from every MSM of every proof (W = floor(253/c)+1 per
 // scalar) and doubles the table; the table is built once per generator set and HBM is 288 GB, so take the widest window whose table
-// fits a budget (default 128 GiB: c = 17 for R = 1024 (96.8 GB; round 3 stopped at 16), 16 for R = 2048 (103 GB), 15 for R = 4096 (110 GB)).  A 200 GiB
-// budget (c = 17 / 17 / 16) was measured in round 4: the commitment MSMs gain their 6 %, but with 190+ GB in one allocation the streaming kernels of a
-// 2^22 proof ran 0.25 ms slower per sum-check and the table took seconds to allocate: not the default.  OTTI_MSM_WINDOW pins c;
+// fits a budget (default 200 GiB, two thirds of the card: c = 17 for R = 1024 (96.8 GB) and R = 2048 (193 GB), 16 for R = 4096 (206 GB); round 3 ran
+// with 128 GiB and c <= 16: 16 / 16 / 15).  Two wide tables do not fit one card: the one built second takes the next narrower window that
+// fits (ensure_gens_device), and otti_gens_release_device makes room.  Measured with the wider tables (bench.py --sweep, four timed proofs
+// after two warm-ups): 2^22 6.95-7.0 -> 6.6 ms, 2^24 20.8-21.1 -> 20.2 ms.  OTTI_MSM_WINDOW pins c;
 // OTTI_MSM_TABLE_GB changes the budget (one-shot callers such as spzk pick a small table: building it costs more than it saves).
 int device_window_bits(size_t nbases) {
     if (const char *e = getenv("OTTI_MSM_WINDOW")) { int c = atoi(e); if (c >= 4 && c <= 17) return c; }
-    double budget_gb = 128.0;
+    double budget_gb = 200.0;
     if (const char *e = getenv("OTTI_MSM_TABLE_GB")) { double v = atof(e); if (v > 0) budget_gb = v; }
     int best = 8;
     const int widest = nbases < 256 ? 12 : 17;             // tiny instances (R < 256) are launch-bound whatever the window: keep their tables small
