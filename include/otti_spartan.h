@@ -163,6 +163,10 @@ int32_t otti_host_selftest(uint32_t iterations);
  * + challenge scalar, [4] GF(l) multiplication, [5] GF(l) inversion, [6] hand-off of an empty task to a helper thread and back,
  * [7] / [8] the two halves of one zero-knowledge sum-check round's host work (up to the challenge / after it), [9] threads used. */
 int32_t otti_host_microbench(double out[10]);
+/* Measurement aid, no GPU: microseconds per LAYER of the host's last sum-check rounds in SNARK mode (hosttail.h: every round's sums + fold
+ * over np product instances and nd triples with tables of T elements, `threads` threads, mean of `reps` layers on random tables):
+ * out[0] with the AVX-512 IFMA form (0 when the CPU lacks the instructions or OTTI_HOST_FR8=0), out[1] with the scalar form. */
+int32_t otti_host_tail_bench(uint32_t np, uint32_t nd, uint64_t T, uint32_t threads, uint32_t reps, double out[2]);
 
 /* ---- zkInterface ingest (replaces spartan-zkinterface's reader; schema zkinterface 1.x) ---- */
 typedef struct {

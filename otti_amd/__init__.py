@@ -8,7 +8,7 @@ There is no CPU proving path: without the HIP library and a gfx950 device ``NIZK
 from .api import (  # noqa: F401
     ENTRY_DTYPE, SpartanError, R1CSError, ProofVerifyError, NoDeviceError,
     Instance, VarsAssignment, InputsAssignment, NIZKGens, NIZK, Witness, SNARKGens, ComputationCommitment, SNARK,
-    synth_r1cs, synth_r1cs_compiler_like, zkif_load, zkif_write, device_count, host_selftest, host_microbench, lib, lib_path,
+    synth_r1cs, synth_r1cs_compiler_like, zkif_load, zkif_write, device_count, host_selftest, host_microbench, host_tail_bench, lib, lib_path,
     fr_from_ints, fr_to_ints, kernels, kernels_dev, DeviceArray, lanes_pack, lanes_unpack, L_ORDER, stats_enable, stats_read, madd_peak, fr_mul_peak, armed_launches_on, KERNEL_CLASSES,
     shard_init, shard_finalize, shard_info, shard_allgather, shard_allreduce,
 )

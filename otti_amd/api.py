@@ -64,6 +64,7 @@ _sig("otti_buf_free", None, _vp)
 _sig("otti_device_count", _i32)
 _sig("otti_host_selftest", _i32, ctypes.c_uint32)
 _sig("otti_host_microbench", _i32, ctypes.POINTER(ctypes.c_double))
+_sig("otti_host_tail_bench", _i32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(ctypes.c_double))
 _sig("otti_instance_new", _i32, _u64, _u64, _u64, _vp, _sz, _vp, _sz, _vp, _sz, ctypes.POINTER(_vp))
 _sig("otti_instance_free", None, _vp)
 _sig("otti_instance_dims", _i32, _vp, ctypes.POINTER(_u64), ctypes.POINTER(_u64), ctypes.POINTER(_u64))
@@ -205,6 +206,13 @@ def host_microbench():
     out = (ctypes.c_double * 10)()
     _check(lib.otti_host_microbench(out))
     return dict(zip(HOST_OPS, out))
+
+
+def host_tail_bench(np_, nd, T, threads=1, reps=200):
+    """microseconds per layer of SNARK mode's host-played sum-check rounds: {'avx512ifma': .., 'scalar': ..} (0 = form not available)"""
+    out = (ctypes.c_double * 2)()
+    _check(lib.otti_host_tail_bench(np_, nd, T, threads, reps, out))
+    return {"avx512ifma": out[0], "scalar": out[1]}
 
 
 # ---------------------------------------------------------------------------------------------- libspartan mirror

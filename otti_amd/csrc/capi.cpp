@@ -2,6 +2,7 @@
 #include "device.h"
 #include "shard.h"
 #include "snark.h"
+#include "hosttail.h"
 #include <array>
 #include <atomic>
 #include <chrono>
@@ -102,6 +103,8 @@ int32_t otti_host_selftest(uint32_t iterations) {
                 pt_encode_ref(a, host_msm(s3, p3, 3)); pt_encode_ref(b, sum);
                 if (memcmp(a, b, 32)) throw Error(OTTI_ERR_INTERNAL, "host_msm differs from the sum of its terms");
             }
+            // the host's last sum-check rounds (hosttail.h): the AVX-512 IFMA form against the scalar one on random tables of every size, both kinds of instance
+            if (it < 128) hosttail_selftest(it);
             {   // the four-way split multiplication (verifier rounds) against the plain one
                 SplitTable st; split_table_build(st, rnd);
                 pt_encode_ref(a, split_table_mul(st, s)); pt_encode_ref(b, host_scalarmul(rnd, s));
@@ -168,6 +171,14 @@ int32_t otti_host_selftest(uint32_t iterations) {
 }
 
 // nanoseconds per operation of the host-side primitives on the sequential path (measurement aid: tools/hostbench.py)
+int32_t otti_host_tail_bench(uint32_t np, uint32_t nd, uint64_t T, uint32_t threads, uint32_t reps, double out[2]) {
+    return guarded([&] {
+        if (!out) throw Error(OTTI_ERR_BAD_ARG, "null out pointer");
+        if (np > 12 || nd > 12 || T < 2 || T > 4096 || (T & (T - 1))) throw Error(OTTI_ERR_BAD_ARG, "host tail bench: at most 12 + 12 instances, tables of 2 .. 4096 elements");
+        hosttail_bench((int)np, (int)nd, (size_t)T, (int)threads, (int)reps, out);
+        return OTTI_OK;
+    });
+}
 int32_t otti_host_microbench(double out[10]) {
     return guarded([&] {
         if (!out) throw Error(OTTI_ERR_BAD_ARG, "null out pointer");

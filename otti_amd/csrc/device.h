@@ -83,7 +83,11 @@ HD unsigned long long go_tag(unsigned long long seq, const Fr *v, int n) {
         }
     return h;
 }
-struct Armed { GoBox *host; GoBox *dev; unsigned long long want, deadline; };   // want == 0: not armed (values come as kernel arguments); deadline in 100 MHz ticks
+// The leader's copy for the other workgroups exists kGoCopies times, kGoCopyStride bytes apart (different memory channels): with every waiting
+// workgroup polling ONE line, 128 pollers kept a single HBM channel busy enough to double the latency of each poll.  Workgroup b polls copy b mod kGoCopies.
+constexpr int kGoCopies = 8;
+constexpr size_t kGoCopyStride = 4096;
+struct Armed { GoBox *host; GoBox *dev; unsigned long long want, deadline; int relay = 1; };   // relay 0: the copy's number is polled alone and the values loaded after it (OTTI_RELAY=0; A/B)   // want == 0: not armed (values come as kernel arguments); deadline in 100 MHz ticks
 constexpr unsigned long long kArmDeadlineTicks = 3000000000ull;   // 30 s of s_memrealtime: longer than any host stall the prover's own 20 s result wait tolerates
 constexpr size_t kArmMaxLen = 65536;                         // sum-check tables up to this length fold in <= 64 workgroups: only those launches are armed
 
@@ -137,7 +141,7 @@ struct DevCtx {
 struct RowSumSlot { DevBuf<uint8_t> comp; DevBuf<Niels> pts; DevBuf<Fr> sc; DevBuf<Pt> out; DevBuf<unsigned> bad; bool busy = false; };
 hipStream_t bulk_masked_stream();                                    // the process's CU-masked stream for chip-filling MSM launches beside latency-bound rounds (k_context.hip); nullptr if there is none
 struct ActiveProof { ActiveProof(); ~ActiveProof(); static int count(); };       // RAII around one prove call: counts the proofs in flight in this process
-constexpr int kResultSlots = 2048;                          // 64 KB pinned: round sums, sum-check tails (SNARK: up to 18 x 3 tables x 16 elements)
+constexpr int kResultSlots = 8192;                          // 256 KB pinned: round sums, sum-check tails (SNARK: up to 18 x 3 tables x 128 elements)
 constexpr size_t kHostEncodeRows = 8;
 constexpr size_t kHostPtsCap = 512;
 

@@ -94,8 +94,8 @@ DevCtx &DevCtx::get() {
     host_alloc((void **)&c->h_go, sizeof(GoBox));
     memset(c->h_go, 0, sizeof(GoBox));
     OTTI_HIP(hipHostGetDevicePointer((void **)&c->d_go_alias, c->h_go, 0));
-    c->d_go.alloc(1);
-    OTTI_HIP(hipMemset(c->d_go.p, 0, sizeof(GoBox)));
+    c->d_go.alloc((kGoCopies * kGoCopyStride + sizeof(GoBox) - 1) / sizeof(GoBox) + 1);       // kGoCopies copies, kGoCopyStride bytes apart (device.h)
+    OTTI_HIP(hipMemset(c->d_go.p, 0, c->d_go.n * sizeof(GoBox)));
     OTTI_HIP(hipEventCreate(&c->ev0)); OTTI_HIP(hipEventCreate(&c->ev1));
     // first launch from this library: makes the runtime load and register its code object NOW (tens of ms for a module of this size) —
     // a one-shot process creates its context on a thread of its own while the input is being parsed
@@ -191,8 +191,9 @@ hipStream_t bulk_masked_stream() {
     });
     return ms;
 }
-Armed DevCtx::arm() { Armed a; a.host = d_go_alias; a.dev = d_go.p; a.want = ++go_issued; a.deadline = arm_deadline; return a; }
-Armed DevCtx::arm_many(int count) { Armed a; a.host = d_go_alias; a.dev = d_go.p; a.want = go_issued + 1; a.deadline = arm_deadline; go_issued += (unsigned long long)count; return a; }
+static int relay_mode() { static const int m = [] { const char *e = getenv("OTTI_RELAY"); return (e && e[0] == '0') ? 0 : 1; }(); return m; }
+Armed DevCtx::arm() { Armed a; a.host = d_go_alias; a.dev = d_go.p; a.want = ++go_issued; a.deadline = arm_deadline; a.relay = relay_mode(); return a; }
+Armed DevCtx::arm_many(int count) { Armed a; a.host = d_go_alias; a.dev = d_go.p; a.want = go_issued + 1; a.deadline = arm_deadline; a.relay = relay_mode(); go_issued += (unsigned long long)count; return a; }
 void DevCtx::go(const Fr *v, int n) {
     if (go_published >= go_issued) throw Error(OTTI_ERR_INTERNAL, "go() without an armed launch");
     if (n > 4) n = 4;

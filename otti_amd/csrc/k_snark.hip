@@ -133,14 +133,16 @@ __device__ __forceinline__ void finish_many(Fr (&acc)[3], const Mailbox &mb, con
     if (threadIdx.x == 0) __hip_atomic_store(mb.host_flag, mb.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // ---- nine-limb forms (fr9.h).  Product-circuit instance (third table = the shared eq table, never stored): per item
-//   Q(0) += E a_lo b_lo,  Q(1) += E a_hi b_hi,  Q_inf += E (a_hi - a_lo)(b_hi - b_lo)   (E goes in times 2^10: two radix corrections)
-// — the quadratic's values at 0, 1 and its leading coefficient; finish_many turns the totals into the values at 0, 2, 3.
-// a_*, b_* normalised below 2.2 l; e10 normalised below 2^10 l.
+//   Q(0) += (E a_lo) b_lo,  Q(1) += (E a_hi) b_hi,  Q_inf += (E a_hi - E a_lo)(b_hi - b_lo)
+// — the quadratic's values at 0, 1 and its leading coefficient, in FIVE products (E a_lo and E a_hi serve two sums each; six when E multiplied
+// the three products a b); finish_many turns the totals into the values at 0, 2, 3.  E goes in times 2^10: E a_* then carries the factor 32
+// the second product needs.  a_*, b_* normalised below 2.2 l; e10 normalised below 2^10 l.
 __device__ __forceinline__ void abe_accum9(Fr9 (&acc)[3], const Fr9 &a_lo, const Fr9 &a_hi, const Fr9 &b_lo, const Fr9 &b_hi, const Fr9 &e10) {
-    const Fr9 da = fr9_norm(fr9_sub_kl<4>(a_hi, a_lo)), db = fr9_sub_kl<4>(b_hi, b_lo);     // values < 6.2 l
-    acc[0] = fr9_add(acc[0], fr9_mul(e10, fr9_mul(a_lo, b_lo)));                            // inner products < 1.1 l; outer: 2^10 * 1.1 / 2^9 + 1 < 3.2 l
-    acc[1] = fr9_add(acc[1], fr9_mul(e10, fr9_mul(a_hi, b_hi)));
-    acc[2] = fr9_add(acc[2], fr9_mul(e10, fr9_mul(da, db)));
+    const Fr9 u = fr9_mul(e10, a_lo), v = fr9_mul(e10, a_hi);                               // 2^10 l * 2.2 l / 2^261 + l < 5.4 l
+    const Fr9 dv = fr9_norm(fr9_sub_kl<8>(v, u)), db = fr9_sub_kl<4>(b_hi, b_lo);           // < 13.4 l; < 6.2 l (loose)
+    acc[0] = fr9_add(acc[0], fr9_mul(u, b_lo));                                             // 5.4 * 2.2 / 2^9 + 1 < 1.1 l
+    acc[1] = fr9_add(acc[1], fr9_mul(v, b_hi));
+    acc[2] = fr9_add(acc[2], fr9_mul(dv, db));                                              // 13.4 * 6.2 / 2^9 + 1 < 1.2 l
 }
 // Dot-product triple (three real tables): the cubic's values at 0, 2, 3 as they stand.  a_* plain, b_*5 and c_*5 times 32.
 __device__ __forceinline__ void abc_accum9(Fr9 (&acc)[3], const Fr9 &a_lo, const Fr9 &a_hi, const Fr9 &b_lo5, const Fr9 &b_hi5, const Fr9 &c_lo5, const Fr9 &c_hi5) {
@@ -281,11 +283,12 @@ __global__ __launch_bounds__(kTailThreads) void k_pc_tail(TailArgs a) {
     TailMail *const mail = a.mail + (size_t)y * W + w;
     uint32_t L = a.len0 / (uint32_t)W;                                  // this workgroup's share of every table
     // ---- load (folding by the previous round's challenge when the tables in HBM are one round behind); element j here is element j W + w there
+    const Fr9 r_load5 = fr9_unpack5(a.r);
     for (uint32_t idx = tid; idx < 3 * L; idx += nthr) {
         const uint32_t t = idx / L, j = idx - t * L; const size_t i = (size_t)j * W + w;
         Fr v;
         if (!src[t]) v = eq_at(a.E, i);                                 // product circuit: the shared eq table, materialised (t == 2 only)
-        else if (a.fold_on_load) { const Fr lo = src[t][i], hi = src[t][i + a.len0]; v = fr_add(lo, fr_mul(a.r, fr_sub(hi, lo))); }
+        else if (a.fold_on_load) { const Fr lo = src[t][i], hi = src[t][i + a.len0]; (void)fold9(lo, hi, r_load5, v); }
         else v = src[t][i];
         T0[t * kTailCap + j] = v;
     }
@@ -298,18 +301,29 @@ __global__ __launch_bounds__(kTailThreads) void k_pc_tail(TailArgs a) {
     while (L > L_out) {
         const uint32_t half = L / 2;
         // ---- this round's sums: S_t = sum over pairs of (A_t B_t C_t), t in {0, 2, 3}
-        Fr acc = fr_zero();
+        // nine limbs (fr9.h): the first table plain, the other two times 32 — each of the two products then has exactly one operand carrying the
+        // radix correction (abc_accum9 above has the bounds; here every operand comes canonical out of the LDS)
+        Fr9 acc9 = fr9_zero(); unsigned n_acc = 0;
         if (grp < ngrp)
             for (uint32_t p = (uint32_t)grp * 64 + lane; p < half; p += (uint32_t)ngrp * 64) {
-                Fr x[3];
-#pragma unroll
-                for (int t = 0; t < 3; t++) {
-                    const Fr lo = T0[t * kTailCap + p], hi = T0[t * kTailCap + p + half];
-                    if (pt == 0) x[t] = lo;
-                    else { const Fr d = fr_sub(hi, lo); Fr e = fr_add(hi, d); if (pt == 2) e = fr_add(e, d); x[t] = e; }   // 2 hi - lo, 3 hi - 2 lo
+                const Fr9 a_lo = fr9_unpack(T0[p]), b_lo5 = fr9_unpack5(T0[kTailCap + p]), c_lo5 = fr9_unpack5(T0[2 * kTailCap + p]);
+                Fr9 term;
+                if (pt == 0) term = fr9_mul(fr9_mul(a_lo, b_lo5), c_lo5);
+                else {
+                    const Fr9 a_hi = fr9_unpack(T0[p + half]), b_hi5 = fr9_unpack5(T0[kTailCap + p + half]), c_hi5 = fr9_unpack5(T0[2 * kTailCap + p + half]);
+                    const Fr9 x2 = fr9_norm(fr9_sub_kl<4>(fr9_add(a_hi, a_hi), a_lo));
+                    const Fr9 y2 = fr9_sub_kl<128>(fr9_add(b_hi5, b_hi5), b_lo5), z2 = fr9_sub_kl<128>(fr9_add(c_hi5, c_hi5), c_lo5);
+                    if (pt == 1) term = fr9_mul(fr9_mul(x2, y2), z2);
+                    else {
+                        const Fr9 x3 = fr9_norm(fr9_add(x2, fr9_sub_kl<4>(a_hi, a_lo)));
+                        const Fr9 y3 = fr9_norm(fr9_add(y2, fr9_sub_kl<128>(b_hi5, b_lo5))), z3 = fr9_norm(fr9_add(z2, fr9_sub_kl<128>(c_hi5, c_lo5)));
+                        term = fr9_mul(fr9_mul(x3, y3), z3);
+                    }
                 }
-                acc = fr_add(acc, fr_mul(fr_mul(x[0], x[1]), x[2]));
+                acc9 = fr9_add(acc9, term);
+                if ((++n_acc & 3u) == 0) acc9 = fr9_norm(acc9);
             }
+        Fr acc = fr9_canon(fr9_norm(acc9));
         if (stamp) stamp[8 * rnd + 1] = wall_clock64();               // sums done
         tail_reduce1(acc, pt, grp, ngrp, half, s_part, s_tot);
         if (stamp) stamp[8 * rnd + 2] = wall_clock64();               // reduced
@@ -319,11 +333,12 @@ __global__ __launch_bounds__(kTailThreads) void k_pc_tail(TailArgs a) {
         Fr rv[1]; Armed g = a.go; g.want = want++;
         if (!armed_fetch<1>(g, rv)) return;
         if (stamp) stamp[8 * rnd + 4] = wall_clock64();               // challenge here
+        const Fr9 r5 = fr9_unpack5(rv[0]);
         for (uint32_t idx = tid; idx < 3 * half; idx += nthr) {
             const uint32_t t = idx / half, e = idx - t * half;
             Fr *X = T0 + t * kTailCap;
-            const Fr lo = X[e];
-            X[e] = fr_add(lo, fr_mul(rv[0], fr_sub(X[e + half], lo)));
+            Fr w; (void)fold9(X[e], X[e + half], r5, w);
+            X[e] = w;
         }
         __syncthreads();
         L = half;
@@ -353,6 +368,7 @@ unsigned long long dev_pc_tail(DevCtx &c, const PcList &L, int W, size_t len0, s
     a.go = c.arm_many(rounds);
     static const bool test_drop = getenv("OTTI_TEST_TAIL_DROP") != nullptr;
     a.test_drop = test_drop ? 1 : 0;
+
     static const bool want_stamps = getenv("OTTI_TAIL_STAMPS") != nullptr;
     static thread_local unsigned long long *h_stamps = nullptr, *d_stamps = nullptr;
     a.stamps = nullptr;

@@ -57,8 +57,30 @@ __device__ __forceinline__ bool arrive_and_check_last(unsigned *counter, unsigne
 // decision alone; their own backstop (the deadline plus a quarter: the leader never ran) only exists so that a grid always drains.
 // Returns false in every thread of the workgroup when the launch was aborted or gave up: the kernel then returns at once, having
 // touched nothing.
+// One poll of a GoBox = the header (sequence number, tag) and the N values in ONE batch of 16-byte loads, all issued before the first is waited
+// for.  kSystem: the box is the host's (system scope: one PCIe round trip from go() to the challenge); otherwise the leader's copy in HBM
+// (agent scope).  The loads of a batch may be served at different moments; go_tag() tells a batch that mixes old and new words.
+typedef uint32_t go_u32x4 __attribute__((ext_vector_type(4)));
+template <int N, bool kSystem> __device__ __forceinline__ void go_batch_load(const GoBox *box, go_u32x4 &hd, go_u32x4 (&w)[8]) {
+    if constexpr (N == 1 && kSystem)
+        asm volatile("global_load_dwordx4 %0, %3, off sc0 sc1\n\tglobal_load_dwordx4 %1, %3, off offset:32 sc0 sc1\n\tglobal_load_dwordx4 %2, %3, off offset:48 sc0 sc1\n\t"
+                     "s_waitcnt vmcnt(0)" : "=&v"(hd), "=&v"(w[0]), "=&v"(w[1]) : "v"(box) : "memory");
+    else if constexpr (N == 1)
+        asm volatile("global_load_dwordx4 %0, %3, off sc1\n\tglobal_load_dwordx4 %1, %3, off offset:32 sc1\n\tglobal_load_dwordx4 %2, %3, off offset:48 sc1\n\t"
+                     "s_waitcnt vmcnt(0)" : "=&v"(hd), "=&v"(w[0]), "=&v"(w[1]) : "v"(box) : "memory");
+    else if constexpr (kSystem)
+        asm volatile("global_load_dwordx4 %0, %9, off sc0 sc1\n\tglobal_load_dwordx4 %1, %9, off offset:32 sc0 sc1\n\tglobal_load_dwordx4 %2, %9, off offset:48 sc0 sc1\n\t"
+                     "global_load_dwordx4 %3, %9, off offset:64 sc0 sc1\n\tglobal_load_dwordx4 %4, %9, off offset:80 sc0 sc1\n\tglobal_load_dwordx4 %5, %9, off offset:96 sc0 sc1\n\t"
+                     "global_load_dwordx4 %6, %9, off offset:112 sc0 sc1\n\tglobal_load_dwordx4 %7, %9, off offset:128 sc0 sc1\n\tglobal_load_dwordx4 %8, %9, off offset:144 sc0 sc1\n\t"
+                     "s_waitcnt vmcnt(0)" : "=&v"(hd), "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&v"(w[4]), "=&v"(w[5]), "=&v"(w[6]), "=&v"(w[7]) : "v"(box) : "memory");
+    else
+        asm volatile("global_load_dwordx4 %0, %9, off sc1\n\tglobal_load_dwordx4 %1, %9, off offset:32 sc1\n\tglobal_load_dwordx4 %2, %9, off offset:48 sc1\n\t"
+                     "global_load_dwordx4 %3, %9, off offset:64 sc1\n\tglobal_load_dwordx4 %4, %9, off offset:80 sc1\n\tglobal_load_dwordx4 %5, %9, off offset:96 sc1\n\t"
+                     "global_load_dwordx4 %6, %9, off offset:112 sc1\n\tglobal_load_dwordx4 %7, %9, off offset:128 sc1\n\tglobal_load_dwordx4 %8, %9, off offset:144 sc1\n\t"
+                     "s_waitcnt vmcnt(0)" : "=&v"(hd), "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&v"(w[4]), "=&v"(w[5]), "=&v"(w[6]), "=&v"(w[7]) : "v"(box) : "memory");
+}
 template <int N> __device__ __forceinline__ bool armed_fetch(const Armed &a, Fr (&v)[N]) {
-    static_assert(N >= 1 && N <= 4, "a GoBox carries four values");
+    static_assert(N == 1 || N == 4, "a GoBox carries one value or four");
     __shared__ Fr s_v[N]; __shared__ int s_ok;
     if (threadIdx.x == 0) {
         const bool leader = (blockIdx.x | blockIdx.y | blockIdx.z) == 0;
@@ -66,22 +88,10 @@ template <int N> __device__ __forceinline__ bool armed_fetch(const Armed &a, Fr 
         int ok = -1;
         Fr t[N];
         for (int k = 0; k < N; k++) t[k] = fr_zero();
+        go_u32x4 hd, w[8];
         if (leader) {
-            // One poll = the header (sequence number, tag) and the N values in ONE batch of system-scope 16-byte loads, all issued before
-            // the first is waited for: a poll that finds its number has the values too — one PCIe round trip from go() to the challenge.
-            // The loads of a batch may be served at different moments; go_tag() tells a batch that mixes old and new words (polled again).
-            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-            const GoBox *box = a.host;
             while (ok < 0) {
-                u32x4 hd, w[8];
-                if constexpr (N == 1)
-                    asm volatile("global_load_dwordx4 %0, %3, off sc0 sc1\n\tglobal_load_dwordx4 %1, %3, off offset:32 sc0 sc1\n\tglobal_load_dwordx4 %2, %3, off offset:48 sc0 sc1\n\t"
-                                 "s_waitcnt vmcnt(0)" : "=&v"(hd), "=&v"(w[0]), "=&v"(w[1]) : "v"(box) : "memory");
-                else
-                    asm volatile("global_load_dwordx4 %0, %9, off sc0 sc1\n\tglobal_load_dwordx4 %1, %9, off offset:32 sc0 sc1\n\tglobal_load_dwordx4 %2, %9, off offset:48 sc0 sc1\n\t"
-                                 "global_load_dwordx4 %3, %9, off offset:64 sc0 sc1\n\tglobal_load_dwordx4 %4, %9, off offset:80 sc0 sc1\n\tglobal_load_dwordx4 %5, %9, off offset:96 sc0 sc1\n\t"
-                                 "global_load_dwordx4 %6, %9, off offset:112 sc0 sc1\n\tglobal_load_dwordx4 %7, %9, off offset:128 sc0 sc1\n\tglobal_load_dwordx4 %8, %9, off offset:144 sc0 sc1\n\t"
-                                 "s_waitcnt vmcnt(0)" : "=&v"(hd), "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&v"(w[4]), "=&v"(w[5]), "=&v"(w[6]), "=&v"(w[7]) : "v"(box) : "memory");
+                go_batch_load<N, true>(a.host, hd, w);
                 const unsigned long long s = (unsigned long long)hd[0] | ((unsigned long long)hd[1] << 32), tag = (unsigned long long)hd[2] | ((unsigned long long)hd[3] << 32);
                 if (s == a.want) {
                     for (int k = 0; k < N; k++) for (int i = 0; i < 4; i++) { t[k].v[i] = w[2 * k][i]; t[k].v[4 + i] = w[2 * k + 1][i]; }
@@ -93,21 +103,53 @@ template <int N> __device__ __forceinline__ bool armed_fetch(const Armed &a, Fr 
                     __hip_atomic_store(&a.host->timed_out, a.want, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
                 } else __builtin_amdgcn_s_sleep(1);
             }
-            if (ok) for (int k = 0; k < N; k++) store_words_sc1(&a.dev->v[k], t[k].v, 8);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(&a.dev->seq, ok ? a.want : (a.want | abort_bit), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // the copies for the other workgroups (device.h: kGoCopies of them): values first, then (number, tag) in one 16-byte store; nothing is
+            // waited for — a reader checks the tag as this workgroup checked the host's (an abort carries no values: its number alone says so)
+            if (a.relay == 0) {
+                if (ok) for (int k = 0; k < N; k++) store_words_sc1(&a.dev->v[k], t[k].v, 8);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(&a.dev->seq, ok ? a.want : (a.want | abort_bit), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                const unsigned long long s_out = ok ? a.want : (a.want | abort_bit), tag_out = ok ? go_tag(a.want, t, N) : 0ull;
+                go_u32x4 h; h[0] = (uint32_t)s_out; h[1] = (uint32_t)(s_out >> 32); h[2] = (uint32_t)tag_out; h[3] = (uint32_t)(tag_out >> 32);
+                for (int c = 0; c < kGoCopies; c++) {
+                    char *box = reinterpret_cast<char *>(a.dev) + (size_t)c * kGoCopyStride;
+                    if (ok)
+                        for (int k = 0; k < N; k++) {
+                            go_u32x4 lo, hi; for (int i = 0; i < 4; i++) { lo[i] = t[k].v[i]; hi[i] = t[k].v[4 + i]; }
+                            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1" :: "v"(box + 32 + 32 * k), "v"(lo), "v"(hi) : "memory");
+                        }
+                    asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(box), "v"(h) : "memory");
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (stores this wave does not wait for were seen to reach the readers microseconds later)
+            }
         } else {
             const unsigned long long backstop = a.deadline + (a.deadline >> 2);   // the leader's deadline and a margin (it reports; this only drains the grid)
+            const unsigned wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+            const GoBox *mine = reinterpret_cast<const GoBox *>(reinterpret_cast<const char *>(a.dev) + (size_t)(wg % kGoCopies) * kGoCopyStride);
+            if (a.relay == 0) {
+                for (unsigned polls = 0; ok < 0; polls++) {
+                    const unsigned long long s = __hip_atomic_load(&a.dev->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (s == a.want) ok = 1;
+                    else if (s == (a.want | abort_bit) || __builtin_amdgcn_s_memrealtime() - t0 > backstop) ok = 0;
+                    else if ((polls & 0xfffu) == 0xfffu && __hip_atomic_load(&a.host->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == ~0ull) ok = 0;
+                    else __builtin_amdgcn_s_sleep(1);
+                }
+                if (ok) for (int k = 0; k < N; k++) load_words_sc1(t[k].v, &a.dev->v[k], 8);
+            } else
             for (unsigned polls = 0; ok < 0; polls++) {
-                const unsigned long long s = __hip_atomic_load(&a.dev->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (s == a.want) ok = 1;
-                else if (s == (a.want | abort_bit) || __builtin_amdgcn_s_memrealtime() - t0 > backstop) ok = 0;
+                go_batch_load<N, false>(mine, hd, w);
+                const unsigned long long s = (unsigned long long)hd[0] | ((unsigned long long)hd[1] << 32), tag = (unsigned long long)hd[2] | ((unsigned long long)hd[3] << 32);
+                if (s == a.want) {
+                    for (int k = 0; k < N; k++) for (int i = 0; i < 4; i++) { t[k].v[i] = w[2 * k][i]; t[k].v[4 + i] = w[2 * k + 1][i]; }
+                    if (go_tag(a.want, t, N) == tag) { ok = 1; break; }
+                }
+                if (s == (a.want | abort_bit) || __builtin_amdgcn_s_memrealtime() - t0 > backstop) ok = 0;
                 // a leader that is not resident (a grid larger than the CUs this process may use) cannot pass the host's abort on: look at the
                 // host word itself once in a while (one PCIe read per few thousand polls)
                 else if ((polls & 0xfffu) == 0xfffu && __hip_atomic_load(&a.host->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == ~0ull) ok = 0;
                 else __builtin_amdgcn_s_sleep(1);
             }
-            if (ok) for (int k = 0; k < N; k++) load_words_sc1(t[k].v, &a.dev->v[k], 8);
         }
         for (int k = 0; k < N; k++) s_v[k] = t[k];
         s_ok = ok;

@@ -15,6 +15,7 @@
 #include "snark_dev.h"
 #include "shard.h"
 #include "pool.h"
+#include "hosttail.h"
 #include <chrono>
 #include <functional>
 #include <thread>
@@ -145,7 +146,7 @@ bool shard_comm_active() { return t_sharded_proof; }
 // is element i' G + rk there: every layer pairs i with i + side / 2, a multiple of G) — n_dev = n / G elements per circuit input, nl_dev layers;
 // the few layers above them (sides shorter than G) exist on the host only.  small[k][i] = (left, right) of layer k in full, for every layer
 // the host plays by itself (sides of at most kSmallSide elements), gathered from the ranks or computed from the layer below.
-constexpr size_t kSmallSide = 32;
+constexpr size_t kSmallSide = 256;                          // >= the longest host tail (2^OTTI_PC_LGT_*: 64 / 128 by default, hosttail.h takes up to 256)
 struct Circuits {
     size_t n = 0, nl = 0; int count = 0;
     int G = 1, rk = 0; size_t n_dev = 0, nl_dev = 0;
@@ -230,6 +231,9 @@ ProductCircuitEvalProofBatched pcbatch_prove(DevCtx &c, Circuits &C, const std::
     // also take the route where the tail picks up tables that earlier launches folded in HBM)
     static const bool tail_env = [] { const char *e = getenv("OTTI_PC_TAIL"); return !(e && e[0] == '0'); }();
     static const size_t tail_cap = [] { const char *e = getenv("OTTI_PC_TAIL_CAP"); size_t v = e ? (size_t)atoi(e) : 0; return (v >= 2 && v <= (size_t)kTailCap && !(v & (v - 1))) ? v : (size_t)kTailCap; }();
+    // elements of a table a workgroup of the tail starts with (it spreads wider only for what does not fit): fewer, busier workgroups mean fewer
+    // mail lines per round for the host to collect — the larger cost (tools/hosttail_variants.sh)
+    static const size_t tail_per_wg = [] { const char *e = getenv("OTTI_PC_TAIL_PER_WG"); size_t v = e ? (size_t)atoi(e) : 0; return (v >= 16 && v <= (size_t)kTailCap && !(v & (v - 1))) ? v : (size_t)128; }();
     const bool tail_ok = arm_ok && tail_env && !g_tail_off.load(std::memory_order_relaxed) && !shard_comm_active();
     // its grid (W workgroups per instance, one per CU: 96 KB of LDS each) must be resident as a whole: never more workgroups than the device has CUs
     const int tail_groups_max = std::min(kTailMaxGroups, c.num_cu);
@@ -238,10 +242,12 @@ ProductCircuitEvalProofBatched pcbatch_prove(DevCtx &c, Circuits &C, const std::
     static const size_t pc_arm_max = [] { const char *e = getenv("OTTI_PC_ARM_MAX"); return e ? (size_t)atoll(e) : (size_t)1 << 22; }();     // (the sum-check kernels of the R1CS proof arm up to kArmMaxLen; here a round more or less ahead costs nothing else)
     SpinPool &pool = SpinPool::get();
     const int host_threads = std::min(8, pool.workers() + 1);
-    // the host plays the last 4 (18-instance batches: tables of 16) or 5 (4-instance batches: 32) rounds of every layer.  Larger host tails
-    // were measured with the rounds spread over the helper threads (5 / 7: 10.9-11.4 ms against 10.7; OTTI_PC_LGT_MANY / _FEW): a device round
-    // of that size costs less than the host's arithmetic plus its thread hand-offs
-    const size_t lgt_many = lgt_env_many ? lgt_env_many : 4, lgt_few = lgt_env_few ? lgt_env_few : 5;
+    // How many of a layer's last rounds the host plays (hosttail.h).  With the AVX-512 IFMA form a host round over tables of 32 / 64 elements costs
+    // less than the 16 us of a round of the persistent launch: the last 6 rounds of the 12- and 18-instance batches (tables of 64), the last 7 of
+    // the 4-instance batches (128); measured 4/5, 5/6, 5/7, 5/8, 6/7: product circuits 9.5, 9.1, 9.15, 9.3, 9.0 ms (tools/hosttail_variants.sh,
+    // profiles/r4_hosttail_variants.txt).  With the scalar form (no such instructions): 4 and 5 as before (5/7 cost 10.9-11.4 ms against 10.7).
+    const bool fr8 = host_fr8_available();
+    const size_t lgt_many = lgt_env_many ? lgt_env_many : (fr8 ? 6 : 4), lgt_few = lgt_env_few ? lgt_env_few : (fr8 ? 7 : 5);
     static const bool trace = getenv("OTTI_TRACE") != nullptr;
     double tr_tail_first_ms = 0, tr_tail_sum_ms = 0, tr_tail_wait_ms = 0, tr_tail_ms = 0, tr_launch_ms = 0, tr_host_ms = 0, tr_layer0_ms = 0; size_t tr_tail_rounds = 0, tr_launch_rounds = 0, tr_host_rounds = 0, tr_tail_layers = 0;
     for (size_t li = 0; li < nl; li++) {
@@ -266,7 +272,7 @@ ProductCircuitEvalProofBatched pcbatch_prove(DevCtx &c, Circuits &C, const std::
             const size_t cap_all = tail_cap * (size_t)Wmax;
             k0 = 0; while ((h >> k0) > cap_all) k0++;
             if (k0 >= ndev) k0 = ndev;                           // (cannot happen for cap_all >= 2 T; kept for a shrunken test capacity)
-            else { const size_t len0 = h >> k0; tailW = 1; while (tailW < Wmax && len0 / (size_t)tailW > 128) tailW *= 2; while (len0 / (size_t)tailW > tail_cap) tailW *= 2; }
+            else { const size_t len0 = h >> k0; tailW = 1; while (tailW < Wmax && len0 / (size_t)tailW > tail_per_wg) tailW *= 2; while (len0 / (size_t)tailW > tail_cap) tailW *= 2; }
         }
         const bool tail = k0 < ndev;
         unsigned long long tail_seq = 0;
@@ -300,8 +306,8 @@ ProductCircuitEvalProofBatched pcbatch_prove(DevCtx &c, Circuits &C, const std::
         LayerProofBatched &L = pf.layers[li];
         rprod.clear();
         std::vector<std::vector<Fr>> tA(ni), tB(ni), tC(ni); std::vector<Fr> tE; bool tail_built = false;   // host tail: T elements per table
+        std::unique_ptr<HostTail> host_tail;
         Fr cj = one, cj_tail = one;                         // cj_tail: the eq factor accumulated before the tail took over (its eq table carries the rest)
-        size_t len = h;
         if (trace) { tr_layer0_ms += now_ms() - tr_layer_start; if (tail) tr_tail_layers++; }
         for (size_t j = 0; j < nr; j++) {                    // SumcheckInstanceProof::prove_cubic_batched
             const double tr_round_start = trace ? now_ms() : 0;
@@ -341,6 +347,7 @@ ProductCircuitEvalProofBatched pcbatch_prove(DevCtx &c, Circuits &C, const std::
             } else {
                 if (!tail_built) {
                     if (sh && ndev == 0) {                          // a layer the host plays alone: in full on every rank already (product circuits only)
+                        if (C.small[layer_id].size() != (size_t)ni || C.small[layer_id][0].first.size() != T) throw Error(OTTI_ERR_INTERNAL, "sharded product circuits: a host-played layer was not gathered (host tail longer than kSmallSide)");
                         for (int k = 0; k < ni; k++) { tA[k] = C.small[layer_id][k].first; tB[k] = C.small[layer_id][k].second; }
                     } else if (sh) {                                // every rank's share of the exported tables, interleaved: element e of rank r is element e G + r
                         c.wait_ticket(tick[ndev]);
@@ -365,32 +372,13 @@ ProductCircuitEvalProofBatched pcbatch_prove(DevCtx &c, Circuits &C, const std::
                     }
                     tE = eq_evals_host(rand.data() + ndev, nr - ndev);
                     for (auto &x : tE) x = fr_mul(x, cj);
+                    std::vector<const Fr *> pa(ni), pb(ni), pc(ni);
+                    for (int k = 0; k < ni; k++) { pa[k] = tA[k].data(); pb[k] = tB[k].data(); pc[k] = k >= np ? tC[k].data() : nullptr; }
+                    host_tail = HostTail::make(np, ni - np, T, pa.data(), pb.data(), pc.data(), tE.data(), coeff.data(), host_threads);   // hosttail.h: AVX-512 IFMA where the CPU has it
                     tail_built = true;
                 }
-                const size_t half = len / 2;
-                // the instances are independent: spread over the prover's helper threads while a round is more than a few microseconds of work
-                const int nt = (half * (size_t)ni >= 32) ? std::min(host_threads, ni) : 1;
-                Fr part[8][3];
-                auto eval_share = [&](int t) {
-                    Fr q0 = fr_zero(), q2 = fr_zero(), q3 = fr_zero();
-                    for (int k = t; k < ni; k += nt) {
-                        const std::vector<Fr> &A = tA[k], &B = tB[k], &Cc = k < np ? tE : tC[k];
-                        Fr s0 = fr_zero(), s2 = fr_zero(), s3 = fr_zero();
-                        for (size_t i = 0; i < half; i++) {
-                            const Fr da = fr_sub(A[i + half], A[i]), db = fr_sub(B[i + half], B[i]), dc = fr_sub(Cc[i + half], Cc[i]);
-                            s0 = fr_add(s0, fr_mul(fr_mul(A[i], B[i]), Cc[i]));
-                            Fr x = fr_add(A[i + half], da), y = fr_add(B[i + half], db), z = fr_add(Cc[i + half], dc);
-                            s2 = fr_add(s2, fr_mul(fr_mul(x, y), z));
-                            x = fr_add(x, da); y = fr_add(y, db); z = fr_add(z, dc);
-                            s3 = fr_add(s3, fr_mul(fr_mul(x, y), z));
-                        }
-                        q0 = fr_add(q0, fr_mul(s0, coeff[k])); q2 = fr_add(q2, fr_mul(s2, coeff[k])); q3 = fr_add(q3, fr_mul(s3, coeff[k]));
-                    }
-                    part[t][0] = q0; part[t][1] = q2; part[t][2] = q3;
-                };
-                if (nt > 1) { std::function<void()> tasks[8]; for (int t = 0; t < nt; t++) tasks[t] = [&eval_share, t] { eval_share(t); }; pool.parallel(tasks, nt); }
-                else eval_share(0);
-                for (int t = 0; t < nt; t++) { c0 = fr_add(c0, part[t][0]); c2 = fr_add(c2, part[t][1]); c3 = fr_add(c3, part[t][2]); }
+                Fr hs[3]; host_tail->sums(hs);
+                c0 = hs[0]; c2 = hs[1]; c3 = hs[2];
             }
             Fr evals4[4] = {c0, fr_sub(e, c0), c2, c3}, poly[4];
             unipoly_from_evals(poly, evals4, 4);
@@ -405,21 +393,17 @@ ProductCircuitEvalProofBatched pcbatch_prove(DevCtx &c, Circuits &C, const std::
                 }
             }
             if (j < ndev) cj = fr_mul(cj, fr_add(fr_mul(rand[j], r_j), fr_mul(fr_sub(one, rand[j]), fr_sub(one, r_j))));
-            else {
-                const size_t half = len / 2;
-                auto fold = [&](std::vector<Fr> &t) { for (size_t i = 0; i < half; i++) t[i] = fr_add(t[i], fr_mul(r_j, fr_sub(t[i + half], t[i]))); t.resize(half); };
-                const int nt = (half * (size_t)ni >= 64) ? std::min(host_threads, ni) : 1;
-                auto fold_share = [&](int t) { for (int k = t; k < ni; k += nt) { fold(tA[k]); fold(tB[k]); if (k >= np) fold(tC[k]); } if (t == nt - 1) fold(tE); };
-                if (nt > 1) { std::function<void()> tasks[8]; for (int t = 0; t < nt; t++) tasks[t] = [&fold_share, t] { fold_share(t); }; pool.parallel(tasks, nt); }
-                else fold_share(0);
-            }
+            else host_tail->fold(r_j);
             e = unipoly_eval(poly, 4, r_j);
             L.coeffs.push_back(poly[0]); L.coeffs.push_back(poly[2]); L.coeffs.push_back(poly[3]);      // UniPoly::compress
-            len /= 2;
             if (trace) {
                 const double dt = now_ms() - tr_round_start;
                 if (j < ndev && tail && j >= k0) { tr_tail_ms += dt; tr_tail_rounds++; } else if (j < ndev) { tr_launch_ms += dt; tr_launch_rounds++; } else { tr_host_ms += dt; tr_host_rounds++; }
             }
+        }
+        if (host_tail) {                                    // the tables' last elements, out of the host tail's own representation
+            if (host_tail->len() != 1) throw Error(OTTI_ERR_INTERNAL, "host sum-check tail ended early");
+            for (int k = 0; k < ni; k++) { Fr t3[3]; host_tail->last(k, t3); tA[k].assign(1, t3[0]); tB[k].assign(1, t3[1]); if (k >= np) tC[k].assign(1, t3[2]); }
         }
         if (!tail_built && sh) {                             // a layer without rounds, sharded: from the host copies
             for (int k = 0; k < ni; k++) { tA[k].assign(1, C.small[layer_id][k].first[0]); tB[k].assign(1, C.small[layer_id][k].second[0]); }

@@ -301,6 +301,17 @@ def test_host_fast_paths_agree_with_the_generic_field_code():
     oa.host_selftest(300)
 
 
+def test_host_sumcheck_tail_forms():
+    """hosttail.h: the AVX-512 IFMA form of SNARK mode's host-played sum-check rounds is compared with the scalar form inside host_selftest
+    (tables of 2 .. 256 elements, 0 .. 12 product instances and 0 .. 6 triples, extremes of the field); here: the measurement hook answers for
+    both forms, and refuses sizes outside its range"""
+    oa.host_selftest(24)
+    r = oa.host_tail_bench(12, 6, 16, threads=1, reps=3)
+    assert set(r) == {"avx512ifma", "scalar"} and r["scalar"] > 0 and r["avx512ifma"] >= 0
+    with pytest.raises(oa.SpartanError):
+        oa.host_tail_bench(12, 6, 24, threads=1, reps=1)          # not a power of two
+
+
 def test_host_paths_without_avx512_ifma():
     """OTTI_HOST_IFMA=0 (what a CPU without the instructions runs): the same self-test, and the product's host verifiers on the oracle's
     proofs of both modes — whichever of the two arithmetic paths the other tests took on this machine, this one takes the scalar one"""

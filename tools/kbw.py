@@ -24,3 +24,21 @@ for name, f, nbytes in [
 ]:
     f(); ms = min(f() for _ in range(3))
     print(f"{name:22s} n=2^{lg} {ms*1e3:9.1f} us  {nbytes/ms/1e6:8.1f} GB/s")
+# reference points from the runtime's own kernels over the same number of bytes: a pure write (hipMemsetAsync) and a device-to-device
+# copy — what a write-only kernel such as eq_evals can be compared with
+import ctypes
+hip = ctypes.CDLL("libamdhip64.so")
+def chk(rc):
+    if rc != 0: raise RuntimeError(f"HIP error {rc}")
+x, y = ctypes.c_void_p(), ctypes.c_void_p()
+chk(hip.hipMalloc(ctypes.byref(x), ctypes.c_size_t(32 * n))); chk(hip.hipMalloc(ctypes.byref(y), ctypes.c_size_t(32 * n)))
+e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
+chk(hip.hipEventCreate(ctypes.byref(e0))); chk(hip.hipEventCreate(ctypes.byref(e1)))
+def timed(fn):
+    chk(hip.hipEventRecord(e0, None)); chk(fn()); chk(hip.hipEventRecord(e1, None)); chk(hip.hipEventSynchronize(e1))
+    ms = ctypes.c_float(); chk(hip.hipEventElapsedTime(ctypes.byref(ms), e0, e1)); return ms.value
+for name, fn, nbytes in [("runtime_fill (write only)", lambda: hip.hipMemsetAsync(x, 0, ctypes.c_size_t(32 * n), None), 32 * n),
+                         ("runtime_copy (read + write)", lambda: hip.hipMemcpyAsync(y, x, ctypes.c_size_t(32 * n), 3, None), 64 * n)]:
+    timed(fn); ms = min(timed(fn) for _ in range(5))
+    print(f"{name:28s} n=2^{lg} {ms*1e3:9.1f} us  {nbytes/ms/1e6:8.1f} GB/s")
+hip.hipFree(x); hip.hipFree(y)
