@@ -287,9 +287,20 @@ static bool tail_sum_range(TailMail *h_tail, int i0, int i1, int W, unsigned lon
 #endif
             }
         }
+        // the line came in one store instruction but as two 64-byte halves nothing orders: read, check the tag, read again until it fits (normally at once)
+        Fr part[3];
+        for (unsigned tries = 0;; tries++) {
+            const unsigned long long s = __atomic_load_n(&h_tail[i].seq, __ATOMIC_ACQUIRE), tag = __atomic_load_n(&h_tail[i].tag, __ATOMIC_ACQUIRE);
+            for (int k = 0; k < 3; k++) part[k] = h_tail[i].s[k];
+            if (s == want && go_tag(s, part, 3) == tag) break;
+            if (tries > 4000000u) { if (bounded) return false; throw Error(OTTI_ERR_INTERNAL, "a sum-check round's mail never became whole"); }
+#if defined(__x86_64__)
+            _mm_pause();
+#endif
+        }
         Fr *acc = sums + 3 * (i / W);
-        if (i % W == 0) { acc[0] = h_tail[i].s[0]; acc[1] = h_tail[i].s[1]; acc[2] = h_tail[i].s[2]; }
-        else { acc[0] = fr_add(acc[0], h_tail[i].s[0]); acc[1] = fr_add(acc[1], h_tail[i].s[1]); acc[2] = fr_add(acc[2], h_tail[i].s[2]); }
+        if (i % W == 0) { acc[0] = part[0]; acc[1] = part[1]; acc[2] = part[2]; }
+        else { acc[0] = fr_add(acc[0], part[0]); acc[1] = fr_add(acc[1], part[1]); acc[2] = fr_add(acc[2], part[2]); }
     }
     return true;
 }

@@ -267,9 +267,19 @@ __device__ __forceinline__ void tail_reduce1(Fr acc, int pt, int grp, int ngrp, 
     if (threadIdx.x < 3) { Fr t = s_part[threadIdx.x][0]; for (int g = 1; g < groups; g++) t = fr_add(t, s_part[threadIdx.x][g]); s_tot[threadIdx.x] = t; }
     __syncthreads();
 }
+// s_tot: the round's sums in LDS (visible to the whole workgroup).  A round's mail is the line in one instruction (snark_dev.h); the hand-over
+// after the last round follows plain stores of the tables into pinned memory and keeps its release fence.
 __device__ __forceinline__ void tail_post(TailMail *m, const Fr *s_tot, bool with_sums, unsigned long long seq) {
-    if (threadIdx.x == 0) {
-        if (with_sums) for (int k = 0; k < 3; k++) m->s[k] = s_tot[k];
+    if (with_sums) {
+        if (threadIdx.x < 8) {
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            const unsigned lane = threadIdx.x;
+            u32x4 q = {0u, 0u, 0u, 0u};
+            if (lane < 6) { const Fr &x = s_tot[lane >> 1]; for (int i = 0; i < 4; i++) q[i] = x.v[4 * (lane & 1) + i]; }
+            else if (lane == 6) { const unsigned long long tag = go_tag(seq, s_tot, 3); q[0] = (uint32_t)seq; q[1] = (uint32_t)(seq >> 32); q[2] = (uint32_t)tag; q[3] = (uint32_t)(tag >> 32); }
+            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(reinterpret_cast<char *>(m) + 16 * lane), "v"(q) : "memory");
+        }
+    } else if (threadIdx.x == 0) {
         __threadfence_system();
         __hip_atomic_store(&m->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }

@@ -28,9 +28,13 @@ unsigned long long dev_pc_export(DevCtx &c, const PcList &L, size_t len, bool fo
 // is materialised in LDS here (a real third table, folded like the others; the host multiplies by the factor accumulated before).
 // No launch, no HBM round trip, no inter-workgroup hand-off per round: a round costs the host's hash plus ~3 us of arithmetic.
 constexpr int kTailCap = 1024, kTailThreads = 1024, kTailMaxGroups = 160;
-// 128 bytes per workgroup.  (Round 4 tried mailing the sums and the number as unordered 16-byte system-scope stores validated by a tag, without the
-// release fence: the lines then reached the host 13 us LATER — stores nothing waits for linger; tools/relay_variants.sh, profiles/r4_relay_variants.txt.)
-struct TailMail { Fr s[3]; unsigned long long seq, pad[3]; };
+// 128 bytes per workgroup = one line, written by ONE store instruction (eight lanes x 16 bytes, system scope) and not followed by a fence: the three
+// sums, then (number, tag).  A release fence per mail is what a round of 128-144 workgroups waited for: all mails in after 8.3 us with
+// "96 bytes, __threadfence_system, number", 3.35 us with the whole line in one instruction (tools/pollprobe.hip, profiles/r4_pollprobe_mail.txt).
+// Nothing orders the two 64-byte halves of the line on their way: tag = go_tag(seq, s, 3) (device.h) lets the host tell a line that is not whole yet.
+// (Partial stores without a fence are no alternative: seven 16-byte stores nobody waited for reached the host 13 us later.)
+struct TailMail { Fr s[3]; unsigned long long seq, tag, pad[2]; };
+static_assert(sizeof(TailMail) == 128, "one mail = one 128-byte line");
 struct TailPlan { int W = 0; size_t k0 = 0; };                         // workgroups per instance; first round played by the tail (== ndev: no tail)
 // rounds played = log2(len0 / t_out) (>= 1).  Round j's partial sums of workgroup (w, y) arrive in c.h_tail[y * W + w] with seq = first_seq + j;
 // after the last fold the tables (t_out elements each) go to c.h_results[slot + (3 y + t) * t_out ..) and every workgroup posts first_seq + rounds.
