@@ -87,7 +87,7 @@ HD unsigned long long go_tag(unsigned long long seq, const Fr *v, int n) {
 // workgroup polling ONE line, 128 pollers kept a single HBM channel busy enough to double the latency of each poll.  Workgroup b polls copy b mod kGoCopies.
 constexpr int kGoCopies = 8;
 constexpr size_t kGoCopyStride = 4096;
-struct Armed { GoBox *host; GoBox *dev; unsigned long long want, deadline; int relay = 1; };   // relay 0: the copy's number is polled alone and the values loaded after it (OTTI_RELAY=0; A/B)   // want == 0: not armed (values come as kernel arguments); deadline in 100 MHz ticks
+struct Armed { GoBox *host; GoBox *dev; unsigned long long want, deadline; int relay = 1, pollers = 1; };   // relay 0: the copy's number is polled alone and the values loaded after it (OTTI_RELAY=0; A/B)   // want == 0: not armed (values come as kernel arguments); deadline in 100 MHz ticks
 constexpr unsigned long long kArmDeadlineTicks = 3000000000ull;   // 30 s of s_memrealtime: longer than any host stall the prover's own 20 s result wait tolerates
 constexpr size_t kArmMaxLen = 65536;                         // sum-check tables up to this length fold in <= 64 workgroups: only those launches are armed
 

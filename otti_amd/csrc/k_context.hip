@@ -191,9 +191,10 @@ hipStream_t bulk_masked_stream() {
     });
     return ms;
 }
+static int go_pollers() { static const int m = [] { const char *e = getenv("OTTI_GO_POLLERS"); int v = e ? atoi(e) : 0; return (v >= 1 && v <= 8) ? v : 1; }(); return m; }
 static int relay_mode() { static const int m = [] { const char *e = getenv("OTTI_RELAY"); return (e && e[0] == '0') ? 0 : 1; }(); return m; }
-Armed DevCtx::arm() { Armed a; a.host = d_go_alias; a.dev = d_go.p; a.want = ++go_issued; a.deadline = arm_deadline; a.relay = relay_mode(); return a; }
-Armed DevCtx::arm_many(int count) { Armed a; a.host = d_go_alias; a.dev = d_go.p; a.want = go_issued + 1; a.deadline = arm_deadline; a.relay = relay_mode(); go_issued += (unsigned long long)count; return a; }
+Armed DevCtx::arm() { Armed a; a.host = d_go_alias; a.dev = d_go.p; a.want = ++go_issued; a.deadline = arm_deadline; a.relay = relay_mode(); a.pollers = go_pollers(); return a; }
+Armed DevCtx::arm_many(int count) { Armed a; a.host = d_go_alias; a.dev = d_go.p; a.want = go_issued + 1; a.deadline = arm_deadline; a.relay = relay_mode(); a.pollers = go_pollers(); go_issued += (unsigned long long)count; return a; }
 void DevCtx::go(const Fr *v, int n) {
     if (go_published >= go_issued) throw Error(OTTI_ERR_INTERNAL, "go() without an armed launch");
     if (n > 4) n = 4;

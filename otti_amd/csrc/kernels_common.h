@@ -79,49 +79,62 @@ template <int N, bool kSystem> __device__ __forceinline__ void go_batch_load(con
                      "global_load_dwordx4 %6, %9, off offset:112 sc1\n\tglobal_load_dwordx4 %7, %9, off offset:128 sc1\n\tglobal_load_dwordx4 %8, %9, off offset:144 sc1\n\t"
                      "s_waitcnt vmcnt(0)" : "=&v"(hd), "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&v"(w[4]), "=&v"(w[5]), "=&v"(w[6]), "=&v"(w[7]) : "v"(box) : "memory");
 }
+// The leader workgroup polls the host's line with up to kGoPollers of its waves, their polls staggered: one poll is a PCIe round trip — 1.2 us alone,
+// 1.9 us measured inside the persistent launch — and with a single poller the host's go() waited 0.95 us on average (up to 1.9) just to be
+// looked at; with four the line is looked at every ~0.5 us.  The first wave to see the number (or an abort, or the deadline) decides for all.
 template <int N> __device__ __forceinline__ bool armed_fetch(const Armed &a, Fr (&v)[N]) {
     static_assert(N == 1 || N == 4, "a GoBox carries one value or four");
-    __shared__ Fr s_v[N]; __shared__ int s_ok;
-    if (threadIdx.x == 0) {
-        const bool leader = (blockIdx.x | blockIdx.y | blockIdx.z) == 0;
+    __shared__ Fr s_v[N]; __shared__ int s_state;             // 0: undecided, 1: the values are in s_v, 2: aborted / gave up, 3: a wave is writing its decision
+    const bool leader = (blockIdx.x | blockIdx.y | blockIdx.z) == 0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, pollers = leader ? min(a.pollers, (int)(blockDim.x >> 6)) : 1;
+    if (threadIdx.x == 0) s_state = 0;
+    __syncthreads();
+    if (lane == 0 && wave < pollers) {
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime(), abort_bit = 1ull << 63;   // 100 MHz
         int ok = -1;
         Fr t[N];
         for (int k = 0; k < N; k++) t[k] = fr_zero();
         go_u32x4 hd, w[8];
         if (leader) {
+            for (int i = 0; i < wave; i++) __builtin_amdgcn_s_sleep(15);                          // ~0.45 us apart
+            bool timed_out = false; unsigned polls = 0;
             while (ok < 0) {
+                if (__hip_atomic_load(&s_state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) break;      // another wave has decided
                 go_batch_load<N, true>(a.host, hd, w);
                 const unsigned long long s = (unsigned long long)hd[0] | ((unsigned long long)hd[1] << 32), tag = (unsigned long long)hd[2] | ((unsigned long long)hd[3] << 32);
                 if (s == a.want) {
                     for (int k = 0; k < N; k++) for (int i = 0; i < 4; i++) { t[k].v[i] = w[2 * k][i]; t[k].v[4 + i] = w[2 * k + 1][i]; }
                     if (go_tag(a.want, t, N) == tag) { ok = 1; break; }
                 }
+                // (the clock is looked at every 64th poll only: s_memrealtime is a round trip of its own — 0.7 us, measured as the difference between a
+                // poll loop with it, 1.9 us per iteration, and the load alone, 1.16 — and sat on the path of every poll)
                 if (s == ~0ull) ok = 0;
-                else if (__builtin_amdgcn_s_memrealtime() - t0 > a.deadline) {
-                    ok = 0;
-                    __hip_atomic_store(&a.host->timed_out, a.want, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-                } else __builtin_amdgcn_s_sleep(1);
+                else if ((++polls & 63u) == 0 && __builtin_amdgcn_s_memrealtime() - t0 > a.deadline) { ok = 0; timed_out = true; }
             }
-            // the copies for the other workgroups (device.h: kGoCopies of them): values first, then (number, tag) in one 16-byte store; nothing is
-            // waited for — a reader checks the tag as this workgroup checked the host's (an abort carries no values: its number alone says so)
-            if (a.relay == 0) {
-                if (ok) for (int k = 0; k < N; k++) store_words_sc1(&a.dev->v[k], t[k].v, 8);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_store(&a.dev->seq, ok ? a.want : (a.want | abort_bit), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else {
-                const unsigned long long s_out = ok ? a.want : (a.want | abort_bit), tag_out = ok ? go_tag(a.want, t, N) : 0ull;
-                go_u32x4 h; h[0] = (uint32_t)s_out; h[1] = (uint32_t)(s_out >> 32); h[2] = (uint32_t)tag_out; h[3] = (uint32_t)(tag_out >> 32);
-                for (int c = 0; c < kGoCopies; c++) {
-                    char *box = reinterpret_cast<char *>(a.dev) + (size_t)c * kGoCopyStride;
-                    if (ok)
-                        for (int k = 0; k < N; k++) {
-                            go_u32x4 lo, hi; for (int i = 0; i < 4; i++) { lo[i] = t[k].v[i]; hi[i] = t[k].v[4 + i]; }
-                            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1" :: "v"(box + 32 + 32 * k), "v"(lo), "v"(hi) : "memory");
-                        }
-                    asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(box), "v"(h) : "memory");
+            if (ok >= 0 && atomicCAS(&s_state, 0, 3) == 0) {
+                if (timed_out) __hip_atomic_store(&a.host->timed_out, a.want, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                // the copies for the other workgroups (device.h: kGoCopies of them): values, then (number, tag) in one 16-byte store; a reader checks
+                // the tag as this workgroup checked the host's (an abort carries no values: its number alone says so)
+                if (a.relay == 0) {
+                    if (ok) for (int k = 0; k < N; k++) store_words_sc1(&a.dev->v[k], t[k].v, 8);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __hip_atomic_store(&a.dev->seq, ok ? a.want : (a.want | abort_bit), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    const unsigned long long s_out = ok ? a.want : (a.want | abort_bit), tag_out = ok ? go_tag(a.want, t, N) : 0ull;
+                    go_u32x4 h; h[0] = (uint32_t)s_out; h[1] = (uint32_t)(s_out >> 32); h[2] = (uint32_t)tag_out; h[3] = (uint32_t)(tag_out >> 32);
+                    for (int c = 0; c < kGoCopies; c++) {
+                        char *box = reinterpret_cast<char *>(a.dev) + (size_t)c * kGoCopyStride;
+                        if (ok)
+                            for (int k = 0; k < N; k++) {
+                                go_u32x4 lo, hi; for (int i = 0; i < 4; i++) { lo[i] = t[k].v[i]; hi[i] = t[k].v[4 + i]; }
+                                asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1" :: "v"(box + 32 + 32 * k), "v"(lo), "v"(hi) : "memory");
+                            }
+                        asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(box), "v"(h) : "memory");
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (stores this wave does not wait for were seen to reach the readers microseconds later)
                 }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (stores this wave does not wait for were seen to reach the readers microseconds later)
+                for (int k = 0; k < N; k++) s_v[k] = t[k];
+                __hip_atomic_store(&s_state, ok ? 1 : 2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         } else {
             const unsigned long long backstop = a.deadline + (a.deadline >> 2);   // the leader's deadline and a margin (it reports; this only drains the grid)
@@ -131,7 +144,7 @@ template <int N> __device__ __forceinline__ bool armed_fetch(const Armed &a, Fr 
                 for (unsigned polls = 0; ok < 0; polls++) {
                     const unsigned long long s = __hip_atomic_load(&a.dev->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (s == a.want) ok = 1;
-                    else if (s == (a.want | abort_bit) || __builtin_amdgcn_s_memrealtime() - t0 > backstop) ok = 0;
+                    else if (s == (a.want | abort_bit) || ((polls & 63u) == 63u && __builtin_amdgcn_s_memrealtime() - t0 > backstop)) ok = 0;
                     else if ((polls & 0xfffu) == 0xfffu && __hip_atomic_load(&a.host->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == ~0ull) ok = 0;
                     else __builtin_amdgcn_s_sleep(1);
                 }
@@ -144,19 +157,19 @@ template <int N> __device__ __forceinline__ bool armed_fetch(const Armed &a, Fr 
                     for (int k = 0; k < N; k++) for (int i = 0; i < 4; i++) { t[k].v[i] = w[2 * k][i]; t[k].v[4 + i] = w[2 * k + 1][i]; }
                     if (go_tag(a.want, t, N) == tag) { ok = 1; break; }
                 }
-                if (s == (a.want | abort_bit) || __builtin_amdgcn_s_memrealtime() - t0 > backstop) ok = 0;
+                if (s == (a.want | abort_bit) || ((polls & 63u) == 63u && __builtin_amdgcn_s_memrealtime() - t0 > backstop)) ok = 0;
                 // a leader that is not resident (a grid larger than the CUs this process may use) cannot pass the host's abort on: look at the
                 // host word itself once in a while (one PCIe read per few thousand polls)
                 else if ((polls & 0xfffu) == 0xfffu && __hip_atomic_load(&a.host->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == ~0ull) ok = 0;
                 else __builtin_amdgcn_s_sleep(1);
             }
+            for (int k = 0; k < N; k++) s_v[k] = t[k];
+            s_state = ok ? 1 : 2;
         }
-        for (int k = 0; k < N; k++) s_v[k] = t[k];
-        s_ok = ok;
     }
     __syncthreads();
     for (int k = 0; k < N; k++) v[k] = s_v[k];
-    return s_ok != 0;
+    return s_state == 1;
 }
 
 // ------------------------------------------------------------------------------------------------ wave / block reductions of Fr

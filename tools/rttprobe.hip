@@ -20,6 +20,18 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kSamples = 1000;
 constexpr unsigned long long kGiveUp = 200000000ull;        // 2 s in 10 ns ticks: never hang the box
 
+// the same line read by ONE load instruction of `lanes` lanes x 16 bytes (what the memory pipeline makes of adjacent lanes: one 64-byte request?)
+__global__ void k_host_load_wide(const unsigned long long *line, int lanes, unsigned *out) {
+    for (int i = 0; i < kSamples; i++) {
+        u32x4 a = {0u, 0u, 0u, 0u};
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        if ((int)threadIdx.x < lanes) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(a) : "v"((const char *)line + 16 * threadIdx.x) : "memory");
+        const unsigned x = __shfl(a[0], 0) ^ __shfl(a[1], lanes - 1);
+        const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+        if (threadIdx.x == 0) out[i] = (unsigned)(t1 - t0) + (x & 0u);
+        __builtin_amdgcn_s_sleep(8);
+    }
+}
 __global__ void k_host_load(const unsigned long long *line, unsigned *out1, unsigned *out3) {
     if (threadIdx.x != 0) return;
     for (int i = 0; i < kSamples; i++) {
@@ -124,6 +136,11 @@ int main() {
     // (1)
     hipLaunchKernelGGL(k_host_load, 1, 64, 0, 0, (const unsigned long long *)line_d, out_d, out2_d); CHECK(hipDeviceSynchronize());
     report("(1) system-scope load of a pinned host line, 16 bytes", out_h); report("(1) the same, three 16-byte loads of the line in one batch (armed_fetch's poll)", out2_h);
+    for (int lanes : {1, 2, 4, 8, 10}) {
+        hipLaunchKernelGGL(k_host_load_wide, 1, 64, 0, 0, (const unsigned long long *)line_d, lanes, out_d); CHECK(hipDeviceSynchronize());
+        char what[200]; snprintf(what, sizeof what, "(1) the line read by ONE load instruction, %d lane(s) x 16 bytes", lanes);
+        report(what, out_h);
+    }
     // (2)
     unsigned long long *words; uint32_t *value; CHECK(hipMalloc((void **)&words, 512)); CHECK(hipMalloc((void **)&value, 256));
     const int pairs[3][2] = {{0, 8}, {0, 1}, {0, 4}};
