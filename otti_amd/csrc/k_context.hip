@@ -5,7 +5,7 @@
 //
 // Kernel <-> upstream hot loop [RECALL: the reference's Spartan/ submodule is empty]:
 //   k_spmv3_*            K1 sparse_mlpoly.rs SparseMatPolynomial::multiply_vec, K6 compute_eval_table_sparse (transposed copy)
-//   k_eq_small/_expand   K2 dense_mlpoly.rs EqPolynomial::evals
+//   k_eq_tree/_expand    K2 dense_mlpoly.rs EqPolynomial::evals
 //   k_sc_*               K3/K7 sumcheck.rs prove_cubic_with_additive_term / prove_quad inner loops, fused with
 //                        K4 dense_mlpoly.rs DensePolynomial::bound_poly_var_top of the previous round
 //   k_fold_top/_bot      K4/K5 bound_poly_var_top / bound_poly_var_bot

@@ -5,18 +5,53 @@ namespace otti {
 
 // ------------------------------------------------------------------------------------------------ K2 eq tables
 struct FrArgs { Fr v[13]; };
-// one workgroup builds eq(r, .) for ell <= 12 by doubling, ping-ponging between two global buffers
-__global__ __launch_bounds__(1024) void k_eq_small(FrArgs r, int ell, Fr *out, Fr *tmp) {
-    Fr *cur = (ell & 1) ? tmp : out, *nxt = (ell & 1) ? out : tmp;   // after ell swaps the result sits in `out`
-    if (threadIdx.x == 0) cur[0] = fr_one();
+// eq(r, .) over n <= 13 variables, index bits MSB-first over r: either the full table (out[0 .. 2^n)) or the "pyramid" of the tables over the
+// LAST k variables, k = 0 .. n (level k, 2^k entries, at out + 2^k - 1; level k prepends r[n-k] as the new most significant index bit) that
+// the sum-checks read their eq factors from.  One level at a time in one workgroup was 12-13 dependent steps through global memory and, at
+// 8191 products, the throughput of ONE CU: 16-26 us per launch, 41 of them on a SNARK proof's sequential path.  Here every workgroup builds
+// the two SMALL pyramids — over the last six variables and over the ones above them (at most seven) — side by side in LDS (six or seven
+// dependent steps, nine-limb products), and the large levels are outer products of the two, dealt out over all workgroups:
+//     level k > 6:  T_k[i] = U_(k-6)[i >> 6] * T_6[i & 63].
+// Up to two jobs per launch (blockIdx.y): the pair of pyramids every layer needs, or the two factors of a table over more than 13 variables.
+struct EqJob { FrArgs r; int n; int pyramid; Fr *out; };
+constexpr int kEqLow = 6, kEqTreeBlock = 256, kEqTreeGroups = 16;
+__device__ __forceinline__ Fr eq_mul9(const Fr &x, const Fr &y) { return fr9_pack_lt2l(fr9_mul(fr9_unpack5(x), fr9_unpack(y))); }   // 32 x y / 2^261 + l < 1.1 l
+__global__ __launch_bounds__(kEqTreeBlock) void k_eq_tree(EqJob j0, EqJob j1) {
+    const EqJob &J = blockIdx.y ? j1 : j0;
+    const int n = J.n, a = n < kEqLow ? n : kEqLow, b = n - a;
+    __shared__ Fr sT[2 << kEqLow], sU[256];                   // pyramids over the last a variables and over the b before them (level k at 2^k - 1)
+    if (threadIdx.x == 0) { sT[0] = fr_one(); sU[0] = fr_one(); }
     __syncthreads();
-    size_t size = 1;
-    for (int j = 0; j < ell; j++) {
-        Fr rj = r.v[j];
-        for (size_t k = threadIdx.x; k < size; k += blockDim.x) { Fr v = cur[k], hi = fr_mul(v, rj); nxt[2 * k + 1] = hi; nxt[2 * k] = fr_sub(v, hi); }
+    for (int s = 1; s <= (a > b ? a : b); s++) {
+        const int half = 1 << (s - 1), t = (int)threadIdx.x;
+        if (s <= a && t < half) { const Fr o = sT[half - 1 + t], hi = eq_mul9(o, J.r.v[n - s]); sT[2 * half - 1 + half + t] = hi; sT[2 * half - 1 + t] = fr_sub(o, hi); }
+        if (s <= b && t >= 64 && t < 64 + half) { const int i = t - 64; const Fr o = sU[half - 1 + i], hi = eq_mul9(o, J.r.v[n - a - s]); sU[2 * half - 1 + half + i] = hi; sU[2 * half - 1 + i] = fr_sub(o, hi); }
         __syncthreads();
-        Fr *t = cur; cur = nxt; nxt = t; size *= 2;
     }
+    const size_t tid = blockIdx.x * (size_t)blockDim.x + threadIdx.x, nthr = (size_t)gridDim.x * blockDim.x, lowmask = ((size_t)1 << a) - 1;
+    const Fr *Ta = sT + lowmask;                              // level a of T
+    if (J.pyramid) {
+        const size_t small = ((size_t)2 << a) - 1, total = ((size_t)2 << n) - 1;       // levels 0 .. a as they stand; the rest by products
+        if (blockIdx.x == 0) for (size_t g = threadIdx.x; g < small; g += blockDim.x) J.out[g] = sT[g];
+        for (size_t g = small + tid; g < total; g += nthr) {
+            const int k = 63 - __builtin_clzll((unsigned long long)(g + 1));           // level of pyramid entry g
+            const size_t i = g + 1 - ((size_t)1 << k);
+            J.out[g] = eq_mul9(sU[((size_t)1 << (k - a)) - 1 + (i >> a)], Ta[i & lowmask]);
+        }
+    } else {
+        const size_t total = (size_t)1 << n;
+        const Fr *Ub = sU + (((size_t)1 << b) - 1);
+        for (size_t i = tid; i < total; i += nthr) J.out[i] = b ? eq_mul9(Ub[i >> a], Ta[i & lowmask]) : Ta[i];
+    }
+}
+static void launch_eq_tree(DevCtx &c, const Fr *r0, size_t n0, bool pyr0, Fr *out0, const Fr *r1, size_t n1, bool pyr1, Fr *out1) {
+    if (n0 > 13 || n1 > 13) throw Error(OTTI_ERR_BAD_ARG, "eq table job over more than 13 variables");
+    EqJob a, b;
+    for (size_t i = 0; i < 13; i++) { a.r.v[i] = i < n0 ? r0[i] : fr_zero(); b.r.v[i] = (out1 && i < n1) ? r1[i] : fr_zero(); }
+    a.n = (int)n0; a.pyramid = pyr0 ? 1 : 0; a.out = out0; b.n = out1 ? (int)n1 : 0; b.pyramid = pyr1 ? 1 : 0; b.out = out1;
+    const size_t big = std::max(n0, out1 ? n1 : (size_t)0);
+    const unsigned groups = big > (size_t)kEqLow ? (unsigned)std::min<size_t>(kEqTreeGroups, (((size_t)2 << big) + kEqTreeBlock - 1) / kEqTreeBlock) : 1u;
+    hipLaunchKernelGGL(k_eq_tree, dim3(groups, out1 ? 2u : 1u), kEqTreeBlock, 0, c.stream, a, b);
 }
 // out[i] = hi[i >> lo_bits] * lo[i & (2^lo_bits - 1)]  (index bits are MSB-first over r, so the product of two sub-tables is the table)
 __global__ __launch_bounds__(kBlock) void k_eq_expand(const Fr *hi, const Fr *lo, int lo_bits, Fr *out, size_t n) {
@@ -25,17 +60,12 @@ __global__ __launch_bounds__(kBlock) void k_eq_expand(const Fr *hi, const Fr *lo
         out[i] = fr9_pack_lt2l(fr9_mul(fr9_unpack5(hi[i >> lo_bits]), fr9_unpack(lo[i & mask])));       // nine limbs (fr9.h): 32 hi * lo / 2^261 + l < 1.1 l
 }
 void dev_eq_evals(DevCtx &c, const Fr *r, size_t ell, Fr *out, Fr *scratch) {
-    auto small = [&](const Fr *rr, int e, Fr *dst, Fr *tmp) {
-        FrArgs a; for (int i = 0; i < 13; i++) a.v[i] = i < e ? rr[i] : fr_zero();
-        hipLaunchKernelGGL(k_eq_small, 1, 1024, 0, c.stream, a, e, dst, tmp);
-    };
     KScope ks(c, KC_EQ);
-    if (ell <= 12) { small(r, (int)ell, out, scratch); return; }
-    int lo_bits = 12, hi_bits = (int)ell - 12;
+    if (ell <= 13) { launch_eq_tree(c, r, ell, false, out, nullptr, 0, false, nullptr); return; }
+    const int lo_bits = 12, hi_bits = (int)ell - 12;
     if (hi_bits > 13) throw Error(OTTI_ERR_BAD_ARG, "eq table larger than 2^25");
-    Fr *lo = scratch, *hi = scratch + 4096, *tmp = hi + (hi_bits > 12 ? 8192 : 4096);   // scratch >= 3 * 4096 (5 * 4096 for ell = 25)
-    small(r + hi_bits, lo_bits, lo, tmp);
-    small(r, hi_bits, hi, tmp);                                          // same stream: ordered after the first use of tmp
+    Fr *lo = scratch, *hi = scratch + 4096;                               // scratch >= 3 * 4096 elements (both factors in one launch, then their product)
+    launch_eq_tree(c, r + hi_bits, lo_bits, false, lo, r, (size_t)hi_bits, false, hi);
     size_t n = (size_t)1 << ell;
     hipLaunchKernelGGL(k_eq_expand, grid_for(n), kBlock, 0, c.stream, hi, lo, lo_bits, out, n);
 }
@@ -128,7 +158,7 @@ __global__ __launch_bounds__(kBlock) void k_sc_cubic_fold_eval(Fr *A, Fr *B, Fr 
 // it never has to be stored, folded or streamed.  The round sums become  e_t = c_j * ((1 - tau_j) + t (2 tau_j - 1)) * S_t  with
 // S_t = sum_i E_j[i] * (A_t[i] B_t[i] - C_t[i]); the kernels below return S_t (three tables instead of four: a quarter less HBM
 // traffic and register pressure), the host applies the two scalar factors.  E_j[i] itself is hi[i >> lo_bits] * lo[i & mask] from the
-// two small "pyramids" of k_eq_pyramid (L2-resident), or lo[i] once at most lo_bits variables are left.
+// two small "pyramids" of k_eq_tree (L2-resident), or lo[i] once at most lo_bits variables are left.
 // ---- the same two kernels in nine 29-bit limbs (fr9.h): operands stay unpacked from load to store.  Per item they sum
 //   Q(0) += E (B_lo C_lo - D_lo),   Q(1) += E (B_hi C_hi - D_hi),   Q_inf += E (B_hi - B_lo)(C_hi - C_lo)
 // — S_t's values at 0 and 1 and its leading coefficient: every operand is a table element or a single difference, so no product needs an
@@ -179,20 +209,6 @@ __global__ __launch_bounds__(kBlock) void k_sc_cubic3_fold_eval(Fr *B, Fr *C, Fr
     }
     Fr tot[3]; acc9_canon<3>(tot, acc);
     finish_in_kernel<3, POST_CUBIC3>(tot, mb);
-}
-// "Pyramid" of eq tables over the LAST k of n variables, k = 0..n: level k (2^k entries) sits at out + 2^k - 1.  Level k prepends
-// variable v = r[n-k] as the new most significant index bit: new[i] = old[i] * (1 - v), new[2^(k-1) + i] = old[i] * v.
-// (two pyramids per launch: workgroup 1, when present, builds the second one — the pair phase one and the SNARK's layers always need)
-__global__ __launch_bounds__(1024) void k_eq_pyramid(FrArgs r0, int n0, Fr *out0, FrArgs r1, int n1, Fr *out1) {
-    const FrArgs &r = blockIdx.x ? r1 : r0; const int n = blockIdx.x ? n1 : n0; Fr *out = blockIdx.x ? out1 : out0;
-    if (threadIdx.x == 0) out[0] = fr_one();
-    __syncthreads();
-    for (int k = 1; k <= n; k++) {
-        const Fr v = r.v[n - k]; const size_t half = (size_t)1 << (k - 1);
-        const Fr *old = out + (half - 1); Fr *nw = out + (2 * half - 1);
-        for (size_t i = threadIdx.x; i < half; i += blockDim.x) { Fr o = old[i], hi = fr_mul(o, v); nw[half + i] = hi; nw[i] = fr_sub(o, hi); }
-        __syncthreads();
-    }
 }
 // ---- phase two in nine limbs: e_0 = sum A_lo B_lo and e_2 = sum (2 A_hi - A_lo)(2 B_hi - B_lo) as they stand (a third sum for the point 1
 // would cost a product; one carried-down operand costs 24 light instructions).  B goes in times 32 (radix 2^261, fr9.h).
@@ -261,11 +277,8 @@ unsigned long long dev_sc_cubic_fold_eval(DevCtx &c, Fr *A, Fr *B, Fr *C, Fr *D,
 }
 void dev_eq_pyramid(DevCtx &c, const Fr *r_host, size_t n, Fr *out) { dev_eq_pyramid2(c, r_host, n, out, nullptr, 0, nullptr); }
 void dev_eq_pyramid2(DevCtx &c, const Fr *r0_host, size_t n0, Fr *out0, const Fr *r1_host, size_t n1, Fr *out1) {
-    if (n0 > 13 || n1 > 13) throw Error(OTTI_ERR_BAD_ARG, "eq pyramid over more than 13 variables");
-    FrArgs a, b;
-    for (size_t i = 0; i < 13; i++) { a.v[i] = i < n0 ? r0_host[i] : fr_zero(); b.v[i] = (out1 && i < n1) ? r1_host[i] : fr_zero(); }
     KScope ks(c, KC_EQ);
-    hipLaunchKernelGGL(k_eq_pyramid, out1 ? 2 : 1, 1024, 0, c.stream, a, (int)n0, out0, b, (int)n1, out1);
+    launch_eq_tree(c, r0_host, n0, true, out0, r1_host, n1, true, out1);
 }
 unsigned long long dev_sc_cubic3_eval(DevCtx &c, const Fr *B, const Fr *C, const Fr *D, size_t len, const EqSrc &E, int slot) {
     size_t half = len / 2; int g = sc_grid(half); Mailbox mb = c.next_mailbox(slot);
