@@ -216,7 +216,10 @@ unsigned long long dev_sc_cubic_eval(DevCtx &c, const Fr *A, const Fr *B, const 
 unsigned long long dev_sc_cubic_fold_eval(DevCtx &c, Fr *A, Fr *B, Fr *C, Fr *D, size_t len, const Fr &r, int slot);   // len >= 4; folds to len/2, sums over the folded tables
 // phase one with the eq table factored out (see k_sumcheck.hip): E[i] = hi ? hi[i >> lo_bits] * lo[i & (2^lo_bits - 1)] : lo[i]
 struct EqSrc { const Fr *hi, *lo; int lo_bits;
-               uint32_t stride = 1, offset = 0; };   // table index of a kernel's item i is i * stride + offset (a rank's residue class of a sharded table; 1, 0 otherwise)
+               uint32_t stride = 1, offset = 0;      // table index of a kernel's item i is i * stride + offset (a rank's residue class of a sharded table; 1, 0 otherwise)
+               // one more variable ABOVE the tabulated ones (eq_at only): E[i] = (bit top_bit of i ? top : 1 - top) * table[i mod 2^top_bit].  The product
+               // circuits' pyramids leave a layer's first variable out — it is the last challenge to be drawn, and without it they are built ahead of time
+               int top_bit = -1; Fr top; };
 void dev_eq_pyramid(DevCtx &c, const Fr *r_host, size_t n, Fr *out /* 2^(n+1) - 1 elements: level k at out + 2^k - 1 */);
 void dev_eq_pyramid2(DevCtx &c, const Fr *r0_host, size_t n0, Fr *out0, const Fr *r1_host, size_t n1, Fr *out1);   // two in one launch (out1 may be null)
 unsigned long long dev_sc_cubic3_eval(DevCtx &c, const Fr *B, const Fr *C, const Fr *D, size_t len, const EqSrc &E, int slot);

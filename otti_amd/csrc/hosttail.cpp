@@ -187,6 +187,7 @@ class HostTailFr8 final : public HostTail {
     static void put(Vec &v, int lane, const Fr &x) { uint64_t l[5]; fr_to_limbs52(x, l); for (int i = 0; i < 5; i++) v.l[i][lane] = l[i]; }
     static Fr get(const Vec &v, int lane) { uint64_t l[5]; for (int i = 0; i < 5; i++) l[i] = v.l[i][lane]; return fr_from_limbs52(l); }
 
+    OTTI_FR8_FN void load_tables(int np, int nd, size_t T, const Fr *const *A, const Fr *const *B, const Fr *const *C, const Fr *E);
     OTTI_FR8_FN void sums_range(int t, int nt, size_t nv, bool single);
     OTTI_FR8_FN void combine(int nt, bool single, Fr out[3]);
     OTTI_FR8_FN void fold_range(int t, int nt, size_t nv, bool single, const uint64_t r16[5]);
@@ -194,20 +195,15 @@ public:
     HostTailFr8(int np, int nd, size_t T, const Fr *const *A, const Fr *const *B, const Fr *const *C, const Fr *E, const Fr *coeff, int threads)
         : np_(np), nup_((np + 3) / 4), nud_((nd + 3) / 4), nu_(nup_ + nud_), threads_(std::max(1, std::min(8, threads))), len_(T), nv0_(T / 2) {
         Vec zero; memset(&zero, 0, sizeof zero);
-        tabs_.assign((size_t)nu_ * 3 * nv0_, zero); ev_.assign(np ? nv0_ : 0, zero); coeff_.assign(nu_, zero); coeff_lo_.assign(nu_, zero);
+        tabs_.resize((size_t)nu_ * 3 * nv0_); ev_.resize(np ? nv0_ : 0); coeff_.assign(nu_, zero); coeff_lo_.assign(nu_, zero);
         part_.assign((size_t)8 * nu_ * 3, zero);
         const Fr two12 = fr_from_u64(4096);                  // (a b) c and the coefficient: three reductions by 2^260 where 2^256 is meant
         for (int k = 0; k < np + nd; k++) {
             const int u = unit_of(k), q = lane_of(k);
-            for (size_t e = 0; e < T; e++) {
-                const int lane = 4 * (int)(e & 1) + q;
-                put(tab(u, 0)[e / 2], lane, A[k][e]); put(tab(u, 1)[e / 2], lane, B[k][e]);
-                if (k >= np) put(tab(u, 2)[e / 2], lane, C[k][e]);
-            }
             const Fr cs = fr_mul(coeff[k], two12);
             put(coeff_[u], q, cs); put(coeff_[u], 4 + q, cs); put(coeff_lo_[u], q, cs);
         }
-        for (size_t e = 0; np && e < T; e++) for (int q = 0; q < 4; q++) put(ev_[e / 2], 4 * (int)(e & 1) + q, E[e]);
+        load_tables(np, nd, T, A, B, C, E);
         for (int u = 0; u < nu_; u++) { tables_.push_back(tab(u, 0)); tables_.push_back(tab(u, 1)); if (u >= nup_) tables_.push_back(tab(u, 2)); }
         if (np) tables_.push_back(ev_.data());
         ntab_ = (int)tables_.size();
@@ -240,6 +236,39 @@ public:
         out[0] = get(tab(u, 0)[0], q); out[1] = get(tab(u, 1)[0], q); out[2] = k < np_ ? get(ev_[0], 0) : get(tab(u, 2)[0], q);
     }
 };
+// The tables into the packed form, a vector (eight elements: two consecutive ones of four instances) at a time: the four 64-bit words of the eight
+// elements are gathered, cut into 52-bit limbs side by side and stored as five rows — element by element this cost more than a layer's arithmetic.
+OTTI_FR8 void pack8(Vec *dst, const Fr *const src[8]) {
+    long long addr[8]; for (int l = 0; l < 8; l++) addr[l] = (long long)(uintptr_t)src[l];
+    const __m512i a = _mm512_loadu_si512((const void *)addr), m = _mm512_set1_epi64((long long)M52);
+    const __m512i w0 = _mm512_i64gather_epi64(a, (const void *)0, 1), w1 = _mm512_i64gather_epi64(a, (const void *)8, 1),
+                  w2 = _mm512_i64gather_epi64(a, (const void *)16, 1), w3 = _mm512_i64gather_epi64(a, (const void *)24, 1);
+    _mm512_store_si512((void *)dst->l[0], _mm512_and_si512(w0, m));
+    _mm512_store_si512((void *)dst->l[1], _mm512_and_si512(_mm512_or_si512(_mm512_srli_epi64(w0, 52), _mm512_slli_epi64(w1, 12)), m));
+    _mm512_store_si512((void *)dst->l[2], _mm512_and_si512(_mm512_or_si512(_mm512_srli_epi64(w1, 40), _mm512_slli_epi64(w2, 24)), m));
+    _mm512_store_si512((void *)dst->l[3], _mm512_and_si512(_mm512_or_si512(_mm512_srli_epi64(w2, 28), _mm512_slli_epi64(w3, 36)), m));
+    _mm512_store_si512((void *)dst->l[4], _mm512_srli_epi64(w3, 16));
+}
+OTTI_FR8_FN void HostTailFr8::load_tables(int np, int nd, size_t T, const Fr *const *A, const Fr *const *B, const Fr *const *C, const Fr *E) {
+    static const Fr zero_fr = fr_zero();
+    for (int u = 0; u < nu_; u++) {
+        const bool triple = u >= nup_; const int k0 = triple ? np + 4 * (u - nup_) : 4 * u, kend = triple ? np + nd : np;
+        for (int t = 0; t < (triple ? 3 : 2); t++) {
+            const Fr *const *tab_src = t == 0 ? A : t == 1 ? B : C;
+            for (size_t j = 0; j < nv0_; j++) {
+                const Fr *src[8];
+                for (int l = 0; l < 8; l++) { const int k = k0 + (l & 3); src[l] = k < kend ? tab_src[k] + 2 * j + (size_t)(l >> 2) : &zero_fr; }
+                pack8(&tab(u, t)[j], src);
+            }
+        }
+        if (!triple) for (size_t j = 0; j < nv0_; j++) memset(&tab(u, 2)[j], 0, sizeof(Vec));
+    }
+    for (size_t j = 0; np && j < nv0_; j++) {
+        const Fr *src[8]; for (int l = 0; l < 8; l++) src[l] = E + 2 * j + (size_t)(l >> 2);
+        pack8(&ev_[j], src);
+    }
+    (void)T;
+}
 // items [t n / nt, (t + 1) n / nt) of the n = units x nv (unit, vector pair) items, unit-major; a pair is (vector j, vector j + nv), or the two halves
 // of vector 0 in the last round
 OTTI_FR8_FN void HostTailFr8::sums_range(int t, int nt, size_t nv, bool single) {

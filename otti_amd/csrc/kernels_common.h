@@ -211,8 +211,11 @@ __device__ __forceinline__ Pair fold_regs(const Fr &x0, const Fr &x1, const Fr &
 // eq table given as the tensor product of two small tables (k_eq_pyramid levels), or as one table once few variables are left
 __device__ __forceinline__ Fr eq_at(const EqSrc &e, size_t i) {
     i = i * e.stride + e.offset;
-    if (!e.hi) return e.lo[i];
-    return fr_mul(e.hi[i >> e.lo_bits], e.lo[i & (((size_t)1 << e.lo_bits) - 1)]);
+    const bool top = e.top_bit >= 0 && ((i >> e.top_bit) & 1);
+    if (e.top_bit >= 0) i &= ((size_t)1 << e.top_bit) - 1;
+    Fr v = !e.hi ? e.lo[i] : fr_mul(e.hi[i >> e.lo_bits], e.lo[i & (((size_t)1 << e.lo_bits) - 1)]);
+    if (e.top_bit >= 0) v = fr_mul(v, top ? e.top : fr_sub(fr_one(), e.top));
+    return v;
 }
 
 

@@ -250,6 +250,7 @@ ProductCircuitEvalProofBatched pcbatch_prove(DevCtx &c, Circuits &C, const std::
     const size_t lgt_many = lgt_env_many ? lgt_env_many : (fr8 ? 6 : 4), lgt_few = lgt_env_few ? lgt_env_few : (fr8 ? 7 : 5);
     static const bool trace = getenv("OTTI_TRACE") != nullptr;
     double tr_tail_first_ms = 0, tr_tail_sum_ms = 0, tr_tail_wait_ms = 0, tr_tail_ms = 0, tr_launch_ms = 0, tr_host_ms = 0, tr_layer0_ms = 0; size_t tr_tail_rounds = 0, tr_launch_rounds = 0, tr_host_rounds = 0, tr_tail_layers = 0;
+    bool pyr_ahead = false;                                  // the pyramids of the layer about to start are already on their way (launched at the end of the layer before)
     for (size_t li = 0; li < nl; li++) {
         const double tr_layer_start = trace ? now_ms() : 0;
         const size_t layer_id = nl - 1 - li, nr = rand.size(), h = (size_t)1 << nr;      // elements per side in this layer, one round per variable
@@ -276,15 +277,21 @@ ProductCircuitEvalProofBatched pcbatch_prove(DevCtx &c, Circuits &C, const std::
         }
         const bool tail = k0 < ndev;
         unsigned long long tail_seq = 0;
-        // eq(rand, .) on the device: pyramids over the last n_lo variables and the n_hi before them
-        const size_t n_lo = std::min<size_t>(nr, 12), n_hi = nr - n_lo;
-        if (n_hi > 13) throw Error(OTTI_ERR_BAD_ARG, "product circuit over more than 2^25 elements");
+        // eq(rand[1..], .) on the device: pyramids over the last n_lo variables and the n_hi before them.  The layer's FIRST variable is left out: no
+        // round's factor table contains it (round j uses eq over rand[j+1..]), only the persistent tail's own eq table when it starts at round 0
+        // (EqSrc.top) — and rand[0] is the last challenge to be drawn, so without it the pyramids of layer li + 1 are launched as soon as layer li's
+        // last round challenge is out (below), and run while the host absorbs the layer's claims and draws the next coefficients.
+        const size_t nv = nr ? nr - 1 : 0, n_lo = std::min<size_t>(nv, 12), n_hi = nv - n_lo;
+        if (n_hi > 13) throw Error(OTTI_ERR_BAD_ARG, "product circuit over more than 2^26 elements");
         Fr *pyr_lo = pyr, *pyr_hi = pyr + 8192;
-        if (ndev) dev_eq_pyramid2(c, rand.data() + n_hi, n_lo, pyr_lo, rand.data(), n_hi, n_hi ? pyr_hi : nullptr);
+        if (ndev && !pyr_ahead) dev_eq_pyramid2(c, rand.data() + 1 + n_hi, n_lo, pyr_lo, rand.data() + 1, n_hi, n_hi ? pyr_hi : nullptr);
+        pyr_ahead = false;
         auto eq_src = [&](size_t m) {
             EqSrc e;
-            if (m <= n_lo) { e.hi = nullptr; e.lo = pyr_lo + (((size_t)1 << m) - 1); e.lo_bits = 0; }
-            else { e.hi = pyr_hi + (((size_t)1 << (m - n_lo)) - 1); e.lo = pyr_lo + (((size_t)1 << n_lo) - 1); e.lo_bits = (int)n_lo; }
+            const size_t mt = std::min(m, nv);                   // tabulated variables
+            if (mt <= n_lo) { e.hi = nullptr; e.lo = pyr_lo + (((size_t)1 << mt) - 1); e.lo_bits = 0; }
+            else { e.hi = pyr_hi + (((size_t)1 << (mt - n_lo)) - 1); e.lo = pyr_lo + (((size_t)1 << n_lo) - 1); e.lo_bits = (int)n_lo; }
+            if (m > nv) { if (m != nv + 1 || !nr) throw Error(OTTI_ERR_INTERNAL, "eq table over more variables than the layer has"); e.top_bit = (int)nv; e.top = rand[0]; }
             e.stride = (uint32_t)G; e.offset = (uint32_t)rk;       // sharded: item i of a kernel is element i G + rk of the table
             return e;
         };
@@ -346,6 +353,7 @@ ProductCircuitEvalProofBatched pcbatch_prove(DevCtx &c, Circuits &C, const std::
                 c0 = fr_add(c0, fr_mul(f0, p0)); c2 = fr_add(c2, fr_mul(f2, p2)); c3 = fr_add(c3, fr_mul(f3, p3));
             } else {
                 if (!tail_built) {
+                    bool direct = false;
                     if (sh && ndev == 0) {                          // a layer the host plays alone: in full on every rank already (product circuits only)
                         if (C.small[layer_id].size() != (size_t)ni || C.small[layer_id][0].first.size() != T) throw Error(OTTI_ERR_INTERNAL, "sharded product circuits: a host-played layer was not gathered (host tail longer than kSmallSide)");
                         for (int k = 0; k < ni; k++) { tA[k] = C.small[layer_id][k].first; tB[k] = C.small[layer_id][k].second; }
@@ -364,16 +372,15 @@ ProductCircuitEvalProofBatched pcbatch_prove(DevCtx &c, Circuits &C, const std::
                         }
                     } else {
                     if (tail) c.wait_tail(ni * tailW, tail_seq + (ndev - k0)); else c.wait_ticket(tick[ndev]);
-                    for (int k = 0; k < ni; k++) {
-                        const Fr *base = &c.h_results[kPcTailSlot + (size_t)3 * k * T];
-                        tA[k].assign(base, base + T); tB[k].assign(base + T, base + 2 * T);
-                        if (k >= np) tC[k].assign(base + 2 * T, base + 3 * T);
-                    }
+                    direct = true;                                  // the host tail packs the tables straight out of the pinned buffer the device exported them to
                     }
                     tE = eq_evals_host(rand.data() + ndev, nr - ndev);
                     for (auto &x : tE) x = fr_mul(x, cj);
                     std::vector<const Fr *> pa(ni), pb(ni), pc(ni);
-                    for (int k = 0; k < ni; k++) { pa[k] = tA[k].data(); pb[k] = tB[k].data(); pc[k] = k >= np ? tC[k].data() : nullptr; }
+                    for (int k = 0; k < ni; k++) {
+                        const Fr *base = &c.h_results[kPcTailSlot + (size_t)3 * k * T];
+                        pa[k] = direct ? base : tA[k].data(); pb[k] = direct ? base + T : tB[k].data(); pc[k] = k < np ? nullptr : direct ? base + 2 * T : tC[k].data();
+                    }
                     host_tail = HostTail::make(np, ni - np, T, pa.data(), pb.data(), pc.data(), tE.data(), coeff.data(), host_threads);   // hosttail.h: AVX-512 IFMA where the CPU has it
                     tail_built = true;
                 }
@@ -385,6 +392,20 @@ ProductCircuitEvalProofBatched pcbatch_prove(DevCtx &c, Circuits &C, const std::
             append_unipoly(tr, poly, 4);
             const Fr r_j = tr.challenge_scalar("challenge_nextround");
             rprod.push_back(r_j);
+            if (j + 1 == nr && li + 1 < nl && j >= ndev) {
+                // the layer's last challenge: everything the NEXT layer's eq pyramids are made of (its variables 1 .. nr are this layer's challenges; its
+                // variable 0 comes after the claims below and is in no pyramid).  The device is idle — this layer's last rounds are the host's — so
+                // the launch runs under the host's closing work and the next layer's coefficient draws instead of in front of its first round.
+                const bool dotp_next = layer_id == 1 && D && D->n;
+                const int ni_next = np + (dotp_next ? D->n : 0);
+                const size_t nr_next = nr + 1, lgT_next = std::min<size_t>(nr_next, ni_next >= 8 ? lgt_many : lgt_few);
+                if (nr_next > lgT_next) {
+                    const size_t lo_next = std::min<size_t>(nr, 12), hi_next = nr - lo_next;
+                    if (hi_next > 13) throw Error(OTTI_ERR_BAD_ARG, "product circuit over more than 2^26 elements");
+                    dev_eq_pyramid2(c, rprod.data() + hi_next, lo_next, pyr, rprod.data(), hi_next, hi_next ? pyr + 8192 : nullptr);
+                    pyr_ahead = true;
+                }
+            }
             if (j < ndev) {
                 if (tail && j >= k0) c.go(&r_j, 1);              // the persistent launch folds and goes on (or exports, after its last round)
                 else {
