@@ -250,51 +250,68 @@ ProductCircuitEvalProofBatched pcbatch_prove(DevCtx &c, Circuits &C, const std::
     const size_t lgt_many = lgt_env_many ? lgt_env_many : (fr8 ? 6 : 4), lgt_few = lgt_env_few ? lgt_env_few : (fr8 ? 7 : 5);
     static const bool trace = getenv("OTTI_TRACE") != nullptr;
     double tr_tail_first_ms = 0, tr_tail_sum_ms = 0, tr_tail_wait_ms = 0, tr_tail_ms = 0, tr_launch_ms = 0, tr_host_ms = 0, tr_layer0_ms = 0; size_t tr_tail_rounds = 0, tr_launch_rounds = 0, tr_host_rounds = 0, tr_tail_layers = 0;
-    bool pyr_ahead = false;                                  // the pyramids of the layer about to start are already on their way (launched at the end of the layer before)
-    for (size_t li = 0; li < nl; li++) {
-        const double tr_layer_start = trace ? now_ms() : 0;
-        const size_t layer_id = nl - 1 - li, nr = rand.size(), h = (size_t)1 << nr;      // elements per side in this layer, one round per variable
-        const bool with_dotp = layer_id == 0 && D && D->n;
-        if (with_dotp) { if (D->len != h / G) throw Error(OTTI_ERR_INTERNAL, "dot-product circuits do not match the input layer"); claims.insert(claims.end(), dotp_evals.begin(), dotp_evals.end()); }
-        const bool on_device = layer_id < C.nl_dev;             // (sharded: the layers with sides shorter than the number of ranks exist on the host only)
-        PcList P; P.n = 0;
-        for (int i = 0; i < np; i++) { P.A[P.n] = on_device ? C.left(i, layer_id) : nullptr; P.B[P.n] = on_device ? C.right(i, layer_id) : nullptr; P.C[P.n] = nullptr; P.n++; }
-        if (with_dotp) for (int i = 0; i < D->n; i++) { P.A[P.n] = D->l[i]; P.B[P.n] = D->r[i]; P.C[P.n] = D->w[i]; P.n++; }
-        const int ni = P.n;
-        const size_t lgT = std::min<size_t>(nr, ni >= 8 ? lgt_many : lgt_few), T = (size_t)1 << lgT, ndev = nr - lgT;
-        if (sh && ndev && (T < G || !on_device)) throw Error(OTTI_ERR_INTERNAL, "sharded product circuits: more ranks than a host tail has elements");
+    // what a layer's rounds are made of, decided from its position alone (so that the NEXT layer's first launches can be issued ahead of time)
+    struct Plan { size_t layer_id = 0, nr = 0, h = 1; bool with_dotp = false, on_device = true; PcList P; int ni = 0; size_t lgT = 0, T = 1, ndev = 0, k0 = 0; int tailW = 1; bool tail = false; };
+    auto make_plan = [&](size_t li_, size_t nr_) {
+        Plan p; p.layer_id = nl - 1 - li_; p.nr = nr_; p.h = (size_t)1 << nr_;      // elements per side in this layer, one round per variable
+        p.with_dotp = p.layer_id == 0 && D && D->n;
+        p.on_device = p.layer_id < C.nl_dev;                     // (sharded: the layers with sides shorter than the number of ranks exist on the host only)
+        p.P.n = 0;
+        for (int i = 0; i < np; i++) { p.P.A[p.P.n] = p.on_device ? C.left(i, p.layer_id) : nullptr; p.P.B[p.P.n] = p.on_device ? C.right(i, p.layer_id) : nullptr; p.P.C[p.P.n] = nullptr; p.P.n++; }
+        if (p.with_dotp) for (int i = 0; i < D->n; i++) { p.P.A[p.P.n] = D->l[i]; p.P.B[p.P.n] = D->r[i]; p.P.C[p.P.n] = D->w[i]; p.P.n++; }
+        p.ni = p.P.n;
+        p.lgT = std::min<size_t>(nr_, p.ni >= 8 ? lgt_many : lgt_few); p.T = (size_t)1 << p.lgT; p.ndev = nr_ - p.lgT;
         // The persistent tail (k_pc_tail, snark_dev.h): from round k0 on — the first round whose tables fit the LDS of W workgroups per
         // instance — ONE launch plays every remaining device round.  Only while this is the process's single proof in flight (its grid
         // must be resident as a whole: the workgroups wait for the host, the host for all of them) and no kernel class it belongs to is
         // being timed; otherwise, and for the rounds before k0, a launch per round as before.
-        size_t k0 = ndev; int tailW = 1;
-        if (ndev && tail_ok && ni <= tail_groups_max) {
-            int Wmax = 1; while (2 * Wmax * ni <= tail_groups_max && (size_t)(2 * Wmax) <= T) Wmax *= 2;
+        p.k0 = p.ndev; p.tailW = 1;
+        if (p.ndev && tail_ok && p.ni <= tail_groups_max) {
+            int Wmax = 1; while (2 * Wmax * p.ni <= tail_groups_max && (size_t)(2 * Wmax) <= p.T) Wmax *= 2;
             const size_t cap_all = tail_cap * (size_t)Wmax;
-            k0 = 0; while ((h >> k0) > cap_all) k0++;
-            if (k0 >= ndev) k0 = ndev;                           // (cannot happen for cap_all >= 2 T; kept for a shrunken test capacity)
-            else { const size_t len0 = h >> k0; tailW = 1; while (tailW < Wmax && len0 / (size_t)tailW > tail_per_wg) tailW *= 2; while (len0 / (size_t)tailW > tail_cap) tailW *= 2; }
+            p.k0 = 0; while ((p.h >> p.k0) > cap_all) p.k0++;
+            if (p.k0 >= p.ndev) p.k0 = p.ndev;                   // (cannot happen for cap_all >= 2 T; kept for a shrunken test capacity)
+            else { const size_t len0 = p.h >> p.k0; p.tailW = 1; while (p.tailW < Wmax && len0 / (size_t)p.tailW > tail_per_wg) p.tailW *= 2; while (len0 / (size_t)p.tailW > tail_cap) p.tailW *= 2; }
         }
-        const bool tail = k0 < ndev;
-        unsigned long long tail_seq = 0;
-        // eq(rand[1..], .) on the device: pyramids over the last n_lo variables and the n_hi before them.  The layer's FIRST variable is left out: no
-        // round's factor table contains it (round j uses eq over rand[j+1..]), only the persistent tail's own eq table when it starts at round 0
-        // (EqSrc.top) — and rand[0] is the last challenge to be drawn, so without it the pyramids of layer li + 1 are launched as soon as layer li's
-        // last round challenge is out (below), and run while the host absorbs the layer's claims and draws the next coefficients.
-        const size_t nv = nr ? nr - 1 : 0, n_lo = std::min<size_t>(nv, 12), n_hi = nv - n_lo;
+        p.tail = p.k0 < p.ndev;
+        return p;
+    };
+    // eq(rand[1..], .) of a layer with nr variables as the round kernels read it: pyramids over the last n_lo of rand[1..] and the n_hi before them
+    Fr *const pyr_lo = pyr, *const pyr_hi = pyr + 8192;
+    auto eq_src_of = [&](size_t nr_, size_t m, const Fr *first_var) {
+        const size_t nv = nr_ ? nr_ - 1 : 0, n_lo = std::min<size_t>(nv, 12);
+        EqSrc e;
+        const size_t mt = std::min(m, nv);                       // tabulated variables
+        if (mt <= n_lo) { e.hi = nullptr; e.lo = pyr_lo + (((size_t)1 << mt) - 1); e.lo_bits = 0; }
+        else { e.hi = pyr_hi + (((size_t)1 << (mt - n_lo)) - 1); e.lo = pyr_lo + (((size_t)1 << n_lo) - 1); e.lo_bits = (int)n_lo; }
+        if (m > nv) { if (m != nv + 1 || !nr_ || !first_var) throw Error(OTTI_ERR_INTERNAL, "eq table over more variables than the layer has"); e.top_bit = (int)nv; e.top = *first_var; }
+        e.stride = (uint32_t)G; e.offset = (uint32_t)rk;           // sharded: item i of a kernel is element i G + rk of the table
+        return e;
+    };
+    auto launch_pyramids = [&](size_t nr_, const Fr *vars_from_1 /* nr_ - 1 of them */) {
+        const size_t nv = nr_ ? nr_ - 1 : 0, n_lo = std::min<size_t>(nv, 12), n_hi = nv - n_lo;
         if (n_hi > 13) throw Error(OTTI_ERR_BAD_ARG, "product circuit over more than 2^26 elements");
-        Fr *pyr_lo = pyr, *pyr_hi = pyr + 8192;
-        if (ndev && !pyr_ahead) dev_eq_pyramid2(c, rand.data() + 1 + n_hi, n_lo, pyr_lo, rand.data() + 1, n_hi, n_hi ? pyr_hi : nullptr);
+        dev_eq_pyramid2(c, vars_from_1 + n_hi, n_lo, pyr_lo, vars_from_1, n_hi, n_hi ? pyr_hi : nullptr);
+    };
+    // launched at the end of the layer before (see there): the pyramids of the layer about to start, and its first round's kernel
+    bool pyr_ahead = false, eval_ahead = false; unsigned long long eval_ahead_tick = 0;
+    for (size_t li = 0; li < nl; li++) {
+        const double tr_layer_start = trace ? now_ms() : 0;
+        Plan plan = make_plan(li, rand.size());
+        const size_t layer_id = plan.layer_id, nr = plan.nr, h = plan.h, lgT = plan.lgT, T = plan.T, ndev = plan.ndev, k0 = plan.k0;
+        const bool with_dotp = plan.with_dotp, on_device = plan.on_device, tail = plan.tail;
+        const PcList &P = plan.P; const int ni = plan.ni, tailW = plan.tailW;
+        (void)lgT;
+        if (with_dotp) { if (D->len != h / G) throw Error(OTTI_ERR_INTERNAL, "dot-product circuits do not match the input layer"); claims.insert(claims.end(), dotp_evals.begin(), dotp_evals.end()); }
+        if (sh && ndev && (T < G || !on_device)) throw Error(OTTI_ERR_INTERNAL, "sharded product circuits: more ranks than a host tail has elements");
+        unsigned long long tail_seq = 0;
+        // The layer's FIRST variable is in no pyramid: no round's factor table contains it (round j uses eq over rand[j+1..]), only the persistent
+        // tail's own eq table when it starts at round 0 (EqSrc.top) — and rand[0] is the last challenge to be drawn, so without it the pyramids of
+        // layer li + 1 (and its first round's kernel, when that is a launch of its own) are issued as soon as layer li's last round challenge is
+        // out (below) and run while the host absorbs the layer's claims and draws the next coefficients.
+        if (ndev && !pyr_ahead) launch_pyramids(nr, rand.data() + 1);
         pyr_ahead = false;
-        auto eq_src = [&](size_t m) {
-            EqSrc e;
-            const size_t mt = std::min(m, nv);                   // tabulated variables
-            if (mt <= n_lo) { e.hi = nullptr; e.lo = pyr_lo + (((size_t)1 << mt) - 1); e.lo_bits = 0; }
-            else { e.hi = pyr_hi + (((size_t)1 << (mt - n_lo)) - 1); e.lo = pyr_lo + (((size_t)1 << n_lo) - 1); e.lo_bits = (int)n_lo; }
-            if (m > nv) { if (m != nv + 1 || !nr) throw Error(OTTI_ERR_INTERNAL, "eq table over more variables than the layer has"); e.top_bit = (int)nv; e.top = rand[0]; }
-            e.stride = (uint32_t)G; e.offset = (uint32_t)rk;       // sharded: item i of a kernel is element i G + rk of the table
-            return e;
-        };
+        auto eq_src = [&](size_t m) { return eq_src_of(nr, m, nr ? rand.data() : nullptr); };
         // launch k >= 1 folds by r_{k-1} and yields the sums of round k (k < ndev) or the exported tail (k == ndev).  Armed (device.h), it is
         // queued one round ahead and starts the moment the host publishes r_{k-1}.
         auto armed = [&](size_t k) { return arm_ok && k >= 1 && k < k0 + (tail ? 0 : 1) && k <= ndev && (h >> (k - 1)) * (size_t)ni <= pc_arm_max; };   // small grids only (device.h); never the tail's own launch
@@ -306,8 +323,9 @@ ProductCircuitEvalProofBatched pcbatch_prove(DevCtx &c, Circuits &C, const std::
             tick[k] = k < ndev ? dev_pc_fold_eval(c, P, len_in, r, eq_src(nr - k - 1), kSumSlot) : dev_pc_export(c, P, len_in, true, r, kPcTailSlot);
         };
         if (tail && k0 == 0) launch_tail(nullptr);
-        else if (ndev) { tick[0] = dev_pc_eval(c, P, h / G, eq_src(nr - 1), kSumSlot); if (armed(1)) launch_for(1, nullptr); }
+        else if (ndev) { tick[0] = eval_ahead ? eval_ahead_tick : dev_pc_eval(c, P, h / G, eq_src(nr - 1), kSumSlot); if (armed(1)) launch_for(1, nullptr); }
         else if (!sh) tick[0] = dev_pc_export(c, P, h, false, nullptr, kPcTailSlot);     // (sharded: the host-only layers are in C.small already)
+        eval_ahead = false;
         std::vector<Fr> coeff = tr.challenge_vector("rand_coeffs_next_layer", claims.size());
         Fr e = fr_zero(); for (size_t k = 0; k < claims.size(); k++) e = fr_add(e, fr_mul(claims[k], coeff[k]));
         LayerProofBatched &L = pf.layers[li];
@@ -395,15 +413,16 @@ ProductCircuitEvalProofBatched pcbatch_prove(DevCtx &c, Circuits &C, const std::
             if (j + 1 == nr && li + 1 < nl && j >= ndev) {
                 // the layer's last challenge: everything the NEXT layer's eq pyramids are made of (its variables 1 .. nr are this layer's challenges; its
                 // variable 0 comes after the claims below and is in no pyramid).  The device is idle — this layer's last rounds are the host's — so
-                // the launch runs under the host's closing work and the next layer's coefficient draws instead of in front of its first round.
-                const bool dotp_next = layer_id == 1 && D && D->n;
-                const int ni_next = np + (dotp_next ? D->n : 0);
-                const size_t nr_next = nr + 1, lgT_next = std::min<size_t>(nr_next, ni_next >= 8 ? lgt_many : lgt_few);
-                if (nr_next > lgT_next) {
-                    const size_t lo_next = std::min<size_t>(nr, 12), hi_next = nr - lo_next;
-                    if (hi_next > 13) throw Error(OTTI_ERR_BAD_ARG, "product circuit over more than 2^26 elements");
-                    dev_eq_pyramid2(c, rprod.data() + hi_next, lo_next, pyr, rprod.data(), hi_next, hi_next ? pyr + 8192 : nullptr);
+                // the pyramids, and the next layer's first sums when they are a launch of their own (they read tables and pyramids only), run under
+                // the host's closing work and the next layer's coefficient draws instead of in front of its first round.
+                const Plan nx = make_plan(li + 1, nr + 1);
+                if (nx.ndev) {
+                    launch_pyramids(nx.nr, rprod.data());
                     pyr_ahead = true;
+                    if (!(nx.tail && nx.k0 == 0) && !(sh && (nx.T < G || !nx.on_device))) {
+                        eval_ahead_tick = dev_pc_eval(c, nx.P, nx.h / G, eq_src_of(nx.nr, nx.nr - 1, nullptr), kSumSlot);
+                        eval_ahead = true;
+                    }
                 }
             }
             if (j < ndev) {
