@@ -122,13 +122,17 @@ def test_snark_sweep_sizes_match_committed_oracle_digests(lg):
 
 @pytest.mark.parametrize("lg,env", [(12, {"OTTI_PC_TAIL": "0"}), (12, {"OTTI_PC_TAIL_CAP": "16"}), (12, {"OTTI_PC_TAIL_CAP": "128"}), (12, {"OTTI_ARMED": "0"}), (12, {}),
                                     (16, {"OTTI_DEREFS_AHEAD": "0"}), (16, {"OTTI_DEREFS_CUMASK": "0"}), (16, {"OTTI_DEREFS_FREE_CUS": "128"}), (16, {"OTTI_PC_LGT_MANY": "5", "OTTI_PC_LGT_FEW": "7"}),
+                                    (16, {"OTTI_HOST_FR8": "0"}), (16, {"OTTI_PC_LGT_MANY": "4", "OTTI_PC_LGT_FEW": "8"}), (16, {"OTTI_RELAY": "0"}), (16, {"OTTI_GO_POLLERS": "4"}),
+                                    (16, {"OTTI_HOST_THREADS": "1"}), (16, {"OTTI_HOST_TAIL_GRAIN": "8"}),
                                     (12, {"OTTI_TEST_TAIL_DROP": "1", "OTTI_TAIL_TIMEOUT_MS": "300"})])
 def test_persistent_tail_variants_give_the_oracles_proof(lg, env):
     """The layered sum-checks of R1CSEvalProof three ways — a launch per round (tail off / nothing armed), the persistent tail with
     its full LDS capacity (small instances: whole layers in one launch), and with a shrunken capacity (the tail then takes over tables
     that earlier launches folded in HBM, as it does at 2^16 and beyond) — must all produce the oracle's bytes (committed digests, 2^12 and
     2^16).  Likewise the row half of the derefs commitment running ahead on the helper's CU-masked stream (2^16: on by default there),
-    switched off, without the mask, with another split of the CUs, and the host tail of the sum-checks at another length."""
+    switched off, without the mask, with another split of the CUs, and the host tail of the sum-checks at other lengths, in its scalar form
+    (OTTI_HOST_FR8=0), single-threaded and with every vector pair handed to a helper thread; the armed launches' hand-over in its older form
+    (OTTI_RELAY=0) and with four pollers in the leader workgroup."""
     import os, subprocess, sys
     g = _golden_snark()[1 << lg]
     e = dict(os.environ); e.update(env)
