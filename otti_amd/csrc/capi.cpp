@@ -104,6 +104,11 @@ int32_t otti_host_selftest(uint32_t iterations) {
                 if (memcmp(a, b, 32)) throw Error(OTTI_ERR_INTERNAL, "host_msm differs from the sum of its terms");
             }
             // the host's last sum-check rounds (hosttail.h): the AVX-512 IFMA form against the scalar one on random tables of every size, both kinds of instance
+            {   // the division-step inversion against the exponentiation (the fast one falls back to the other if its own check fails: also count that it did not)
+                Fr inv_fast; const Fr inv_ref = fr_inv(s);
+                if (!fr_inv_fast_try(s, inv_fast)) throw Error(OTTI_ERR_INTERNAL, "fr_inv_fast gave up on an input");
+                if (!fr_eq(inv_ref, inv_fast)) throw Error(OTTI_ERR_INTERNAL, "fr_inv_fast differs from fr_inv");
+            }
             if (it < 128) hosttail_selftest(it);
             {   // the four-way split multiplication (verifier rounds) against the plain one
                 SplitTable st; split_table_build(st, rnd);

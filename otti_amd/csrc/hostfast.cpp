@@ -187,4 +187,110 @@ void pt_encode_fe(uint8_t out[32], const PtFe &p) {
     fp_to_bytes(out, fp_abs(fe_to_fp(fe_mul(deninv, zy))));
 }
 
+
+// ------------------------------------------------------------------------------------------------ fr_inv_fast
+namespace {
+typedef __int128 i128;
+constexpr int64_t kM62 = (int64_t)(((uint64_t)1 << 62) - 1);
+struct S62 { int64_t v[5]; };                               // sum v[i] 2^(62 i); limbs 0..3 in [0, 2^62), limb 4 signed
+struct T2x2 { int64_t u, v, q, r; };
+// l = 2^252 + 27742317777372353535851937790883648493 in signed-62 limbs, and l^-1 mod 2^62
+struct ModL { S62 m; uint64_t inv62; };
+const ModL &mod_l() {
+    static const ModL M = [] {
+        const uint64_t w[4] = {0x5812631a5cf5d3edULL, 0x14def9dea2f79cd6ULL, 0, 0x1000000000000000ULL};
+        ModL r;
+        r.m.v[0] = (int64_t)(w[0] & (uint64_t)kM62); r.m.v[1] = (int64_t)(((w[0] >> 62) | (w[1] << 2)) & (uint64_t)kM62); r.m.v[2] = (int64_t)(((w[1] >> 60) | (w[2] << 4)) & (uint64_t)kM62);
+        r.m.v[3] = (int64_t)(((w[2] >> 58) | (w[3] << 6)) & (uint64_t)kM62); r.m.v[4] = (int64_t)(w[3] >> 56);
+        uint64_t x = 1; for (int i = 0; i < 6; i++) x *= 2 - w[0] * x;        // Newton: l^-1 mod 2^64
+        r.inv62 = x & (uint64_t)kM62;
+        return r;
+    }();
+    return M;
+}
+// 62 division steps on the low words (variable time: runs of zero bits of g in one go), eta = -delta
+int64_t divsteps_62_var(int64_t eta, uint64_t f0, uint64_t g0, T2x2 &t) {
+    uint64_t u = 1, v = 0, q = 0, r = 1, f = f0, g = g0;
+    int i = 62;
+    for (;;) {
+        const int zeros = __builtin_ctzll(g | (~(uint64_t)0 << i));       // a sentinel bit stops the count at i
+        g >>= zeros; u <<= zeros; v <<= zeros; eta -= zeros; i -= zeros;
+        if (i == 0) break;
+        if (eta < 0) {                                       // delta > 0 and g odd: (f, g) <- (g, -f)
+            eta = -eta;
+            uint64_t tmp = f; f = g; g = 0 - tmp;
+            tmp = u; u = q; q = 0 - tmp;
+            tmp = v; v = r; r = 0 - tmp;
+        }
+        // g odd here: one step g <- g + f (f odd), the run of zeros it creates is taken at the top of the loop
+        g += f; q += u; r += v;
+    }
+    t.u = (int64_t)u; t.v = (int64_t)v; t.q = (int64_t)q; t.r = (int64_t)r;
+    return eta;
+}
+// (f, g) <- t (f, g) / 2^62 (exact)
+void update_fg(S62 &f, S62 &g, const T2x2 &t) {
+    i128 cf = (i128)t.u * f.v[0] + (i128)t.v * g.v[0], cg = (i128)t.q * f.v[0] + (i128)t.r * g.v[0];
+    cf >>= 62; cg >>= 62;
+    for (int i = 1; i < 5; i++) {
+        cf += (i128)t.u * f.v[i] + (i128)t.v * g.v[i]; cg += (i128)t.q * f.v[i] + (i128)t.r * g.v[i];
+        f.v[i - 1] = (int64_t)cf & kM62; cf >>= 62; g.v[i - 1] = (int64_t)cg & kM62; cg >>= 62;
+    }
+    f.v[4] = (int64_t)cf; g.v[4] = (int64_t)cg;
+}
+// (d, e) <- t (d, e) / 2^62 mod l: multiples of l are added so that the division is exact; d, e stay in (-2 l, l)
+void update_de(S62 &d, S62 &e, const T2x2 &t, const ModL &M) {
+    const int64_t sd = d.v[4] >> 63, se = e.v[4] >> 63;
+    int64_t md = (t.u & sd) + (t.v & se), me = (t.q & sd) + (t.r & se);
+    i128 cd = (i128)t.u * d.v[0] + (i128)t.v * e.v[0], ce = (i128)t.q * d.v[0] + (i128)t.r * e.v[0];
+    md -= (int64_t)((M.inv62 * (uint64_t)cd + (uint64_t)md) & (uint64_t)kM62);
+    me -= (int64_t)((M.inv62 * (uint64_t)ce + (uint64_t)me) & (uint64_t)kM62);
+    cd += (i128)M.m.v[0] * md; ce += (i128)M.m.v[0] * me;
+    cd >>= 62; ce >>= 62;
+    for (int i = 1; i < 5; i++) {
+        cd += (i128)t.u * d.v[i] + (i128)t.v * e.v[i]; ce += (i128)t.q * d.v[i] + (i128)t.r * e.v[i];
+        if (M.m.v[i]) { cd += (i128)M.m.v[i] * md; ce += (i128)M.m.v[i] * me; }
+        d.v[i - 1] = (int64_t)cd & kM62; cd >>= 62; e.v[i - 1] = (int64_t)ce & kM62; ce >>= 62;
+    }
+    d.v[4] = (int64_t)cd; e.v[4] = (int64_t)ce;
+}
+}  // namespace
+bool fr_inv_fast_try(const Fr &a, Fr &out) {
+    const ModL &M = mod_l();
+    uint64_t w[4]; memcpy(w, a.v, 32);
+    out = fr_zero();
+    if (!(w[0] | w[1] | w[2] | w[3])) return true;
+    S62 f = M.m, g, d, e;
+    g.v[0] = (int64_t)(w[0] & (uint64_t)kM62); g.v[1] = (int64_t)(((w[0] >> 62) | (w[1] << 2)) & (uint64_t)kM62); g.v[2] = (int64_t)(((w[1] >> 60) | (w[2] << 4)) & (uint64_t)kM62);
+    g.v[3] = (int64_t)(((w[2] >> 58) | (w[3] << 6)) & (uint64_t)kM62); g.v[4] = (int64_t)(w[3] >> 56);
+    for (int i = 0; i < 5; i++) { d.v[i] = 0; e.v[i] = 0; }
+    e.v[0] = 1;
+    int64_t eta = -1; bool done = false;
+    for (int it = 0; it < 24 && !done; it++) {               // (12 rounds of 62 steps suffice for 256 bits; twice that before giving up)
+        T2x2 t;
+        eta = divsteps_62_var(eta, (uint64_t)f.v[0], (uint64_t)g.v[0], t);
+        update_de(d, e, t, M);
+        update_fg(f, g, t);
+        done = !(g.v[0] | g.v[1] | g.v[2] | g.v[3] | g.v[4]);
+    }
+    bool ok = false;
+    if (done) {
+        // f = +-1: the inverse of the integer a' = a R is +-d; into [0, l), then times R^3 / R: (a R)^-1 R^2 = a^-1 R
+        const bool neg = f.v[4] < 0;
+        i128 cy = 0; int64_t r[5];
+        for (int i = 0; i < 5; i++) { cy += neg ? -(i128)d.v[i] : (i128)d.v[i]; if (i < 4) { r[i] = (int64_t)cy & kM62; cy >>= 62; } else r[4] = (int64_t)cy; }      // the top limb keeps the sign
+        for (int pass = 0; pass < 3 && r[4] < 0; pass++) { cy = 0; for (int i = 0; i < 5; i++) { cy += (i128)r[i] + M.m.v[i]; if (i < 4) { r[i] = (int64_t)cy & kM62; cy >>= 62; } else r[4] = (int64_t)cy; } }
+        if (r[4] >= 0) {
+            const uint64_t x[5] = {(uint64_t)r[0], (uint64_t)r[1], (uint64_t)r[2], (uint64_t)r[3], (uint64_t)r[4]};
+            uint64_t o[4] = {x[0] | (x[1] << 62), (x[1] >> 2) | (x[2] << 60), (x[2] >> 4) | (x[3] << 58), (x[3] >> 6) | (x[4] << 56)};
+            uint32_t w32[8]; memcpy(w32, o, 32);
+            const Fr inv_int = fr_cond_sub_l(w32, 0);          // below 2 l at worst
+            out = fr_mul(inv_int, fr_R3());
+            ok = fr_eq(fr_mul(out, a), fr_one());
+        }
+    }
+    return ok;
+}
+Fr fr_inv_fast(const Fr &a) { Fr r; return fr_inv_fast_try(a, r) ? r : fr_inv(a); }
+
 }  // namespace otti

@@ -313,7 +313,7 @@ DotProductProofLog dplog_prove_device(DevCtx &c, const DeviceGens &DG, const Gen
         CPoint Lp = point_at(c, 0), Rp = point_at(c, 1);
         tr.append_point("L", Lp.b); tr.append_point("R", Rp.b);
         pf.L_vec.push_back(Lp); pf.R_vec.push_back(Rp);
-        u = tr.challenge_scalar("u"); ui = fr_inv(u);
+        u = tr.challenge_scalar("u"); ui = fr_inv_fast(u);                 // (hostfast.h: 1.5 us instead of 8.8, once per round on the sequential path)
         if (round + 1 < n_rounds) {
             if (arm) { const Fr v4[4] = {u, ui, fr_to_raw(u), fr_to_raw(ui)}; c.go(v4, 4); if (round + 2 < n_rounds) launch_round(round + 2, true); }
             else launch_round(round + 1, false);
