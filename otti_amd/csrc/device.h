@@ -210,6 +210,7 @@ void dev_fill_zero(DevCtx &c, Fr *p, size_t n);
 void dev_spmv3(DevCtx &c, const DeviceCsrSet &m, const Fr *x, Fr *out0, Fr *out1, Fr *out2, bool combine, const Fr coef[3]);
 // ---- K2: eq tables.  r is a HOST array (challenges come from the transcript)
 void dev_eq_evals(DevCtx &c, const Fr *r_host, size_t ell, Fr *out, Fr *scratch /* >= 3 * 4096 elements; 5 * 4096 for ell = 25 */);
+void dev_eq_evals2(DevCtx &c, const Fr *r0_host, size_t ell0, Fr *out0, const Fr *r1_host, size_t ell1, Fr *out1, Fr *scratch);   // both in one launch when each has at most 13 variables
 // ---- K3/K4/K5/K7: sum-check rounds.  Results land in c.h_results[slot .. slot+k)
 // each returns a ticket: c.wait_ticket(ticket) returns once h_results[slot..] hold that launch's sums (no stream synchronise)
 unsigned long long dev_sc_cubic_eval(DevCtx &c, const Fr *A, const Fr *B, const Fr *C, const Fr *D, size_t len, int slot);

@@ -59,6 +59,12 @@ __global__ __launch_bounds__(kBlock) void k_eq_expand(const Fr *hi, const Fr *lo
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         out[i] = fr9_pack_lt2l(fr9_mul(fr9_unpack5(hi[i >> lo_bits]), fr9_unpack(lo[i & mask])));       // nine limbs (fr9.h): 32 hi * lo / 2^261 + l < 1.1 l
 }
+// two tables of at most 13 variables each in ONE launch (the L and R halves of an evaluation point: every polynomial-evaluation proof starts with them)
+void dev_eq_evals2(DevCtx &c, const Fr *r0, size_t ell0, Fr *out0, const Fr *r1, size_t ell1, Fr *out1, Fr *scratch) {
+    if (ell0 > 13 || ell1 > 13) { dev_eq_evals(c, r0, ell0, out0, scratch); dev_eq_evals(c, r1, ell1, out1, scratch); return; }
+    KScope ks(c, KC_EQ);
+    launch_eq_tree(c, r0, ell0, false, out0, r1, ell1, false, out1);
+}
 void dev_eq_evals(DevCtx &c, const Fr *r, size_t ell, Fr *out, Fr *scratch) {
     KScope ks(c, KC_EQ);
     if (ell <= 13) { launch_eq_tree(c, r, ell, false, out, nullptr, 0, false, nullptr); return; }

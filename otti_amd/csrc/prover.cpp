@@ -673,8 +673,7 @@ void r1cs_prove_device(Instance &I, DeviceWitness &wit, Gens &g, Transcript &tr,
     {
         const Fr *r = P.ry.data() + 1; const size_t lv = ell / 2;
         std::vector<Fr> Lv_host = eq_evals_host(r, lv);                             // L-side table also needed on the host for LZ_blind
-        dev_eq_evals(c, r, lv, S.Lv.p, S.eqs.p);
-        dev_eq_evals(c, r + lv, ell - lv, S.Rv.p, S.eqs.p);
+        dev_eq_evals2(c, r, lv, S.Lv.p, r + lv, ell - lv, S.Rv.p, S.eqs.p);
         dev_poly_bound(c, my_rows, Ll, Rsz, S.Lv.p + rk * Ll, S.LZ.p, S.bound_scratch.p);
         if (sh) {                                                                    // partial L^T Z of this rank's rows -> sum over ranks
             std::vector<Fr> lz(Rsz);

@@ -481,8 +481,7 @@ DotProductProofLog polyeval_prove_plain(DevCtx &c, Gens &gens, const PcSet &s, c
     Fr *Lv = W.get(SS_PE0 + 0, s.L), *Rv = W.get(SS_PE0 + 1, s.R), *LZ = W.get(SS_PE0 + 2, s.R), *a = W.get(SS_PE0 + 3, s.R), *sbuf = W.get(SS_PE0 + 4, s.R),
        *b2 = W.get(SS_PE0 + 5, s.R), *s2 = W.get(SS_PE0 + 6, s.R), *rows = W.get(SS_PE0 + 7, 2 * s.R), *extras = W.get(SS_PE0 + 8, 4 * (lgR + 1)),
        *eqs = W.get(SS_PE0 + 9, 5 * 4096), *bound = W.get(SS_PE0 + 10, 64 * s.R);
-    dev_eq_evals(c, r.data(), lv, Lv, eqs);
-    dev_eq_evals(c, r.data() + lv, s.num_vars - lv, Rv, eqs);
+    dev_eq_evals2(c, r.data(), lv, Lv, r.data() + lv, s.num_vars - lv, Rv, eqs);
     dev_poly_bound(c, Z, s.L, s.R, Lv, LZ, bound);
     const PcView pv = {s.h_n, s.g1, s.h1, s.R};
     const PeBufs pb = {LZ, Rv, a, sbuf, b2, s2, rows, extras};
