@@ -254,6 +254,7 @@ void dev_dot(DevCtx &c, const Fr *a, const Fr *b, size_t n, int slot);
 // One launch per round.  If fold_first, a and b (length 2*n_cur) are folded to n_cur with (u, u_inv) and s is updated; then, for
 // n_cur >= 2, the next round's c_L, c_R go to extra_out[0], extra_out[2] and the dense scalar rows sL, sR (length R each) to rows[0..2R).
 void dev_bullet_step(DevCtx &c, Fr *a, Fr *b, Fr *s, size_t R, size_t n_cur, bool fold_first, const Fr &u, const Fr &u_inv, Fr *rows, Fr *extra_out);
+void dev_bullet_finish(DevCtx &c, Fr *a, Fr *b, Fr *s, size_t R, const Fr &u, const Fr &u_inv, const Fr &d, Fr *rows, int slot_a);   // last fold (2 -> 1), a, b to result slots slot_a, slot_a + 1, rows = d s
 // One bullet-reduction round as ONE launch: applies the previous challenge (fold), derives the scalars of L and R from the round state
 // and sums both rows (fused finish; compressed L, R arrive in c.h_points[0..64) after c.wait_points(ticket)).  extra_s: 4 scalars
 // {unused, blind_L, unused, blind_R} (the c_L / c_R terms are computed in the kernel); extra_base: {Q, H}.

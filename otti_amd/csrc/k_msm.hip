@@ -715,6 +715,20 @@ __global__ __launch_bounds__(1024) void k_bullet_step(Fr *a, Fr *b, Fr *s, size_
         rows[R + j] = i < h ? fr_mul(a[i + h], sj) : fr_zero();    // R = <a_R, G_L>
     }
 }
+// The reduction's last step in one launch: the fold from length 2 to 1, the folded a and b into the pinned result buffer (slots slot_a, slot_a + 1:
+// the stream's next synchronisation or mailed result makes them visible) and rows[j] = d s[j], the scalars of delta's g_hat term — it used to be
+// a step, two copies and a scaling launch in a row on the proof's sequential path.
+__global__ __launch_bounds__(1024) void k_bullet_finish(Fr *a, Fr *b, Fr *s, size_t R, Fr u, Fr uinv, Fr d, Fr *rows, Fr *host_out) {
+    if (threadIdx.x == 0) {
+        const Fr af = fr_add(fr_mul(a[0], u), fr_mul(uinv, a[1])), bf = fr_add(fr_mul(b[0], uinv), fr_mul(u, b[1]));
+        a[0] = af; b[0] = bf; host_out[0] = af; host_out[1] = bf;
+    }
+    for (size_t j = threadIdx.x; j < R; j += blockDim.x) { const Fr sj = fr_mul(s[j], ((j & 1) == 0) ? uinv : u); s[j] = sj; rows[j] = fr_mul(sj, d); }
+}
+void dev_bullet_finish(DevCtx &c, Fr *a, Fr *b, Fr *s, size_t R, const Fr &u, const Fr &u_inv, const Fr &d, Fr *rows, int slot_a) {
+    KScope ks(c, KC_BULLET);
+    hipLaunchKernelGGL(k_bullet_finish, 1, 1024, 0, c.stream, a, b, s, R, u, u_inv, d, rows, c.d_results_alias + slot_a);
+}
 void dev_bullet_step(DevCtx &c, Fr *a, Fr *b, Fr *s, size_t R, size_t n_cur, bool fold_first, const Fr &u, const Fr &u_inv, Fr *rows, Fr *extra_out) {
     KScope ks(c, KC_BULLET);
     hipLaunchKernelGGL(k_bullet_step, 1, 1024, 0, c.stream, a, b, s, R, n_cur, (int)fold_first, u, u_inv, rows, extra_out);

@@ -287,6 +287,7 @@ DotProductProofLog dplog_prove_device(DevCtx &c, const DeviceGens &DG, const Gen
     // BulletReductionProof::prove on the original generators (see k_msm.hip)
     std::vector<Fr> ex(4 * (lgR + 1), fr_zero());
     for (size_t k = 0; k < lgR; k++) { ex[4 * k + 1] = bv1[k]; ex[4 * k + 3] = bv2[k]; }
+    ex[4 * lgR] = r_delta;                                            // delta's blind rides along (its slot is past every round's four)
     OTTI_HIP(hipMemcpyAsync(B.extras, ex.data(), ex.size() * sizeof(Fr), hipMemcpyHostToDevice, c.stream));
     // round state ping-pongs between two buffer sets: launch k reads set k&1 and writes the folded state to set (k+1)&1
     Fr *abuf[2] = {B.LZ, B.a}, *bbuf[2] = {B.Rv, B.b2}, *sbuf[2] = {B.s, B.s2};
@@ -322,13 +323,11 @@ DotProductProofLog dplog_prove_device(DevCtx &c, const DeviceGens &DG, const Gen
     }
     // last fold (length 2 -> 1) in place on the current set; s gets its final coefficients
     Fr *afin = abuf[round & 1], *bvec = bbuf[round & 1], *sfin = sbuf[round & 1];
-    if (round) dev_bullet_step(c, afin, bvec, sfin, Rsz, 1, true, u, ui, B.rows, B.extras);
-    dev_fetch(c, afin, 13, 1); dev_fetch(c, bvec, 14, 1);
-    // delta = d * g_hat + r_delta * h with g_hat = sum_j s[j] P[j]
-    dev_scale(c, sfin, d, B.rows, Rsz);
-    OTTI_HIP(hipMemcpyAsync(B.extras, &r_delta, sizeof(Fr), hipMemcpyHostToDevice, c.stream));
+    // delta = d * g_hat + r_delta * h with g_hat = sum_j s[j] P[j]: the last fold, the folded a and b for the host (slots 13, 14) and d s in one launch
+    if (round) dev_bullet_finish(c, afin, bvec, sfin, Rsz, u, ui, d, B.rows, 13);
+    else { dev_fetch(c, afin, 13, 1); dev_fetch(c, bvec, 14, 1); dev_scale(c, sfin, d, B.rows, Rsz); }
     unsigned long long tk_delta;
-    { uint32_t hb = v.h1; tk_delta = dev_msm_rows(c, DG, B.rows, Rsz, Rsz, 1, B.extras, &hb, 1); }
+    { uint32_t hb = v.h1; tk_delta = dev_msm_rows(c, DG, B.rows, Rsz, Rsz, 1, B.extras + 4 * lgR, &hb, 1); }
     c.wait_points(tk_delta);
     const Fr x_hat = c.h_results[13], a_hat = c.h_results[14];
     pf.delta = point_at(c, 0);
