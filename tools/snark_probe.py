@@ -19,3 +19,7 @@ vc = oa.ComputationCommitment.from_bytes(comm.bytes)
 for k in range(3):                                              # the first call allocates the verifier's device buffers (kept with the context)
     t0 = time.perf_counter(); p.verify(vc, i, gens, b"snark_example"); t1 = time.perf_counter()
     print(f"  verify {1e3*(t1-t0):.1f} ms", flush=True)
+# device objects go before the interpreter starts taking modules apart (under rocprofv3 a fault in the process's teardown was seen otherwise)
+del p, comm, vc, gens, inst, v, i
+import gc
+gc.collect()
