@@ -2,6 +2,8 @@
 // line itself (P pollers on the PCIe link), (b) workgroup 0 polls the host line and republishes in HBM, the others poll HBM (what armed_fetch
 // does).  Each workgroup then echoes into a pinned host line of its own (as the sum-check tail mails its partial sums); the host measures
 // the time from its store to the LAST echo, 2000 rounds, P = 1, 16, 64, 144.
+// `pollprobe.bin vram`: the host's line in fine-grained GPU memory instead (the CPU stores through the PCIe BAR, every workgroup polls local memory, no relay):
+// the stores arrive, but the polls see them after anything between 2 us and 10 ms (profiles/r4_pollprobe_vram.txt) — not usable.
 //   hipcc -O2 --offload-arch=gfx950 tools/pollprobe.hip -o tools/pollprobe.bin
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -57,12 +59,15 @@ __global__ __launch_bounds__(1024) void k_poll(const unsigned long long *door, u
         __syncthreads();
     }
 }
-static int measure(int P, int mode, int sleep, int fenced = 0, int threads = 256, int lds = 0) {
+static int measure(int P, int mode, int sleep, int fenced = 0, int threads = 256, int lds = 0, int vram_door = 0) {
     unsigned long long *door_h, *door_d, *relay; Line *echo_h, *echo_d;
-    CHECK(hipHostMalloc((void **)&door_h, 128, hipHostMallocCoherent | hipHostMallocMapped)); CHECK(hipHostGetDevicePointer((void **)&door_d, door_h, 0));
+    if (vram_door) {   // the line the host publishes in lives in the GPU's own memory (fine-grained; the CPU stores through the PCIe BAR): every workgroup polls LOCAL memory
+        CHECK(hipExtMallocWithFlags((void **)&door_d, 128, hipDeviceMallocFinegrained)); CHECK(hipMemset(door_d, 0, 128)); CHECK(hipDeviceSynchronize());
+        door_h = door_d;
+    } else { CHECK(hipHostMalloc((void **)&door_h, 128, hipHostMallocCoherent | hipHostMallocMapped)); CHECK(hipHostGetDevicePointer((void **)&door_d, door_h, 0)); }
     CHECK(hipHostMalloc((void **)&echo_h, sizeof(Line) * P, hipHostMallocCoherent | hipHostMallocMapped)); CHECK(hipHostGetDevicePointer((void **)&echo_d, echo_h, 0));
     CHECK(hipMalloc((void **)&relay, 128)); CHECK(hipMemset(relay, 0, 128));
-    memset(echo_h, 0, sizeof(Line) * P); *door_h = 0;
+    memset(echo_h, 0, sizeof(Line) * P); if (!vram_door) *door_h = 0;
     const unsigned long long rounds = 2000;
     hipStream_t st; CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     if (lds) CHECK(hipFuncSetAttribute((const void *)k_poll, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -83,15 +88,23 @@ static int measure(int P, int mode, int sleep, int fenced = 0, int threads = 256
     }
     CHECK(hipStreamSynchronize(st));
     std::sort(last.begin(), last.end()); std::sort(first.begin(), first.end());
-    printf("P=%3d %s%-58s all echoes in: median %.2f us, p10 %.2f, p90 %.2f, p99 %.2f  (workgroup 0's: median %.2f)\n", P,
-           fenced == 2 ? (threads == 1024 ? "[1024 threads, 96 KB LDS, mail = the 128-byte line in one store instruction, no fence] " : "[mail = the 128-byte line in one store instruction, no fence] ") : fenced ? (threads == 1024 ? "[1024 threads, 96 KB LDS, mail = 96 B + fence + number] " : "[mail = 96 B + fence + number] ") : "", mode == 0 ? (sleep ? "every workgroup polls the host line (s_sleep 1 between polls)" : "every workgroup polls the host line (no sleep)") : "workgroup 0 polls the host line, republishes in HBM",
+    printf("P=%3d %s%s%-58s all echoes in: median %.2f us, p10 %.2f, p90 %.2f, p99 %.2f  (workgroup 0's: median %.2f)\n", P,
+           vram_door ? "[the host's line in GPU memory, written through the BAR] " : "", fenced == 2 ? (threads == 1024 ? "[1024 threads, 96 KB LDS, mail = the 128-byte line in one store instruction, no fence] " : "[mail = the 128-byte line in one store instruction, no fence] ") : fenced ? (threads == 1024 ? "[1024 threads, 96 KB LDS, mail = 96 B + fence + number] " : "[mail = 96 B + fence + number] ") : "", mode == 0 ? (sleep ? "every workgroup polls the host line (s_sleep 1 between polls)" : "every workgroup polls the host line (no sleep)") : "workgroup 0 polls the host line, republishes in HBM",
            last[last.size() / 2], last[last.size() / 10], last[last.size() * 9 / 10], last[last.size() * 99 / 100], first[first.size() / 2]);
     (void)fenced;
-    (void)hipHostFree(door_h); (void)hipHostFree(echo_h); (void)hipFree(relay); (void)hipStreamDestroy(st);
+    if (vram_door) (void)hipFree(door_d); else (void)hipHostFree(door_h);
+    (void)hipHostFree(echo_h); (void)hipFree(relay); (void)hipStreamDestroy(st);
     return 0;
 }
-int main() {
+#include <signal.h>
+static void on_segv(int) { const char m[] = "the CPU cannot store into fine-grained GPU memory on this system (fault): no such variant here\n"; (void)!write(1, m, sizeof m - 1); _exit(0); }
+int main(int argc, char **argv) {
     const int Ps[4] = {1, 16, 64, 144};
+    if (argc > 1 && !strcmp(argv[1], "vram")) {
+        signal(SIGSEGV, on_segv); signal(SIGBUS, on_segv);
+        for (int p = 0; p < 4; p++) { if (measure(Ps[p], 0, 0, 2, 256, 0, 1) == 1) return 1; if (measure(Ps[p], 0, 0, 2, 1024, 96 * 1024, 1) == 1) return 1; if (measure(Ps[p], 1, 0, 2, 1024, 96 * 1024, 0) == 1) return 1; }
+        return 0;
+    }
     for (int p = 0; p < 4; p++) for (int mode = 0; mode < 3; mode++) { int rc = measure(Ps[p], mode == 2 ? 1 : 0, mode == 1 ? 1 : 0); if (rc == 1) return 1; }
     // the leader-and-relay form with what a round of the persistent sum-check tail mails, small and tail-sized workgroups
     for (int p = 0; p < 4; p++) { if (measure(Ps[p], 1, 0, 1) == 1) return 1; if (measure(Ps[p], 1, 0, 1, 1024, 96 * 1024) == 1) return 1; if (measure(Ps[p], 1, 0, 2) == 1) return 1; if (measure(Ps[p], 1, 0, 2, 1024, 96 * 1024) == 1) return 1; }
