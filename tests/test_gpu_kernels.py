@@ -20,8 +20,8 @@ def fr_inv(x):
     return orc.fr_from_ints([pow(v, -1, orc.L_ORDER) for v in orc.fr_to_ints(x)])
 
 
-# ------------------------------------------------------------------------------------------------ eq pyramids (k_eq_pyramid)
-@pytest.mark.parametrize("n", [0, 1, 2, 7, 12, 13])
+# ------------------------------------------------------------------------------------------------ eq pyramids (k_eq_tree: two small pyramids in LDS, the large levels as outer products)
+@pytest.mark.parametrize("n", [0, 1, 2, 5, 6, 7, 8, 12, 13])
 def test_eq_pyramid_levels_are_eq_tables_of_the_suffixes(rng, n):
     r = orc.rand_fr(rng, n)
     pyr = K.eq_pyramid(r)

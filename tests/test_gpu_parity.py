@@ -47,7 +47,7 @@ def test_canonical_roundtrip(rng):
 
 
 # ------------------------------------------------------------------------------------------------ K2 eq tables
-@pytest.mark.parametrize("ell", [0, 1, 2, 5, 10, 12, 13, 16, 25])
+@pytest.mark.parametrize("ell", [0, 1, 2, 5, 6, 7, 10, 12, 13, 14, 16, 19, 25])
 def test_eq_evals(rng, ell):
     r = orc.rand_fr(rng, ell)
     out, _ = K.eq_evals(r)
