@@ -55,7 +55,7 @@ struct DeviceGens {
 };
 
 // where a sum-check kernel's last workgroup delivers the round's totals (see finish_in_kernel)
-struct Mailbox { Fr *partials; unsigned *counter; Fr *host_results; unsigned long long *host_flag; unsigned long long seq; int slot;
+struct Mailbox { Fr *partials; unsigned *counter; Fr *host_results; unsigned long long *host_flag; unsigned long long seq; int slot; int line_mail = 0;
                  Fr *dev_results; };   // dev_results: the totals once more in HBM (same slots), for a device-side collective over them (shard.h, RCCL transport)
 
 // Armed launches.  The sequential rounds cost a launch + dispatch (10-15 us) on top of the kernel itself when the kernel can only be
@@ -87,6 +87,12 @@ HD unsigned long long go_tag(unsigned long long seq, const Fr *v, int n) {
 // workgroup polling ONE line, 128 pollers kept a single HBM channel busy enough to double the latency of each poll.  Workgroup b polls copy b mod kGoCopies.
 constexpr int kGoCopies = 8;
 constexpr size_t kGoCopyStride = 4096;
+// The completion flag lives in result slot 3 — with slots 0..2 one 128-byte line: {Fr s[3]; u64 seq; u64 tag; u64 pad[2]}.  A launch whose K <= 3
+// totals go to slot 0 mails that line with ONE store instruction and no fence (Mailbox.line_mail; the persistent tail does the same, snark_dev.h):
+// number and tag travel in one 16-byte store; the low 32 bits of the tag are the number's xor kLineMark, which tells the host that the line's
+// first half is covered by the tag (a fenced mail leaves an older tag behind, whose number does not fit) and must be checked.
+constexpr unsigned long long kLineMark = 0x5a5a5a5aull;
+HD unsigned long long line_tag(unsigned long long seq, const Fr *s3) { return (go_tag(seq, s3, 3) & ~0xffffffffull) | ((seq ^ kLineMark) & 0xffffffffull); }
 struct Armed { GoBox *host; GoBox *dev; unsigned long long want, deadline; int relay = 1, pollers = 1; };   // relay 0: the copy's number is polled alone and the values loaded after it (OTTI_RELAY=0; A/B)   // want == 0: not armed (values come as kernel arguments); deadline in 100 MHz ticks
 constexpr unsigned long long kArmDeadlineTicks = 3000000000ull;   // 30 s of s_memrealtime: longer than any host stall the prover's own 20 s result wait tolerates
 constexpr size_t kArmMaxLen = 65536;                         // sum-check tables up to this length fold in <= 64 workgroups: only those launches are armed

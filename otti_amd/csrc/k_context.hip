@@ -85,9 +85,9 @@ DevCtx &DevCtx::get() {
     auto host_alloc = [&](void **p, size_t bytes) { mail_alloc(*c, p, bytes); };
     host_alloc((void **)&c->h_results, kResultSlots * sizeof(Fr));
     OTTI_HIP(hipHostGetDevicePointer((void **)&c->d_results_alias, c->h_results, 0));
-    host_alloc((void **)&c->h_flag, 64);
-    *c->h_flag = 0;
-    OTTI_HIP(hipHostGetDevicePointer((void **)&c->d_flag_alias, c->h_flag, 0));
+    memset(c->h_results, 0, 4 * sizeof(Fr));
+    c->h_flag = reinterpret_cast<unsigned long long *>(&c->h_results[3]);         // slots 0..2 + the flag: one line (device.h, kLineMark)
+    c->d_flag_alias = reinterpret_cast<unsigned long long *>(&c->d_results_alias[3]);
     c->d_counter.alloc(1);
     OTTI_HIP(hipMemset(c->d_counter.p, 0, sizeof(unsigned)));
     c->d_counts.alloc(2);
@@ -148,7 +148,8 @@ void KStats::reset() { used = 0; for (int k = 0; k < KC_COUNT; k++) { total_ms[k
 
 Mailbox DevCtx::next_mailbox(int slot) {
     Mailbox mb; mb.partials = partials.p; mb.counter = d_counter.p; mb.host_results = d_results_alias; mb.host_flag = d_flag_alias;
-    mb.seq = ++seq; mb.slot = slot; mb.dev_results = results.p; return mb;
+    static const bool line_env = [] { const char *e = getenv("OTTI_LINE_MAIL"); return !(e && e[0] == '0'); }();
+    mb.seq = ++seq; mb.slot = slot; mb.dev_results = results.p; mb.line_mail = (line_env && slot == 0 && host_coherent) ? 1 : 0; return mb;
 }
 static std::atomic<int> g_active_proofs{0};
 ActiveProof::ActiveProof() { g_active_proofs.fetch_add(1, std::memory_order_relaxed); }
@@ -222,7 +223,21 @@ void DevCtx::wait_ticket(unsigned long long ticket) {
     volatile unsigned long long *f = h_flag;
     const auto t0 = std::chrono::steady_clock::now();
     for (unsigned spins = 0;; spins++) {
-        if (*f >= ticket) return;
+        if (*f >= ticket) {
+            // a line mail (device.h kLineMark): number and tag came in one 16-byte store, the sums' first half possibly not yet — read until the tag fits
+            if (*f == ticket && ((f[1] ^ ticket ^ kLineMark) & 0xffffffffull) == 0) {
+                for (unsigned tries = 0;; tries++) {
+                    Fr s3[3]; const unsigned long long tag = __atomic_load_n(&h_flag[1], __ATOMIC_ACQUIRE);
+                    for (int k = 0; k < 3; k++) s3[k] = h_results[k];
+                    if (line_tag(ticket, s3) == tag || *f != ticket) break;
+                    if (tries > 50000000u) throw Error(OTTI_ERR_INTERNAL, "a round's mailed line never became whole");
+#if defined(__x86_64__)
+                    _mm_pause();
+#endif
+                }
+            }
+            return;
+        }
 #if defined(__x86_64__)
         _mm_pause();
 #endif
