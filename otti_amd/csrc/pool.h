@@ -87,9 +87,18 @@ public:
         s.fn = std::move(f);
         s.state.store(1, std::memory_order_release);
     }
+    // A task its helper has not picked up by the time the caller wants the result is taken back and run by the caller: the helper is most
+    // likely off its core (it spins pinned to one core; another process's thread scheduled there costs it a time slice: proofs of 6-11 ms among
+    // the 3.0 ms ones, 0.4 % of them on a busy box, tools/outlier_probe.py) — waiting for it would be waiting for the scheduler.
     void wait(int w) {
         Slot &s = slots_[w];
-        while (s.state.load(std::memory_order_acquire) == 1) relax();
+        for (unsigned idle = 0;; idle++) {
+            const int st = s.state.load(std::memory_order_acquire);
+            if (st == 2) break;
+            // (a helper that is on its core takes a task within ~50 ns; after a microsecond or two without that, it is not)
+            if (st == 1 && idle >= 48) { int exp = 1; if (s.state.compare_exchange_strong(exp, 4, std::memory_order_acq_rel)) { s.fn(); break; } }
+            relax();
+        }
         s.state.store(0, std::memory_order_relaxed);
     }
     // run the given tasks concurrently: task 0 on the calling thread, the others on workers (falls back to inline when short of workers)
@@ -202,7 +211,11 @@ private:
         Slot &s = slots_[i];
         for (;;) {
             if (quit_.load()) return;
-            if (s.state.load(std::memory_order_acquire) == 1) { s.fn(); s.state.store(2, std::memory_order_release); continue; }
+            if (s.state.load(std::memory_order_acquire) == 1) {
+                int exp = 1;                                          // (the caller may take the task back: wait())
+                if (s.state.compare_exchange_strong(exp, 3, std::memory_order_acq_rel)) { s.fn(); s.state.store(2, std::memory_order_release); }
+                continue;
+            }
             if (active_.load(std::memory_order_relaxed) > 0) {
                 if (i < workers()) relax();
                 else std::this_thread::sleep_for(std::chrono::microseconds(20));      // over the budget of a crowded process: leave the core to a prover thread
