@@ -189,6 +189,10 @@ hipStream_t bulk_masked_stream() {
         if ((e && e[0] == '0') || ncu < 128 || words > 8 || free_words >= words) { ms = nullptr; return; }
         uint32_t mask[8]; for (int i = 0; i < 8; i++) mask[i] = (i < free_words || i >= words) ? 0u : (i == words - 1 && (ncu & 31)) ? ((1u << (ncu & 31)) - 1u) : 0xffffffffu;
         if (hipExtStreamCreateWithCUMask(&ms, (uint32_t)words, mask) != hipSuccess) { (void)hipGetLastError(); ms = nullptr; }
+        // given back before the runtime's own exit handlers run (this one is registered after them): a process that still held a CU-masked stream
+        // at exit faulted in its teardown under rocprofv3
+        static hipStream_t to_destroy; to_destroy = ms;
+        if (ms) atexit([] { if (to_destroy) { (void)hipStreamSynchronize(to_destroy); (void)hipStreamDestroy(to_destroy); to_destroy = nullptr; } });
     });
     return ms;
 }
