@@ -322,10 +322,45 @@ OTTI_FR8_FN void HostTailFr8::fold_range(int t, int nt, size_t nv, bool single, 
     const size_t n = (size_t)ntab_ * nv, i0 = n * (size_t)t / (size_t)nt, i1 = n * (size_t)(t + 1) / (size_t)nt;
     for (size_t i = i0; i < i1; i++) fold_vec(tables_[i / nv], i % nv, nv, single, r, c);
 }
+OTTI_FR8_FN void weighted_sums3_fr8(const Fr *s, const Fr *w, int n0, int n, Fr out0[3], Fr out1[3]) {
+    static const Fr zero_fr = fr_zero(), sixteen = fr_from_u64(16);      // one reduction by 2^260 where 2^256 is meant
+    const VC c = vconsts();
+    V5 acc[2][3];
+    for (int g = 0; g < 2; g++) for (int t = 0; t < 3; t++) acc[g][t] = vzero();
+    Fr w16[24];
+    for (int k = 0; k < n; k++) w16[k] = fr_mul(w[k], sixteen);
+    for (int g = 0; g < 2; g++) {
+        const int k0 = g ? n0 : 0, k1 = g ? n : n0;
+        for (int base = k0; base < k1; base += 8) {
+            const Fr *wp[8]; for (int l = 0; l < 8; l++) wp[l] = base + l < k1 ? &w16[base + l] : &zero_fr;
+            Vec wv; pack8(&wv, wp);
+            const V5 wvv = vload(&wv);
+            for (int t = 0; t < 3; t++) {
+                const Fr *sp[8]; for (int l = 0; l < 8; l++) sp[l] = base + l < k1 ? &s[3 * (base + l) + t] : &zero_fr;
+                Vec sv; pack8(&sv, sp);
+                acc[g][t] = vadd(acc[g][t], vmul(vload(&sv), wvv, c));         // each below 2 l; at most three vectors per group
+            }
+        }
+    }
+    for (int g = 0; g < 2; g++) for (int t = 0; t < 3; t++) {
+        Vec v; vstore(&v, vnorm(acc[g][t], c));
+        Fr x = fr_zero();
+        for (int lane = 0; lane < 8; lane++) { uint64_t l[5]; for (int i = 0; i < 5; i++) l[i] = v.l[i][lane]; x = fr_add(x, fr_from_limbs52(l)); }
+        (g ? out1 : out0)[t] = x;
+    }
+}
 }  // namespace
 #else
 bool host_fr8_available() { return false; }
 #endif
+void weighted_sums3(const Fr *s, const Fr *w, int n0, int n, Fr out0[3], Fr out1[3]) {
+    if (n < 0 || n > 24 || n0 < 0 || n0 > n) throw Error(OTTI_ERR_INTERNAL, "weighted sums: bad sizes");
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+    if (host_fr8_available() && n >= 6) { weighted_sums3_fr8(s, w, n0, n, out0, out1); return; }
+#endif
+    for (int t = 0; t < 3; t++) { out0[t] = fr_zero(); out1[t] = fr_zero(); }
+    for (int k = 0; k < n; k++) for (int t = 0; t < 3; t++) { Fr &a = (k < n0 ? out0 : out1)[t]; a = fr_add(a, fr_mul(s[3 * k + t], w[k])); }
+}
 
 std::unique_ptr<HostTail> HostTail::make(int np, int nd, size_t T, const Fr *const *A, const Fr *const *B, const Fr *const *C, const Fr *E, const Fr *coeff, int threads, bool force_scalar) {
     if (np < 0 || nd < 0 || np + nd < 1 || T < 2 || (T & (T - 1))) throw Error(OTTI_ERR_INTERNAL, "host sum-check tail: bad geometry");
@@ -371,6 +406,13 @@ void hosttail_selftest(uint32_t seed) {
         const Fr r = rnd_fr(ref->len() == 4 ? 1 : 5);
         ref->fold(r); got->fold(r);
         if (ref->len() != got->len()) throw Error(OTTI_ERR_INTERNAL, "host sum-check tail: lengths differ");
+    }
+    {   // the weighted sums of a device round, vector form against the plain loop
+        std::vector<Fr> s3((size_t)3 * ni); for (auto &x : s3) x = rnd_fr(3);
+        Fr a0[3], a1[3], b0[3] = {fr_zero(), fr_zero(), fr_zero()}, b1[3] = {fr_zero(), fr_zero(), fr_zero()};
+        weighted_sums3(s3.data(), coeff.data(), np, ni, a0, a1);
+        for (int k = 0; k < ni; k++) for (int t = 0; t < 3; t++) { Fr &x = (k < np ? b0 : b1)[t]; x = fr_add(x, fr_mul(s3[3 * k + t], coeff[k])); }
+        for (int t = 0; t < 3; t++) if (!fr_eq(a0[t], b0[t]) || !fr_eq(a1[t], b1[t])) throw Error(OTTI_ERR_INTERNAL, "weighted sums: the vector form differs from the plain loop");
     }
     for (int k = 0; k < ni; k++) {
         Fr l1[3], l2[3]; ref->last(k, l1); got->last(k, l2);

@@ -30,6 +30,9 @@ public:
     virtual const char *kind() const = 0;
 };
 bool host_fr8_available();
+// out0[t] = sum_{k < n0} w_k s[k][t], out1[t] = sum_{n0 <= k < n} w_k s[k][t] for t = 0, 1, 2 — a device round's per-instance sums (3 each) times the
+// batching coefficients, product instances and triples apart; n <= 24.  Eight products at a time where the CPU has the instructions.
+void weighted_sums3(const Fr *s, const Fr *w, int n0, int n, Fr out0[3], Fr out1[3]);
 // selftest hook (otti_host_selftest): both implementations on the same random tables; throws on the first difference
 void hosttail_selftest(uint32_t seed);
 // measurement aid (otti_host_tail_bench): microseconds per layer (every round's sums + fold) on random tables; out[0]: the vector form (0 without the instructions), out[1]: scalar

@@ -348,13 +348,9 @@ ProductCircuitEvalProofBatched pcbatch_prove(DevCtx &c, Circuits &C, const std::
                     c.wait_tail_sums(ni, tailW, tail_seq + (j - k0), inst_sums);
                     if (trace) tr_tail_wait_ms += now_ms() - tw;
                 }
-                Fr p0 = fr_zero(), p2 = fr_zero(), p3 = fr_zero();
-                for (int k = 0; k < ni; k++) {
-                    const Fr &s0 = inst_sums[3 * k], &s2 = inst_sums[3 * k + 1], &s3 = inst_sums[3 * k + 2];
-                    Fr &a0 = k < np ? p0 : c0, &a2 = k < np ? p2 : c2, &a3 = k < np ? p3 : c3;
-                    a0 = fr_add(a0, fr_mul(s0, coeff[k])); a2 = fr_add(a2, fr_mul(s2, coeff[k])); a3 = fr_add(a3, fr_mul(s3, coeff[k]));
-                }
-                c0 = fr_add(c0, fr_mul(cj_tail, p0)); c2 = fr_add(c2, fr_mul(cj_tail, p2)); c3 = fr_add(c3, fr_mul(cj_tail, p3));
+                Fr ps[3], ds[3];                                      // the product instances' sums (they share the eq factor) and the triples', times the coefficients
+                weighted_sums3(inst_sums, coeff.data(), np, ni, ps, ds);
+                c0 = fr_add(ds[0], fr_mul(cj_tail, ps[0])); c2 = fr_add(ds[1], fr_mul(cj_tail, ps[1])); c3 = fr_add(ds[2], fr_mul(cj_tail, ps[2]));
                 if (trace) tr_tail_sum_ms += now_ms() - tr_round_start;
             } else if (j < ndev) {
                 c.wait_ticket(tick[j]);
@@ -362,13 +358,9 @@ ProductCircuitEvalProofBatched pcbatch_prove(DevCtx &c, Circuits &C, const std::
                 const Fr &tau = rand[j];
                 const Fr w0 = fr_sub(one, tau), dw = fr_sub(fr_add(tau, tau), one), w2 = fr_add(w0, fr_add(dw, dw)), w3 = fr_add(w2, dw);
                 const Fr f0 = fr_mul(cj, w0), f2 = fr_mul(cj, w2), f3 = fr_mul(cj, w3);
-                Fr p0 = fr_zero(), p2 = fr_zero(), p3 = fr_zero();                  // the product circuits share the eq factor
-                for (int k = 0; k < ni; k++) {
-                    const Fr *ev = &c.h_results[kSumSlot + 3 * k];
-                    Fr &a0 = k < np ? p0 : c0, &a2 = k < np ? p2 : c2, &a3 = k < np ? p3 : c3;
-                    a0 = fr_add(a0, fr_mul(ev[0], coeff[k])); a2 = fr_add(a2, fr_mul(ev[1], coeff[k])); a3 = fr_add(a3, fr_mul(ev[2], coeff[k]));
-                }
-                c0 = fr_add(c0, fr_mul(f0, p0)); c2 = fr_add(c2, fr_mul(f2, p2)); c3 = fr_add(c3, fr_mul(f3, p3));
+                Fr ps[3], ds[3];                                      // the product circuits share the eq factor
+                weighted_sums3(&c.h_results[kSumSlot], coeff.data(), np, ni, ps, ds);
+                c0 = fr_add(ds[0], fr_mul(f0, ps[0])); c2 = fr_add(ds[1], fr_mul(f2, ps[1])); c3 = fr_add(ds[2], fr_mul(f3, ps[2]));
             } else {
                 if (!tail_built) {
                     bool direct = false;
