@@ -99,6 +99,8 @@ constexpr size_t kArmMaxLen = 65536;                         // sum-check tables
 
 struct DevCtx {
     hipStream_t stream = nullptr;
+    hipStream_t side = nullptr; hipEvent_t ev_side = nullptr;   // a second stream for work that runs beside a latency-bound stage (SNARK mode: hash-layer evaluations beside the second batched sum-check); made on first use
+    hipStream_t side_stream();
     int device = 0, num_cu = 256;
     DevBuf<Fr> partials;                                      // [kMaxBlocks][4] per-block partial sums
     DevBuf<Fr> spmv_partial;                                  // 3 partial sums per long-row segment of the SpMV in flight
@@ -254,6 +256,8 @@ double dev_small_fraction(DevCtx &c, const Fr *z, size_t n);               // sh
 // compresses (row sum + addend)).  Lets the host draw the blinds while the device already sums the witness terms.
 // ---- K9: LZ[j] = sum_i Lv[i] * Z[i*R + j]
 void dev_poly_bound(DevCtx &c, const Fr *Z, size_t L, size_t R, const Fr *Lv, Fr *out, Fr *scratch /* >= 64*R */);
+// chunk sums of the same bound over eq(rest) alone (k_sumcheck.hip): out = (L / m) x R; false (nothing launched) when the geometry does not allow it
+bool dev_poly_bound_chunks(DevCtx &c, const Fr *Z, size_t L, size_t R, const Fr *Lv_rest, size_t m, Fr *out, Fr *scratch /* >= 64*R */);
 // dot product of two device vectors -> h_results[slot]
 void dev_dot(DevCtx &c, const Fr *a, const Fr *b, size_t n, int slot);
 // ---- K10: bullet reduction bookkeeping on the ORIGINAL generators (see prover.cpp)

@@ -146,6 +146,30 @@ void KStats::flush() {
 }
 void KStats::reset() { used = 0; for (int k = 0; k < KC_COUNT; k++) { total_ms[k] = 0; count[k] = 0; } }
 
+// A second stream for bandwidth-bound work queued beside a chain of latency-bound rounds (SNARK mode's hash-layer pass beside the memory
+// circuits' sum-check).  ONE per process, made on first use and kept, given back at exit like the bulk stream.  OTTI_SIDE_CUS=32..: confined to
+// the FIRST that many CUs (hipExtStreamCreateWithCUMask); measured at 32 / 64 / 96 against none, the rounds beside it cost the same (what they
+// lose is not CU time: profiles/r4_hash_layer_ab.txt), so the default is an ordinary stream.
+static hipStream_t side_masked_stream() {
+    static std::once_flag once; static hipStream_t ss = nullptr;
+    std::call_once(once, [] {
+        const char *e = getenv("OTTI_SIDE_CUS");
+        const int cus = e ? atoi(e) : 0, ncu = DevCtx::get().num_cu, words = (ncu + 31) / 32;
+        if (cus >= 32 && cus < ncu && words <= 8) {
+            uint32_t mask[8]; for (int i = 0; i < 8; i++) mask[i] = (i < cus / 32) ? 0xffffffffu : 0u;
+            if (hipExtStreamCreateWithCUMask(&ss, (uint32_t)words, mask) != hipSuccess) { (void)hipGetLastError(); ss = nullptr; }
+        }
+        if (!ss && hipStreamCreateWithFlags(&ss, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); ss = nullptr; }
+        static hipStream_t to_destroy; to_destroy = ss;
+        if (ss) atexit([] { if (to_destroy) { (void)hipStreamSynchronize(to_destroy); (void)hipStreamDestroy(to_destroy); to_destroy = nullptr; } });
+    });
+    return ss;
+}
+hipStream_t DevCtx::side_stream() {
+    if (!ev_side) OTTI_HIP(hipEventCreateWithFlags(&ev_side, hipEventDisableTiming));
+    if (!side) side = side_masked_stream();
+    return side;
+}
 Mailbox DevCtx::next_mailbox(int slot) {
     Mailbox mb; mb.partials = partials.p; mb.counter = d_counter.p; mb.host_results = d_results_alias; mb.host_flag = d_flag_alias;
     static const bool line_env = [] { const char *e = getenv("OTTI_LINE_MAIL"); return !(e && e[0] == '0'); }();

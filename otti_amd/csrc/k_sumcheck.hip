@@ -347,12 +347,12 @@ void dev_dot(DevCtx &c, const Fr *a, const Fr *b, size_t n, int slot) {
 }
 
 // ------------------------------------------------------------------------------------------------ K9 DensePolynomial::bound
-__global__ __launch_bounds__(kBlock) void k_poly_bound_slab(const Fr *Z, size_t L, size_t R, const Fr *Lv, size_t rows_per_slab, Fr *scratch) {
+__global__ __launch_bounds__(kBlock) void k_poly_bound_slab(const Fr *Z, size_t L, size_t R, const Fr *Lv, size_t rows_per_slab, Fr *scratch, size_t lv_mask) {
     size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (j >= R) return;
     size_t i0 = blockIdx.y * rows_per_slab, i1 = min(L, i0 + rows_per_slab);
     Fr acc = fr_zero();
-    for (size_t i = i0; i < i1; i++) acc = fr_add(acc, fr_mul(Lv[i], Z[i * R + j]));
+    for (size_t i = i0; i < i1; i++) acc = fr_add(acc, fr_mul(Lv[i & lv_mask], Z[i * R + j]));
     scratch[(size_t)blockIdx.y * R + j] = acc;
 }
 __global__ __launch_bounds__(kBlock) void k_colsum(const Fr *scratch, size_t slabs, size_t R, Fr *out) {
@@ -366,8 +366,28 @@ void dev_poly_bound(DevCtx &c, const Fr *Z, size_t L, size_t R, const Fr *Lv, Fr
     size_t slabs = std::min<size_t>(L, 64), rps = (L + slabs - 1) / slabs;
     KScope ks(c, KC_BOUND);
     dim3 grid((unsigned)((R + kBlock - 1) / kBlock), (unsigned)slabs);
-    hipLaunchKernelGGL(k_poly_bound_slab, grid, kBlock, 0, c.stream, Z, L, R, Lv, rps, scratch);
+    hipLaunchKernelGGL(k_poly_bound_slab, grid, kBlock, 0, c.stream, Z, L, R, Lv, rps, scratch, ~(size_t)0);
     hipLaunchKernelGGL(k_colsum, (unsigned)((R + kBlock - 1) / kBlock), kBlock, 0, c.stream, (const Fr *)scratch, slabs, R, out);
+}
+// The same bound in two steps, for an evaluation point whose FIRST variables are not known yet: with the left table L = eq(first a variables) x eq(rest),
+//     (L^T Z)[j] = sum_c eq(first)[c] * P_c[j],   P_c[j] = sum_i' eq(rest)[i'] Z[(c m + i') R + j]     (m = 2^(variables of rest) rows per chunk).
+// This computes the chunk sums P_c (chunks x R, out) from eq(rest) alone (Lv_rest, m entries); the caller finishes with dev_poly_bound(out, chunks, R, eq(first)).
+__global__ __launch_bounds__(kBlock) void k_colsum_groups(const Fr *scratch, size_t group, size_t R, Fr *out) {
+    size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (j >= R) return;
+    const Fr *base = scratch + (size_t)blockIdx.y * group * R;
+    Fr acc = base[j];
+    for (size_t s = 1; s < group; s++) acc = fr_add(acc, base[s * R + j]);
+    out[(size_t)blockIdx.y * R + j] = acc;
+}
+bool dev_poly_bound_chunks(DevCtx &c, const Fr *Z, size_t L, size_t R, const Fr *Lv_rest, size_t m, Fr *out, Fr *scratch) {
+    const size_t slabs = std::min<size_t>(L, 64), rps = (L + slabs - 1) / slabs;
+    if (!m || (m & (m - 1)) || m > L || L % m || m % rps || slabs * rps != L) return false;        // (chunks must be whole groups of slabs)
+    KScope ks(c, KC_BOUND);
+    dim3 grid((unsigned)((R + kBlock - 1) / kBlock), (unsigned)slabs);
+    hipLaunchKernelGGL(k_poly_bound_slab, grid, kBlock, 0, c.stream, Z, L, R, Lv_rest, rps, scratch, m - 1);
+    hipLaunchKernelGGL(k_colsum_groups, dim3((unsigned)((R + kBlock - 1) / kBlock), (unsigned)(L / m)), kBlock, 0, c.stream, (const Fr *)scratch, m / rps, R, out);
+    return true;
 }
 
 }  // namespace otti

@@ -42,7 +42,7 @@ struct SnarkScratch {
     std::vector<DevBuf<Fr>> b;
     Fr *get(size_t slot, size_t n) { if (b.size() <= slot) b.resize(slot + 1); if (b[slot].n < n) b[slot].alloc(n); return b[slot].p; }
 };
-enum { SS_MEM_RX = 0, SS_MEM_RY, SS_EQS, SS_DEREFS, SS_PARTIALS, SS_DOTP, SS_PYR, SS_EO, SS_EM, SS_PE0 /* 11 slots */, SS_OPS = SS_PE0 + 11 /* 12 */, SS_MEMC = SS_OPS + 12 /* 4 */ };
+enum { SS_MEM_RX = 0, SS_MEM_RY, SS_EQS, SS_DEREFS, SS_PARTIALS, SS_DOTP, SS_PYR, SS_EO, SS_EM, SS_PE0 /* 11 slots */, SS_OPS = SS_PE0 + 11 /* 12 */, SS_MEMC = SS_OPS + 12 /* 4 */, SS_AHEAD = SS_MEMC + 4 /* 6: chunk sums of two bounds, their left and right eq tables */ };
 static SnarkScratch &snark_workspace(DevCtx &c) { if (!c.snark_scratch) c.snark_scratch = new SnarkScratch(); return *c.snark_scratch; }
 
 namespace {
@@ -214,11 +214,12 @@ struct DotpTables { Fr *l[6], *r[6], *w[6]; size_t len = 0; int n = 0; };
 // host applies c_j * ((1 - rand_j) + t (2 rand_j - 1)).  Once the tables are down to T elements they are exported to pinned memory and
 // the host plays the last rounds itself: a launch + hand-off costs more than the arithmetic of such a round on a host core.
 constexpr int kPcTailSlot = 128;
+constexpr int kPcPreExportEnd = 7400;                       // pre-exported host-only layers end below the hash layer's ahead-of-time results (kHashEvalSlot)
 // sh (sharded SNARK::prove): the tables are this rank's residue classes (Circuits above; D: strided copies); a device round works on them
 // with the eq factor taken at the global index, its sums are added across the ranks (allreduce_fr: 3 elements per instance), and where the
 // host takes a layer over the ranks' shares of its tables are gathered and interleaved.  Host rounds run on every rank alike.
 ProductCircuitEvalProofBatched pcbatch_prove(DevCtx &c, Circuits &C, const std::vector<Fr> &evals, DotpTables *D, const std::vector<Fr> &dotp_evals, Transcript &tr,
-                                             Fr *pyr, std::vector<Fr> &rand_out, ShardComm *sh = nullptr) {
+                                             Fr *pyr, std::vector<Fr> &rand_out, ShardComm *sh = nullptr, const std::function<void()> *on_start = nullptr) {
     const int np = C.count; const size_t nl = C.nl;
     const size_t G = sh ? (size_t)sh->world() : 1, rk = sh ? (size_t)sh->rank() : 0;
     if (sh && (C.G != (int)G || C.small.size() != nl)) throw Error(OTTI_ERR_INTERNAL, "sharded product circuits were not prepared for this exchange");
@@ -295,6 +296,22 @@ ProductCircuitEvalProofBatched pcbatch_prove(DevCtx &c, Circuits &C, const std::
     };
     // launched at the end of the layer before (see there): the pyramids of the layer about to start, and its first round's kernel
     bool pyr_ahead = false, eval_ahead = false; unsigned long long eval_ahead_tick = 0;
+    // The layers the host plays alone (sides of at most T elements: the first 7 / 8 layers) are exported to pinned memory by ONE run of tiny launches
+    // queued here, each to a place of its own — not one launch and one wait at the head of each layer (layer li has li variables whatever the
+    // challenges are).  on_start (the caller's work for a second stream) is queued after them, so that they are not held up behind it.
+    // OTTI_PC_PREEXPORT=0: a launch per layer as before.
+    static const bool preexport_env = [] { const char *e = getenv("OTTI_PC_PREEXPORT"); return !(e && e[0] == '0'); }();
+    std::vector<unsigned long long> pre_tick(nl, 0); std::vector<int> pre_slot(nl, kPcTailSlot);
+    if (!sh && preexport_env) {
+        size_t at = kPcTailSlot;
+        for (size_t li = 0; li < nl; li++) {
+            const Plan p = make_plan(li, li);
+            const size_t need = (size_t)3 * p.ni * p.h;
+            if (p.ndev || !p.on_device || at + need > (size_t)kPcPreExportEnd) break;
+            pre_slot[li] = (int)at; pre_tick[li] = dev_pc_export(c, p.P, p.h, false, nullptr, (int)at); at += need;
+        }
+    }
+    if (on_start) (*on_start)();
     for (size_t li = 0; li < nl; li++) {
         const double tr_layer_start = trace ? now_ms() : 0;
         Plan plan = make_plan(li, rand.size());
@@ -324,7 +341,8 @@ ProductCircuitEvalProofBatched pcbatch_prove(DevCtx &c, Circuits &C, const std::
         };
         if (tail && k0 == 0) launch_tail(nullptr);
         else if (ndev) { tick[0] = eval_ahead ? eval_ahead_tick : dev_pc_eval(c, P, h / G, eq_src(nr - 1), kSumSlot); if (armed(1)) launch_for(1, nullptr); }
-        else if (!sh) tick[0] = dev_pc_export(c, P, h, false, nullptr, kPcTailSlot);     // (sharded: the host-only layers are in C.small already)
+        else if (!sh) tick[0] = pre_tick[li] ? pre_tick[li] : dev_pc_export(c, P, h, false, nullptr, kPcTailSlot);     // (sharded: the host-only layers are in C.small already)
+        const int layer_slot = (!ndev && pre_tick[li]) ? pre_slot[li] : kPcTailSlot;      // where this layer's exported tables are
         eval_ahead = false;
         std::vector<Fr> coeff = tr.challenge_vector("rand_coeffs_next_layer", claims.size());
         Fr e = fr_zero(); for (size_t k = 0; k < claims.size(); k++) e = fr_add(e, fr_mul(claims[k], coeff[k]));
@@ -388,7 +406,7 @@ ProductCircuitEvalProofBatched pcbatch_prove(DevCtx &c, Circuits &C, const std::
                     for (auto &x : tE) x = fr_mul(x, cj);
                     std::vector<const Fr *> pa(ni), pb(ni), pc(ni);
                     for (int k = 0; k < ni; k++) {
-                        const Fr *base = &c.h_results[kPcTailSlot + (size_t)3 * k * T];
+                        const Fr *base = &c.h_results[layer_slot + (size_t)3 * k * T];
                         pa[k] = direct ? base : tA[k].data(); pb[k] = direct ? base + T : tB[k].data(); pc[k] = k < np ? nullptr : direct ? base + 2 * T : tC[k].data();
                     }
                     host_tail = HostTail::make(np, ni - np, T, pa.data(), pb.data(), pc.data(), tE.data(), coeff.data(), host_threads);   // hosttail.h: AVX-512 IFMA where the CPU has it
@@ -441,7 +459,7 @@ ProductCircuitEvalProofBatched pcbatch_prove(DevCtx &c, Circuits &C, const std::
             for (int k = 0; k < ni; k++) { tA[k].assign(1, C.small[layer_id][k].first[0]); tB[k].assign(1, C.small[layer_id][k].second[0]); }
         } else if (!tail_built) {                            // a layer without rounds: the tables are single elements
             c.wait_ticket(tick[0]);
-            for (int k = 0; k < ni; k++) { const Fr *base = &c.h_results[kPcTailSlot + (size_t)3 * k * T]; tA[k].assign(base, base + 1); tB[k].assign(base + T, base + T + 1); if (k >= np) tC[k].assign(base + 2 * T, base + 2 * T + 1); }
+            for (int k = 0; k < ni; k++) { const Fr *base = &c.h_results[layer_slot + (size_t)3 * k * T]; tA[k].assign(base, base + 1); tB[k].assign(base + T, base + T + 1); if (k >= np) tC[k].assign(base + 2 * T, base + 2 * T + 1); }
         }
         // the tables' last elements: claims_prod (left, right per circuit; the eq table's is not sent), then the dot-product triples
         L.left.resize(np); L.right.resize(np);
@@ -465,7 +483,10 @@ ProductCircuitEvalProofBatched pcbatch_prove(DevCtx &c, Circuits &C, const std::
 }
 
 // PolyEvalProof::prove(poly, None, r, Zr, None, gens, ..) on a polynomial resident in HBM
-DotProductProofLog polyeval_prove_plain(DevCtx &c, Gens &gens, const PcSet &s, const Fr *Z, const std::vector<Fr> &r, const Fr &Zr, Transcript &tr, RandomTape &tape) {
+// chunks (optional): the bound's chunk sums over eq of the left point's variables a .. (dev_poly_bound_chunks, computed ahead of time: the point's first
+// a variables are the last to be drawn) — the bound is then a 2^a-row one over them
+DotProductProofLog polyeval_prove_plain(DevCtx &c, Gens &gens, const PcSet &s, const Fr *Z, const std::vector<Fr> &r, const Fr &Zr, Transcript &tr, RandomTape &tape,
+                                        const Fr *chunks = nullptr, size_t a_first = 0) {
     if (r.size() != s.num_vars) throw Error(OTTI_ERR_INTERNAL, "evaluation point of the wrong length");
     tr.append_protocol_name("polynomial evaluation proof");
     const size_t lv = s.num_vars / 2, lgR = ilog2(s.R);
@@ -473,8 +494,13 @@ DotProductProofLog polyeval_prove_plain(DevCtx &c, Gens &gens, const PcSet &s, c
     Fr *Lv = W.get(SS_PE0 + 0, s.L), *Rv = W.get(SS_PE0 + 1, s.R), *LZ = W.get(SS_PE0 + 2, s.R), *a = W.get(SS_PE0 + 3, s.R), *sbuf = W.get(SS_PE0 + 4, s.R),
        *b2 = W.get(SS_PE0 + 5, s.R), *s2 = W.get(SS_PE0 + 6, s.R), *rows = W.get(SS_PE0 + 7, 2 * s.R), *extras = W.get(SS_PE0 + 8, 4 * (lgR + 1)),
        *eqs = W.get(SS_PE0 + 9, 5 * 4096), *bound = W.get(SS_PE0 + 10, 64 * s.R);
-    dev_eq_evals2(c, r.data(), lv, Lv, r.data() + lv, s.num_vars - lv, Rv, eqs);
-    dev_poly_bound(c, Z, s.L, s.R, Lv, LZ, bound);
+    if (chunks) {
+        dev_eq_evals2(c, r.data(), a_first, Lv, r.data() + lv, s.num_vars - lv, Rv, eqs);
+        dev_poly_bound(c, chunks, (size_t)1 << a_first, s.R, Lv, LZ, bound);
+    } else {
+        dev_eq_evals2(c, r.data(), lv, Lv, r.data() + lv, s.num_vars - lv, Rv, eqs);
+        dev_poly_bound(c, Z, s.L, s.R, Lv, LZ, bound);
+    }
     const PcView pv = {s.h_n, s.g1, s.h1, s.R};
     const PeBufs pb = {LZ, Rv, a, sbuf, b2, s2, rows, extras};
     CPoint Cy;
@@ -572,6 +598,7 @@ static std::vector<uint8_t> snark_prove_resident_once(Instance &I, CompComm &com
     // first-use HIP objects are made BEFORE the session narrows this thread's affinity to its helpers' L3 group (pool.h hold_caller): a thread
     // the runtime starts while making them would inherit the narrowed mask for good
     if (!sh && c.num_cu >= 128) (void)bulk_masked_stream();
+    if (!sh) (void)c.side_stream();
     SpinPool::Session pool_session;
     struct Sharded { bool was; explicit Sharded(bool on) : was(t_sharded_proof) { t_sharded_proof = on; } ~Sharded() { t_sharded_proof = was; } } sharded_scope(sh != nullptr);
     if (!comm.dec) throw Error(OTTI_ERR_BAD_ARG, "this computation commitment carries no decommitment (it was parsed from bytes): SNARK::prove needs the one SNARK::encode returned");
@@ -751,12 +778,54 @@ static std::vector<uint8_t> snark_prove_resident_once(Instance &I, CompComm &com
         if (!fr_eq(fr_add(E.dotp_left[k], E.dotp_right[k]), S.inst_evals[k])) throw Error(OTTI_ERR_INTERNAL, "sparse polynomial evaluation does not match its dot-product circuits");
     }
     std::vector<Fr> rand_ops, rand_mem;
+    // The hash layer's work that depends on rand_ops alone.  The two evaluation proofs' points are [3 or 4 challenges drawn later | rand_ops] and a
+    // committed vector is one CHUNK of rows of its polynomial's matrix, so ONE pass over the 21 vectors gives both the chunk sums of the proofs' bounds
+    // (dev_poly_bound_chunks: P_c[j] = sum_i' eq(rand_ops[0 .. rest))[i'] v_c[i' R + j]) and, as dot products of length R with eq(rand_ops[rest ..]),
+    // the 21 evaluations v_c(rand_ops) themselves — instead of a pass for the evaluations (with an eq table of N elements) and one per bound (3.1 GB
+    // -> 1.6 GB at 2^20: hash layer 3.11 -> 2.93 ms).  OTTI_HASH_FUSED=0: the separate passes as before.  That pass is queued on a second stream when
+    // rand_ops comes out and runs beside the memory circuits' sum-check, a chain of short rounds (hash layer 2.93 -> 2.62 ms, those rounds + 0.07 ms:
+    // profiles/r4_hash_layer_ab.txt; with the unfused 3.1 GB the rounds lost what the layer gained).  OTTI_HASH_AHEAD=0: on the proof's own stream.
+    static const bool hash_fused_env = [] { const char *e = getenv("OTTI_HASH_FUSED"); return !(e && e[0] == '0'); }();
+    static const bool hash_ahead_env = [] { const char *e = getenv("OTTI_HASH_AHEAD"); return !(e && e[0] == '0'); }();
+    const size_t lgN_ = ilog2(N);
+    const bool hash_fused = hash_fused_env && g.derefs.num_vars == lgN_ + 3 && g.ops.num_vars == lgN_ + 4 && g.derefs.num_vars / 2 > 3 && g.ops.num_vars / 2 > 4 && g.derefs.L * g.derefs.R == 8 * N && g.ops.L * g.ops.R == 16 * N;
+    const bool hash_ahead = hash_fused && hash_ahead_env && !sh && c.side_stream();
+    Fr *chunks_d = nullptr, *chunks_o = nullptr;
+    constexpr int kHashEvalSlot = kPcPreExportEnd;                        // result slots of the 21 evaluations (clear of the round sums and the exported tails)
+    bool hash_evals_queued = false;
+    // work queued on the second stream uses this context's buffers: an exception on the way to the hash layer must not let the context go back to the pool under it
+    struct SideDrain { DevCtx &c; bool pending = false; ~SideDrain() { if (pending && c.ev_side) (void)hipEventSynchronize(c.ev_side); } } side_drain{c};
+    auto queue_hash_evals = [&] {                               // on c.stream; false (chunks_* null) when the bounds' geometry does not allow the chunked form
+        const size_t lv_d = g.derefs.num_vars / 2, lv_o = g.ops.num_vars / 2, rest_d = lv_d - 3, rest_o = lv_o - 4;
+        Fr *tab_d = W.get(SS_AHEAD + 2, (size_t)1 << rest_d), *tab_o = W.get(SS_AHEAD + 3, (size_t)1 << rest_o), *rv_d = W.get(SS_AHEAD + 4, g.derefs.R), *rv_o = W.get(SS_AHEAD + 5, g.ops.R);
+        Fr *bound = W.get(SS_PE0 + 10, 64 * std::max(g.derefs.R, g.ops.R));
+        chunks_d = W.get(SS_AHEAD, 8 * g.derefs.R); chunks_o = W.get(SS_AHEAD + 1, 16 * g.ops.R);
+        dev_eq_evals2(c, rand_ops.data(), rest_d, tab_d, rand_ops.data(), rest_o, tab_o, eqs.p);
+        if (!dev_poly_bound_chunks(c, derefs.p, g.derefs.L, g.derefs.R, tab_d, (size_t)1 << rest_d, chunks_d, bound) ||
+            !dev_poly_bound_chunks(c, d.comb_ops.p, g.ops.L, g.ops.R, tab_o, (size_t)1 << rest_o, chunks_o, bound)) { chunks_d = chunks_o = nullptr; return false; }
+        dev_eq_evals2(c, rand_ops.data() + rest_d, lgN_ - rest_d, rv_d, rand_ops.data() + rest_o, lgN_ - rest_o, rv_o, eqs.p);
+        PtrList Ld, Lo; Ld.n = 0; Lo.n = 0;
+        for (int k = 0; k < 6; k++) Ld.p[Ld.n++] = chunks_d + (size_t)k * g.derefs.R;            // = drow(0..2), dcol(0..2)
+        for (int k = 0; k < 15; k++) Lo.p[Lo.n++] = chunks_o + (size_t)k * g.ops.R;              // = d.part(p, k), p = 0..4
+        dev_dot_many(c, rv_d, Ld, g.derefs.R, partials.p, kHashEvalSlot);
+        dev_dot_many(c, rv_o, Lo, g.ops.R, partials.p, kHashEvalSlot + 6);
+        return true;
+    };
     lap("dotp copies, circuit outputs");
     {
         const Ptr pyr{W.get(SS_PYR, 2 * 8192)};
         E.proof_ops = pcbatch_prove(c, ops, ops_evals, &D, dotp_evals, tr, pyr.p, rand_ops, pc_sh);
         lap("batched proof: ops");
-        E.proof_mem = pcbatch_prove(c, mem, mem_evals, nullptr, {}, tr, pyr.p, rand_mem, pc_sh);
+        // rand_ops is out.  OTTI_HASH_AHEAD=1: the hash layer's rand_ops-only work to a second stream now (after the memory circuits' first launches)
+        const std::function<void()> queue_hash_ahead = [&] {
+            hipStream_t own = c.stream;
+            struct Restore { DevCtx &c; hipStream_t s; ~Restore() { c.stream = s; } } restore{c, own};
+            c.stream = c.side_stream();
+            hash_evals_queued = queue_hash_evals();
+            OTTI_HIP(hipEventRecord(c.ev_side, c.stream));
+            side_drain.pending = true;
+        };
+        E.proof_mem = pcbatch_prove(c, mem, mem_evals, nullptr, {}, tr, pyr.p, rand_mem, pc_sh, hash_ahead ? &queue_hash_ahead : nullptr);
         lap("batched proof: mem");
     }
     T.ms[7] = now_ms() - t0;
@@ -765,23 +834,33 @@ static std::vector<uint8_t> snark_prove_resident_once(Instance &I, CompComm &com
     t0 = now_ms();
     tr.append_protocol_name("Sparse polynomial hash layer proof");
     {   // evaluations at rand_ops of the six dereferenced vectors and the fifteen committed ones, at rand_mem of the two audit vectors
-        const Ptr Eo{W.get(SS_EO, N)}, Em{W.get(SS_EM, M)};
-        dev_eq_evals(c, rand_ops.data(), rand_ops.size(), Eo.p, eqs.p);
-        dev_eq_evals(c, rand_mem.data(), rand_mem.size(), Em.p, eqs.p);
-        PtrList Lo; Lo.n = 0;
-        for (int k = 0; k < 3; k++) Lo.p[Lo.n++] = drow(k);
-        for (int k = 0; k < 3; k++) Lo.p[Lo.n++] = dcol(k);
-        for (int p = 0; p < 5; p++) for (int k = 0; k < 3; k++) Lo.p[Lo.n++] = d.part(p, k);
-        dev_dot_many(c, Eo.p, Lo, N, partials.p, kSumSlot);
-        c.sync();
-        for (int k = 0; k < 3; k++) {
-            E.h_deref_row[k] = c.h_results[kSumSlot + k]; E.h_deref_col[k] = c.h_results[kSumSlot + 3 + k];
-            E.h_row_addr[k] = c.h_results[kSumSlot + 6 + k]; E.h_row_read_ts[k] = c.h_results[kSumSlot + 9 + k];
-            E.h_col_addr[k] = c.h_results[kSumSlot + 12 + k]; E.h_col_read_ts[k] = c.h_results[kSumSlot + 15 + k]; E.h_val[k] = c.h_results[kSumSlot + 18 + k];
+        const Ptr Em{W.get(SS_EM, M)};
+        int es = kSumSlot;
+        if (hash_ahead) {                                       // queued on the second stream when rand_ops came out
+            OTTI_HIP(hipEventSynchronize(c.ev_side));
+            OTTI_HIP(hipStreamWaitEvent(c.stream, c.ev_side, 0));
+            side_drain.pending = false;
+        } else if (hash_fused) hash_evals_queued = queue_hash_evals();
+        if (hash_evals_queued) es = kHashEvalSlot;
+        else {
+            const Ptr Eo{W.get(SS_EO, N)};
+            dev_eq_evals(c, rand_ops.data(), rand_ops.size(), Eo.p, eqs.p);
+            PtrList Lo; Lo.n = 0;
+            for (int k = 0; k < 3; k++) Lo.p[Lo.n++] = drow(k);
+            for (int k = 0; k < 3; k++) Lo.p[Lo.n++] = dcol(k);
+            for (int p = 0; p < 5; p++) for (int k = 0; k < 3; k++) Lo.p[Lo.n++] = d.part(p, k);
+            dev_dot_many(c, Eo.p, Lo, N, partials.p, kSumSlot + 8);
         }
+        if (!hash_evals_queued) es = kSumSlot + 8;
+        dev_eq_evals(c, rand_mem.data(), rand_mem.size(), Em.p, eqs.p);
         PtrList Lm; Lm.n = 2; Lm.p[0] = d.comb_mem.p; Lm.p[1] = d.comb_mem.p + M;
         dev_dot_many(c, Em.p, Lm, M, partials.p, kSumSlot);
-        c.sync();
+        c.sync();                                               // one synchronise for the 21 + 2 evaluations
+        for (int k = 0; k < 3; k++) {
+            E.h_deref_row[k] = c.h_results[es + k]; E.h_deref_col[k] = c.h_results[es + 3 + k];
+            E.h_row_addr[k] = c.h_results[es + 6 + k]; E.h_row_read_ts[k] = c.h_results[es + 9 + k];
+            E.h_col_addr[k] = c.h_results[es + 12 + k]; E.h_col_read_ts[k] = c.h_results[es + 15 + k]; E.h_val[k] = c.h_results[es + 18 + k];
+        }
         E.h_row_audit = c.h_results[kSumSlot]; E.h_col_audit = c.h_results[kSumSlot + 1];
     }
     lap("hash layer evaluations");
@@ -798,14 +877,14 @@ static std::vector<uint8_t> snark_prove_resident_once(Instance &I, CompComm &com
         std::vector<Fr> ev(8, fr_zero()), rj;
         for (int k = 0; k < 3; k++) { ev[k] = E.h_deref_row[k]; ev[3 + k] = E.h_deref_col[k]; }
         const Fr j = joint(ev, "evals_ops_val", "challenge_combine_n_to_one", "joint_claim_eval", rand_ops, rj);
-        E.pe_derefs = polyeval_prove_plain(c, *g.eval, g.derefs, derefs.p, rj, j, tr, tape);
+        E.pe_derefs = polyeval_prove_plain(c, *g.eval, g.derefs, derefs.p, rj, j, tr, tape, chunks_d, 3);
     }
     lap("polyeval derefs");
     {
         std::vector<Fr> ev(16, fr_zero()), rj;
         for (int k = 0; k < 3; k++) { ev[k] = E.h_row_addr[k]; ev[3 + k] = E.h_row_read_ts[k]; ev[6 + k] = E.h_col_addr[k]; ev[9 + k] = E.h_col_read_ts[k]; ev[12 + k] = E.h_val[k]; }
         const Fr j = joint(ev, "claim_evals_ops", "challenge_combine_n_to_one", "joint_claim_eval_ops", rand_ops, rj);
-        E.pe_ops = polyeval_prove_plain(c, *g.eval, g.ops, d.comb_ops.p, rj, j, tr, tape);
+        E.pe_ops = polyeval_prove_plain(c, *g.eval, g.ops, d.comb_ops.p, rj, j, tr, tape, chunks_o, 4);
     }
     lap("polyeval ops");
     {
