@@ -54,10 +54,14 @@ static void launch_eq_tree(DevCtx &c, const Fr *r0, size_t n0, bool pyr0, Fr *ou
     hipLaunchKernelGGL(k_eq_tree, dim3(groups, out1 ? 2u : 1u), kEqTreeBlock, 0, c.stream, a, b);
 }
 // out[i] = hi[i >> lo_bits] * lo[i & (2^lo_bits - 1)]  (index bits are MSB-first over r, so the product of two sub-tables is the table)
-__global__ __launch_bounds__(kBlock) void k_eq_expand(const Fr *hi, const Fr *lo, int lo_bits, Fr *out, size_t n) {
-    size_t mask = ((size_t)1 << lo_bits) - 1;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        out[i] = fr9_pack_lt2l(fr9_mul(fr9_unpack5(hi[i >> lo_bits]), fr9_unpack(lo[i & mask])));       // nine limbs (fr9.h): 32 hi * lo / 2^261 + l < 1.1 l
+// A thread keeps ONE lo entry unpacked and walks `per` hi entries (the same for the whole workgroup: scalar loads): per element one
+// nine-limb product and one pack, stores of 8 KB per workgroup and step.  per = 1 .. 16, so that small tables still fill the chip.
+__global__ __launch_bounds__(kBlock) void k_eq_expand(const Fr *__restrict__ hi, const Fr *__restrict__ lo, int lo_bits, Fr *__restrict__ out, size_t n_hi, size_t per) {
+    const size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x;                   // < 2^lo_bits (the grid's x is exact)
+    const Fr9 l9 = fr9_unpack(lo[j]);
+    const size_t h0 = (size_t)blockIdx.y * per, h1 = min(n_hi, h0 + per);
+    for (size_t h = h0; h < h1; h++)
+        out[(h << lo_bits) | j] = fr9_pack_lt2l(fr9_mul(fr9_unpack5(hi[h]), l9));     // nine limbs (fr9.h): 32 hi * lo / 2^261 + l < 1.1 l
 }
 // two tables of at most 13 variables each in ONE launch (the L and R halves of an evaluation point: every polynomial-evaluation proof starts with them)
 void dev_eq_evals2(DevCtx &c, const Fr *r0, size_t ell0, Fr *out0, const Fr *r1, size_t ell1, Fr *out1, Fr *scratch) {
@@ -72,8 +76,8 @@ void dev_eq_evals(DevCtx &c, const Fr *r, size_t ell, Fr *out, Fr *scratch) {
     if (hi_bits > 13) throw Error(OTTI_ERR_BAD_ARG, "eq table larger than 2^25");
     Fr *lo = scratch, *hi = scratch + 4096;                               // scratch >= 3 * 4096 elements (both factors in one launch, then their product)
     launch_eq_tree(c, r + hi_bits, lo_bits, false, lo, r, (size_t)hi_bits, false, hi);
-    size_t n = (size_t)1 << ell;
-    hipLaunchKernelGGL(k_eq_expand, grid_for(n), kBlock, 0, c.stream, hi, lo, lo_bits, out, n);
+    const size_t n_hi = (size_t)1 << hi_bits, per = std::min<size_t>(16, std::max<size_t>(1, n_hi / 128));       // >= 2048 workgroups where the table allows
+    hipLaunchKernelGGL(k_eq_expand, dim3((unsigned)(((size_t)1 << lo_bits) / kBlock), (unsigned)((n_hi + per - 1) / per)), kBlock, 0, c.stream, hi, lo, lo_bits, out, n_hi, per);
 }
 
 // ------------------------------------------------------------------------------------------------ K3/K4/K7 sum-check rounds
