@@ -146,10 +146,10 @@ void KStats::flush() {
 }
 void KStats::reset() { used = 0; for (int k = 0; k < KC_COUNT; k++) { total_ms[k] = 0; count[k] = 0; } }
 
-// A second stream for bandwidth-bound work queued beside a chain of latency-bound rounds (SNARK mode's hash-layer pass beside the memory
-// circuits' sum-check).  ONE per process, made on first use and kept, given back at exit like the bulk stream.  OTTI_SIDE_CUS=32..: confined to
-// the FIRST that many CUs (hipExtStreamCreateWithCUMask); measured at 32 / 64 / 96 against none, the rounds beside it cost the same (what they
-// lose is not CU time: profiles/r4_hash_layer_ab.txt), so the default is an ordinary stream.
+// A second stream for bandwidth-bound work queued beside a chain of latency-bound rounds (SNARK mode, opt-in OTTI_HASH_AHEAD=1: the hash
+// layer's pass beside the memory circuits' sum-check).  ONE per process, made on first use and kept, given back at exit like the bulk stream.
+// OTTI_SIDE_CUS=32..: confined to the FIRST that many CUs (hipExtStreamCreateWithCUMask); measured at 32 / 64 / 96 against none, the rounds
+// beside it cost the same (what they lose is not CU time: profiles/r4_hash_layer_ab.txt), so the default is an ordinary stream.
 static hipStream_t side_masked_stream() {
     static std::once_flag once; static hipStream_t ss = nullptr;
     std::call_once(once, [] {

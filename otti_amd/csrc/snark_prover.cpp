@@ -598,7 +598,7 @@ static std::vector<uint8_t> snark_prove_resident_once(Instance &I, CompComm &com
     // first-use HIP objects are made BEFORE the session narrows this thread's affinity to its helpers' L3 group (pool.h hold_caller): a thread
     // the runtime starts while making them would inherit the narrowed mask for good
     if (!sh && c.num_cu >= 128) (void)bulk_masked_stream();
-    if (!sh) (void)c.side_stream();
+    if (!sh && getenv("OTTI_HASH_AHEAD")) (void)c.side_stream();
     SpinPool::Session pool_session;
     struct Sharded { bool was; explicit Sharded(bool on) : was(t_sharded_proof) { t_sharded_proof = on; } ~Sharded() { t_sharded_proof = was; } } sharded_scope(sh != nullptr);
     if (!comm.dec) throw Error(OTTI_ERR_BAD_ARG, "this computation commitment carries no decommitment (it was parsed from bytes): SNARK::prove needs the one SNARK::encode returned");
@@ -782,11 +782,11 @@ static std::vector<uint8_t> snark_prove_resident_once(Instance &I, CompComm &com
     // committed vector is one CHUNK of rows of its polynomial's matrix, so ONE pass over the 21 vectors gives both the chunk sums of the proofs' bounds
     // (dev_poly_bound_chunks: P_c[j] = sum_i' eq(rand_ops[0 .. rest))[i'] v_c[i' R + j]) and, as dot products of length R with eq(rand_ops[rest ..]),
     // the 21 evaluations v_c(rand_ops) themselves — instead of a pass for the evaluations (with an eq table of N elements) and one per bound (3.1 GB
-    // -> 1.6 GB at 2^20: hash layer 3.11 -> 2.93 ms).  OTTI_HASH_FUSED=0: the separate passes as before.  That pass is queued on a second stream when
-    // rand_ops comes out and runs beside the memory circuits' sum-check, a chain of short rounds (hash layer 2.93 -> 2.62 ms, those rounds + 0.07 ms:
-    // profiles/r4_hash_layer_ab.txt; with the unfused 3.1 GB the rounds lost what the layer gained).  OTTI_HASH_AHEAD=0: on the proof's own stream.
+    // -> 1.6 GB at 2^20: hash layer 3.11 -> 2.9 ms).  OTTI_HASH_FUSED=0: the separate passes as before.  OTTI_HASH_AHEAD=1: that pass queued on a second
+    // stream when rand_ops comes out, beside the memory circuits' sum-check (hash layer 2.9 -> 2.6 ms, but those rounds lose 0.1-0.35 ms — more than
+    // that inside bench.py's SNARK leg, whatever CU mask the second stream has: profiles/r4_hash_layer_ab.txt; off by default).
     static const bool hash_fused_env = [] { const char *e = getenv("OTTI_HASH_FUSED"); return !(e && e[0] == '0'); }();
-    static const bool hash_ahead_env = [] { const char *e = getenv("OTTI_HASH_AHEAD"); return !(e && e[0] == '0'); }();
+    static const bool hash_ahead_env = [] { const char *e = getenv("OTTI_HASH_AHEAD"); return e && e[0] == '1'; }();
     const size_t lgN_ = ilog2(N);
     const bool hash_fused = hash_fused_env && g.derefs.num_vars == lgN_ + 3 && g.ops.num_vars == lgN_ + 4 && g.derefs.num_vars / 2 > 3 && g.ops.num_vars / 2 > 4 && g.derefs.L * g.derefs.R == 8 * N && g.ops.L * g.ops.R == 16 * N;
     const bool hash_ahead = hash_fused && hash_ahead_env && !sh && c.side_stream();

@@ -124,8 +124,8 @@ def test_snark_sweep_sizes_match_committed_oracle_digests(lg):
                                     (16, {"OTTI_DEREFS_AHEAD": "0"}), (16, {"OTTI_DEREFS_CUMASK": "0"}), (16, {"OTTI_DEREFS_FREE_CUS": "128"}), (16, {"OTTI_PC_LGT_MANY": "5", "OTTI_PC_LGT_FEW": "7"}),
                                     (16, {"OTTI_HOST_FR8": "0"}), (16, {"OTTI_PC_LGT_MANY": "4", "OTTI_PC_LGT_FEW": "8"}), (16, {"OTTI_RELAY": "0"}), (16, {"OTTI_GO_POLLERS": "4"}),
                                     (16, {"OTTI_HOST_THREADS": "1"}), (16, {"OTTI_HOST_TAIL_GRAIN": "8"}),
-                                    (16, {"OTTI_HASH_FUSED": "0"}), (16, {"OTTI_HASH_AHEAD": "0"}), (16, {"OTTI_PC_PREEXPORT": "0"}), (16, {"OTTI_SIDE_CUS": "64"}),
-                                    (12, {"OTTI_HASH_AHEAD": "0", "OTTI_PC_PREEXPORT": "0"}),
+                                    (16, {"OTTI_HASH_FUSED": "0"}), (16, {"OTTI_HASH_AHEAD": "1"}), (16, {"OTTI_PC_PREEXPORT": "0"}), (16, {"OTTI_HASH_AHEAD": "1", "OTTI_SIDE_CUS": "64"}),
+                                    (12, {"OTTI_HASH_AHEAD": "1", "OTTI_PC_PREEXPORT": "0"}),
                                     (12, {"OTTI_TEST_TAIL_DROP": "1", "OTTI_TAIL_TIMEOUT_MS": "300"})])
 def test_persistent_tail_variants_give_the_oracles_proof(lg, env):
     """The layered sum-checks of R1CSEvalProof three ways — a launch per round (tail off / nothing armed), the persistent tail with
@@ -135,7 +135,7 @@ def test_persistent_tail_variants_give_the_oracles_proof(lg, env):
     switched off, without the mask, with another split of the CUs, and the host tail of the sum-checks at other lengths, in its scalar form
     (OTTI_HOST_FR8=0), single-threaded and with every vector pair handed to a helper thread; the armed launches' hand-over in its older form
     (OTTI_RELAY=0) and with four pollers in the leader workgroup; the hash layer's evaluations and bounds as separate passes (OTTI_HASH_FUSED=0), the
-    fused pass on the proof's own stream (OTTI_HASH_AHEAD=0) or on a CU-masked second stream, the host-only layers exported one launch at a time."""
+    fused pass on a second stream beside the memory circuits' sum-check (OTTI_HASH_AHEAD=1), plain or CU-masked, the host-only layers exported one launch at a time."""
     import os, subprocess, sys
     g = _golden_snark()[1 << lg]
     e = dict(os.environ); e.update(env)

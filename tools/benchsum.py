@@ -9,5 +9,5 @@ for k, v in (d.get("sweep") or {}).items():
     if isinstance(v, dict) and "ms_per_proof" in v: print(" sweep", k, v["ms_per_proof"], "ms", v.get("stage_ms"), "ok" if v.get("equals_oracle_digest") else "DIGEST?")
 s = d.get("snark") or {}
 print("snark", {k: s.get(k) for k in ("ms_per_proof", "value", "verify_ms", "encode_ms", "equals_oracle_digest", "stage_ms")})
-print("in_flight", d.get("in_flight", {}).get("value"), "verify_ms", d.get("verify_ms"), "prepare_device_ms", d.get("prepare_device_ms"), "cpu", d.get("cpu_baseline", {}).get("value"))
+print("in_flight", (d.get("in_flight") or {}).get("value"), "verify_ms", d.get("verify_ms"), "prepare_device_ms", d.get("prepare_device_ms"), "cpu", (d.get("cpu_baseline") or {}).get("value"))
 print("e2e", d.get("spzk_e2e", {}).get("wall_ms"), "floor", d.get("hip_process_floor_ms"), "equals digest", d.get("equals_oracle_digest"), d.get("proof_sha256", "")[:12])
