@@ -10,4 +10,4 @@ for k, v in (d.get("sweep") or {}).items():
 s = d.get("snark") or {}
 print("snark", {k: s.get(k) for k in ("ms_per_proof", "value", "verify_ms", "encode_ms", "equals_oracle_digest", "stage_ms")})
 print("in_flight", (d.get("in_flight") or {}).get("value"), "verify_ms", d.get("verify_ms"), "prepare_device_ms", d.get("prepare_device_ms"), "cpu", (d.get("cpu_baseline") or {}).get("value"))
-print("e2e", d.get("spzk_e2e", {}).get("wall_ms"), "floor", d.get("hip_process_floor_ms"), "equals digest", d.get("equals_oracle_digest"), d.get("proof_sha256", "")[:12])
+print("e2e", (d.get("spzk_e2e") or {}).get("wall_ms"), "floor", d.get("hip_process_floor_ms"), "equals digest", d.get("equals_oracle_digest"), d.get("proof_sha256", "")[:12])
