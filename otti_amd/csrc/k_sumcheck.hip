@@ -351,27 +351,52 @@ void dev_dot(DevCtx &c, const Fr *a, const Fr *b, size_t n, int slot) {
 }
 
 // ------------------------------------------------------------------------------------------------ K9 DensePolynomial::bound
-__global__ __launch_bounds__(kBlock) void k_poly_bound_slab(const Fr *Z, size_t L, size_t R, const Fr *Lv, size_t rows_per_slab, Fr *scratch, size_t lv_mask) {
-    size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (j >= R) return;
-    size_t i0 = blockIdx.y * rows_per_slab, i1 = min(L, i0 + rows_per_slab);
-    Fr acc = fr_zero();
-    for (size_t i = i0; i < i1; i++) acc = fr_add(acc, fr_mul(Lv[i & lv_mask], Z[i * R + j]));
-    scratch[(size_t)blockIdx.y * R + j] = acc;
+// A workgroup is 2^lanes_log2 row lanes x (kBlock >> lanes_log2) columns (>= 64 columns: a wave has one lane): lane l takes rows l, l + lanes, ...
+// of its slab, the lanes' sums meet in LDS.  More, shorter threads where the matrix is small (2^20: 16 dependent products per thread on one wave per
+// SIMD became 4 on four) — sums of field elements, so the result does not depend on the split.
+template <int K> __device__ __forceinline__ Fr lanes_sum(Fr acc, int lane, int lanes, int cols) {
+    __shared__ Fr sm[K][kBlock];
+    if (lanes > 1) {
+        sm[0][threadIdx.x] = acc;
+        __syncthreads();
+        for (int s = lanes >> 1; s >= 1; s >>= 1) {
+            if (lane < s) { acc = fr_add(acc, sm[0][threadIdx.x + s * cols]); sm[0][threadIdx.x] = acc; }
+            __syncthreads();
+        }
+    }
+    return acc;
 }
+__global__ __launch_bounds__(kBlock) void k_poly_bound_slab(const Fr *Z, size_t L, size_t R, const Fr *Lv, size_t rows_per_slab, Fr *scratch, size_t lv_mask, int lanes_log2) {
+    const int lanes = 1 << lanes_log2, cols = kBlock >> lanes_log2, lane = (int)threadIdx.x / cols, cj = (int)threadIdx.x % cols;
+    const size_t j = blockIdx.x * (size_t)cols + cj;
+    const size_t i0 = blockIdx.y * rows_per_slab, i1 = min(L, i0 + rows_per_slab);
+    Fr acc = fr_zero();
+    if (j < R) for (size_t i = i0 + lane; i < i1; i += lanes) acc = fr_add(acc, fr_mul(Lv[i & lv_mask], Z[i * R + j]));
+    acc = lanes_sum<1>(acc, lane, lanes, cols);
+    if (lane == 0 && j < R) scratch[(size_t)blockIdx.y * R + j] = acc;
+}
+constexpr int kColsumLanesLog2 = 3;                          // 8 lanes x 32 columns: 8 + 3 dependent additions for 64 slabs instead of 63
 __global__ __launch_bounds__(kBlock) void k_colsum(const Fr *scratch, size_t slabs, size_t R, Fr *out) {
-    size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (j >= R) return;
-    Fr acc = scratch[j];
-    for (size_t s = 1; s < slabs; s++) acc = fr_add(acc, scratch[s * R + j]);
-    out[j] = acc;
+    const int lanes = 1 << kColsumLanesLog2, cols = kBlock >> kColsumLanesLog2, lane = (int)threadIdx.x / cols, cj = (int)threadIdx.x % cols;
+    const size_t j = blockIdx.x * (size_t)cols + cj;
+    Fr acc = fr_zero();
+    if (j < R) for (size_t s = lane; s < slabs; s += lanes) acc = fr_add(acc, scratch[s * R + j]);
+    acc = lanes_sum<1>(acc, lane, lanes, cols);
+    if (lane == 0 && j < R) out[j] = acc;
+}
+// row lanes per workgroup of the slab kernel: as many (up to 4) as keep every lane at least two rows and the launch below ~2048 workgroups
+static int bound_lanes_log2(size_t R, size_t slabs, size_t rps) {
+    int lg = 0;
+    while (lg < 2 && ((size_t)2 << lg) * 2 <= rps && ((R + (kBlock >> (lg + 1)) - 1) / (kBlock >> (lg + 1))) * slabs <= 2048) lg++;
+    return lg;
 }
 void dev_poly_bound(DevCtx &c, const Fr *Z, size_t L, size_t R, const Fr *Lv, Fr *out, Fr *scratch) {
     size_t slabs = std::min<size_t>(L, 64), rps = (L + slabs - 1) / slabs;
     KScope ks(c, KC_BOUND);
-    dim3 grid((unsigned)((R + kBlock - 1) / kBlock), (unsigned)slabs);
-    hipLaunchKernelGGL(k_poly_bound_slab, grid, kBlock, 0, c.stream, Z, L, R, Lv, rps, scratch, ~(size_t)0);
-    hipLaunchKernelGGL(k_colsum, (unsigned)((R + kBlock - 1) / kBlock), kBlock, 0, c.stream, (const Fr *)scratch, slabs, R, out);
+    const int ll = bound_lanes_log2(R, slabs, rps); const size_t cols = (size_t)kBlock >> ll, ccols = (size_t)kBlock >> kColsumLanesLog2;
+    dim3 grid((unsigned)((R + cols - 1) / cols), (unsigned)slabs);
+    hipLaunchKernelGGL(k_poly_bound_slab, grid, kBlock, 0, c.stream, Z, L, R, Lv, rps, scratch, ~(size_t)0, ll);
+    hipLaunchKernelGGL(k_colsum, (unsigned)((R + ccols - 1) / ccols), kBlock, 0, c.stream, (const Fr *)scratch, slabs, R, out);
 }
 // The same bound in two steps, for an evaluation point whose FIRST variables are not known yet: with the left table L = eq(first a variables) x eq(rest),
 //     (L^T Z)[j] = sum_c eq(first)[c] * P_c[j],   P_c[j] = sum_i' eq(rest)[i'] Z[(c m + i') R + j]     (m = 2^(variables of rest) rows per chunk).
@@ -388,8 +413,9 @@ bool dev_poly_bound_chunks(DevCtx &c, const Fr *Z, size_t L, size_t R, const Fr 
     const size_t slabs = std::min<size_t>(L, 64), rps = (L + slabs - 1) / slabs;
     if (!m || (m & (m - 1)) || m > L || L % m || m % rps || slabs * rps != L) return false;        // (chunks must be whole groups of slabs)
     KScope ks(c, KC_BOUND);
-    dim3 grid((unsigned)((R + kBlock - 1) / kBlock), (unsigned)slabs);
-    hipLaunchKernelGGL(k_poly_bound_slab, grid, kBlock, 0, c.stream, Z, L, R, Lv_rest, rps, scratch, m - 1);
+    const int ll = bound_lanes_log2(R, slabs, rps); const size_t cols = (size_t)kBlock >> ll;
+    dim3 grid((unsigned)((R + cols - 1) / cols), (unsigned)slabs);
+    hipLaunchKernelGGL(k_poly_bound_slab, grid, kBlock, 0, c.stream, Z, L, R, Lv_rest, rps, scratch, m - 1, ll);
     hipLaunchKernelGGL(k_colsum_groups, dim3((unsigned)((R + kBlock - 1) / kBlock), (unsigned)(L / m)), kBlock, 0, c.stream, (const Fr *)scratch, m / rps, R, out);
     return true;
 }
